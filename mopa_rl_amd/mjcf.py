@@ -1,0 +1,528 @@
+"""MJCF-subset scene compiler: XML model -> flat kinematic/collision arrays.
+
+The reference loads its scene with MuJoCo's own XML compiler
+(`mj_loadXML`, reference motion_planners/include/mujoco_wrapper.h:75 and
+motion_planners/KinematicPlanner.cpp:72).  MuJoCo is not available to this
+build, so this module re-implements the part of the MJCF compile step the
+state-validity path needs:
+
+  * ``<include>`` expansion (paths relative to the top-level model file),
+  * nested ``<default class=...>`` inheritance + ``childclass`` scoping,
+  * the body tree in depth-first document order (MuJoCo's body/geom/joint id
+    order), hinge / slide / free joints with their qpos addresses,
+  * primitive geoms (plane, sphere, capsule, cylinder, box; ``fromto``),
+    ``contype`` / ``conaffinity``, ``<contact><exclude>``,
+  * the *static* candidate collision-pair list after MuJoCo's filters
+    (same body, same weld group, parent-child weld groups unless the parent
+    group is the world, excludes, ``(ct1&ca2)|(ct2&ca1)``) -- see
+    SURVEY.md Appendix D [3P].
+
+Everything here is plain Python + numpy; nothing is on the hot path.  The
+result is a :class:`CompiledModel`, serialisable to a small JSON file
+(``mopa_rl_amd/scenes/*.json``) so that the GPU box -- which has no access to
+the reference's asset directory -- loads the same numbers.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+import xml.etree.ElementTree as ET
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+# MuJoCo enum values (mjtGeom / mjtJoint) -- kept so geom/joint type codes mean
+# the same thing on both sides of the boundary.
+GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_ELLIPSOID, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = range(8)
+JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = range(4)
+
+_GEOM_TYPES = {
+    "plane": GEOM_PLANE, "hfield": GEOM_HFIELD, "sphere": GEOM_SPHERE, "capsule": GEOM_CAPSULE,
+    "ellipsoid": GEOM_ELLIPSOID, "cylinder": GEOM_CYLINDER, "box": GEOM_BOX, "mesh": GEOM_MESH,
+}
+_JNT_TYPES = {"free": JNT_FREE, "ball": JNT_BALL, "slide": JNT_SLIDE, "hinge": JNT_HINGE}
+GEOM_TYPE_NAMES = {v: k for k, v in _GEOM_TYPES.items()}
+
+SUPPORTED_COLLISION_TYPES = (GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX)
+
+
+class MjcfError(ValueError):
+    pass
+
+
+def _floats(s: str) -> List[float]:
+    return [float(x) for x in s.replace(",", " ").split()]
+
+
+def _quat_mul(a, b):
+    aw, ax, ay, az = a
+    bw, bx, by, bz = b
+    return np.array([
+        aw * bw - ax * bx - ay * by - az * bz,
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by - ax * bz + ay * bw + az * bx,
+        aw * bz + ax * by - ay * bx + az * bw,
+    ])
+
+
+def _normalize_quat(q):
+    q = np.asarray(q, dtype=np.float64)
+    n = math.sqrt(float(q @ q))
+    if n < 1e-15:
+        return np.array([1.0, 0.0, 0.0, 0.0])
+    return q / n
+
+
+def _euler_to_quat(e, seq: str, to_rad: float):
+    """MuJoCo `eulerseq`: lower-case = intrinsic (rotating-frame) axes."""
+    q = np.array([1.0, 0.0, 0.0, 0.0])
+    for ang, ax in zip(e, seq):
+        h = 0.5 * ang * to_rad
+        r = np.array([math.cos(h), 0.0, 0.0, 0.0])
+        r["xyz".index(ax.lower()) + 1] = math.sin(h)
+        q = _quat_mul(q, r) if ax.islower() else _quat_mul(r, q)
+    return q
+
+
+def _z_to_vec_quat(v):
+    """Quaternion rotating +z onto unit vector ``v`` (MuJoCo's fromto rule)."""
+    v = np.asarray(v, dtype=np.float64)
+    v = v / np.linalg.norm(v)
+    z = np.array([0.0, 0.0, 1.0])
+    axis = np.cross(z, v)
+    s = np.linalg.norm(axis)
+    c = float(z @ v)
+    if s < 1e-10:
+        # parallel / anti-parallel
+        return np.array([1.0, 0.0, 0.0, 0.0]) if c > 0 else np.array([0.0, 1.0, 0.0, 0.0])
+    axis = axis / s
+    ang = math.atan2(s, c)
+    return np.array([math.cos(ang / 2), *(axis * math.sin(ang / 2))])
+
+
+@dataclass
+class CompiledModel:
+    """Flat arrays describing kinematics + collision geometry of one scene."""
+    name: str
+    nq: int
+    # bodies (index 0 = world)
+    body_names: List[str]
+    body_parent: np.ndarray      # [nbody] i32
+    body_pos: np.ndarray         # [nbody,3]
+    body_quat: np.ndarray        # [nbody,4] normalised wxyz
+    body_jntadr: np.ndarray      # [nbody] first joint id or -1
+    body_jntnum: np.ndarray      # [nbody]
+    body_weldid: np.ndarray      # [nbody]
+    # joints
+    jnt_names: List[str]
+    jnt_type: np.ndarray         # [njnt]
+    jnt_qposadr: np.ndarray      # [njnt]
+    jnt_body: np.ndarray         # [njnt]
+    jnt_axis: np.ndarray         # [njnt,3] normalised
+    jnt_pos: np.ndarray          # [njnt,3]
+    jnt_ref: np.ndarray          # [njnt] qpos0 for hinge/slide
+    jnt_limited: np.ndarray      # [njnt]
+    jnt_range: np.ndarray        # [njnt,2]
+    qpos0: np.ndarray            # [nq]
+    # all geoms (MuJoCo id order) -- names only, for name2id parity
+    all_geom_names: List[str]
+    all_geom_body: np.ndarray    # [ngeom_all]
+    # collidable geoms (contype|conaffinity != 0)
+    geom_mjid: np.ndarray        # [ngeom] id among all geoms
+    geom_type: np.ndarray        # [ngeom]
+    geom_body: np.ndarray        # [ngeom]
+    geom_size: np.ndarray        # [ngeom,3]
+    geom_pos: np.ndarray         # [ngeom,3]
+    geom_quat: np.ndarray        # [ngeom,4]
+    geom_contype: np.ndarray
+    geom_conaffinity: np.ndarray
+    geom_margin: np.ndarray
+    geom_mesh: List[str]         # mesh asset name or ""
+    # candidate pairs after static filters: indices into the collidable table,
+    # ordered (type1<=type2, then id) as MuJoCo orders geom1/geom2 of a contact
+    pair_geom: np.ndarray        # [npair,2]
+    # sites
+    site_names: List[str]
+    site_body: np.ndarray
+    site_pos: np.ndarray
+    site_quat: np.ndarray
+    meta: Dict[str, object] = field(default_factory=dict)
+
+    # ---- name lookups mirroring the mujoco-py calls the reference makes ----
+    def geom_name2id(self, name: str) -> int:
+        return self.all_geom_names.index(name)
+
+    def body_name2id(self, name: str) -> int:
+        return self.body_names.index(name)
+
+    def joint_name2id(self, name: str) -> int:
+        return self.jnt_names.index(name)
+
+    def site_name2id(self, name: str) -> int:
+        return self.site_names.index(name)
+
+    def get_joint_qpos_addr(self, name: str) -> int:
+        return int(self.jnt_qposadr[self.joint_name2id(name)])
+
+    def geoms_of_bodies(self, body_names: List[str]) -> List[int]:
+        """MuJoCo geom ids of every geom attached to the named bodies
+        (reference env/base.py `static_geom_ids`)."""
+        ids = [self.body_name2id(b) for b in body_names]
+        return [g for g, b in enumerate(self.all_geom_body) if int(b) in ids]
+
+    # ---- serialisation ----
+    _ARRAYS = (
+        "body_parent body_pos body_quat body_jntadr body_jntnum body_weldid jnt_type jnt_qposadr jnt_body "
+        "jnt_axis jnt_pos jnt_ref jnt_limited jnt_range qpos0 all_geom_body geom_mjid geom_type geom_body "
+        "geom_size geom_pos geom_quat geom_contype geom_conaffinity geom_margin pair_geom site_body site_pos "
+        "site_quat"
+    ).split()
+    _LISTS = "body_names jnt_names all_geom_names geom_mesh site_names".split()
+
+    def to_json(self) -> str:
+        d = {"name": self.name, "nq": self.nq, "meta": self.meta}
+        for k in self._LISTS:
+            d[k] = getattr(self, k)
+        for k in self._ARRAYS:
+            a = getattr(self, k)
+            d[k] = {"dtype": str(a.dtype), "shape": list(a.shape),
+                    "data": [float(x).hex() if a.dtype.kind == "f" else int(x) for x in a.ravel()]}
+        return json.dumps(d, indent=None, separators=(",", ":"))
+
+    @classmethod
+    def from_json(cls, s: str) -> "CompiledModel":
+        d = json.loads(s)
+        kw = {"name": d["name"], "nq": d["nq"], "meta": d.get("meta", {})}
+        for k in cls._LISTS:
+            kw[k] = list(d[k])
+        for k in cls._ARRAYS:
+            e = d[k]
+            if e["dtype"].startswith("float"):
+                a = np.array([float.fromhex(x) for x in e["data"]], dtype=np.float64)
+            else:
+                a = np.array(e["data"], dtype=np.int32)
+            kw[k] = a.reshape(e["shape"])
+        return cls(**kw)
+
+    def save(self, path: str) -> None:
+        with open(path, "w") as f:
+            f.write(self.to_json())
+
+    @classmethod
+    def load(cls, path: str) -> "CompiledModel":
+        with open(path) as f:
+            return cls.from_json(f.read())
+
+
+# --------------------------------------------------------------------------
+# XML front end
+# --------------------------------------------------------------------------
+def _expand_includes(elem: ET.Element, base_dir: str) -> None:
+    """Replace every <include file=.../> by the children of the included root.
+    MuJoCo resolves include paths relative to the top-level model file."""
+    i = 0
+    while i < len(elem):
+        child = elem[i]
+        if child.tag == "include":
+            path = os.path.join(base_dir, child.attrib["file"])
+            sub = ET.parse(path).getroot()
+            _expand_includes(sub, base_dir)
+            elem.remove(child)
+            for k, sc in enumerate(list(sub)):
+                elem.insert(i + k, sc)
+            i += len(list(sub))
+        else:
+            _expand_includes(child, base_dir)
+            i += 1
+
+
+class _Defaults:
+    """Default-class tree: class name -> {tag -> attrib dict}, with parents."""
+
+    def __init__(self):
+        self.classes: Dict[str, Dict[str, Dict[str, str]]] = {"main": {}}
+        self.parent: Dict[str, Optional[str]] = {"main": None}
+
+    def add_section(self, elem: ET.Element, cls: str = "main") -> None:
+        for ch in elem:
+            if ch.tag == "default":
+                name = ch.attrib.get("class")
+                if name is None:
+                    raise MjcfError("nested <default> without class")
+                if name not in self.classes:
+                    self.classes[name] = {}
+                    self.parent[name] = cls
+                self.add_section(ch, name)
+            else:
+                self.classes[cls].setdefault(ch.tag, {}).update(ch.attrib)
+
+    def resolve(self, cls: Optional[str], tag: str) -> Dict[str, str]:
+        chain = []
+        c = cls or "main"
+        if c not in self.classes:
+            raise MjcfError(f"unknown default class {c!r}")
+        while c is not None:
+            chain.append(c)
+            c = self.parent[c]
+        out: Dict[str, str] = {}
+        for c in reversed(chain):
+            out.update(self.classes[c].get(tag, {}))
+        return out
+
+
+class _Builder:
+    def __init__(self, xml_path: str):
+        self.xml_path = xml_path
+        root = ET.parse(xml_path).getroot()
+        if root.tag != "mujoco":
+            raise MjcfError("top-level element must be <mujoco>")
+        _expand_includes(root, os.path.dirname(os.path.abspath(xml_path)))
+        self.root = root
+        self.model_name = root.attrib.get("model", os.path.basename(xml_path))
+        comp: Dict[str, str] = {}
+        for c in root.findall("compiler"):
+            comp.update(c.attrib)
+        self.to_rad = 1.0 if comp.get("angle", "degree") == "radian" else math.pi / 180.0
+        self.eulerseq = comp.get("eulerseq", "xyz")
+        self.defaults = _Defaults()
+        for d in root.findall("default"):
+            self.defaults.add_section(d)
+        # accumulators
+        self.bodies: List[dict] = []
+        self.joints: List[dict] = []
+        self.geoms: List[dict] = []
+        self.sites: List[dict] = []
+        self.nq = 0
+
+    # orientation of a frame-bearing element
+    def _orient(self, at: Dict[str, str]) -> np.ndarray:
+        if "quat" in at:
+            return _normalize_quat(_floats(at["quat"]))
+        if "euler" in at:
+            return _normalize_quat(_euler_to_quat(_floats(at["euler"]), self.eulerseq, self.to_rad))
+        for k in ("axisangle", "xyaxes", "zaxis"):
+            if k in at:
+                raise MjcfError(f"orientation attribute {k!r} not supported by this MJCF subset")
+        return np.array([1.0, 0.0, 0.0, 0.0])
+
+    def _attrs(self, elem: ET.Element, childclass: Optional[str]) -> Dict[str, str]:
+        cls = elem.attrib.get("class", childclass)
+        at = dict(self.defaults.resolve(cls, elem.tag))
+        at.update(elem.attrib)
+        return at
+
+    def build(self) -> CompiledModel:
+        world = {"name": "world", "parent": 0, "pos": np.zeros(3), "quat": np.array([1.0, 0, 0, 0]),
+                 "jntadr": -1, "jntnum": 0}
+        self.bodies.append(world)
+        # world-level elements of every <worldbody> section, in document order
+        wbs = self.root.findall("worldbody")
+        for wb in wbs:
+            self._body_contents(wb, 0, None, recurse=False)
+        for wb in wbs:
+            for ch in wb:
+                if ch.tag == "body":
+                    self._body(ch, 0, None)
+        return self._finish()
+
+    def _body_contents(self, elem: ET.Element, bid: int, childclass: Optional[str], recurse: bool = True) -> None:
+        for ch in elem:
+            if ch.tag in ("joint", "freejoint"):
+                self._joint(ch, bid, childclass)
+            elif ch.tag == "geom":
+                self._geom(ch, bid, childclass)
+            elif ch.tag == "site":
+                self._site(ch, bid, childclass)
+
+    def _body(self, elem: ET.Element, parent: int, childclass: Optional[str]) -> None:
+        childclass = elem.attrib.get("childclass", childclass)
+        bid = len(self.bodies)
+        b = {"name": elem.attrib.get("name", f"body{bid}"), "parent": parent,
+             "pos": np.array(_floats(elem.attrib.get("pos", "0 0 0")), dtype=np.float64),
+             "quat": self._orient(elem.attrib), "jntadr": -1, "jntnum": 0}
+        self.bodies.append(b)
+        self._body_contents(elem, bid, childclass)
+        for ch in elem:
+            if ch.tag == "body":
+                self._body(ch, bid, childclass)
+
+    def _joint(self, elem: ET.Element, bid: int, childclass: Optional[str]) -> None:
+        if elem.tag == "freejoint":
+            at = dict(elem.attrib)
+            jtype = JNT_FREE
+        else:
+            at = self._attrs(elem, childclass)
+            jtype = _JNT_TYPES[at.get("type", "hinge")]
+        jid = len(self.joints)
+        axis = np.array(_floats(at.get("axis", "0 0 1")), dtype=np.float64)
+        n = np.linalg.norm(axis)
+        if jtype in (JNT_HINGE, JNT_SLIDE):
+            if n < 1e-12:
+                raise MjcfError("zero joint axis")
+            axis = axis / n
+        ref = float(at.get("ref", "0"))
+        rng = _floats(at.get("range", "0 0"))
+        if jtype == JNT_HINGE:
+            ref *= self.to_rad
+            rng = [r * self.to_rad for r in rng]
+        limited = at.get("limited", "false") == "true"
+        j = {"name": at.get("name", f"joint{jid}"), "type": jtype, "qposadr": self.nq, "body": bid,
+             "axis": axis, "pos": np.array(_floats(at.get("pos", "0 0 0")), dtype=np.float64),
+             "ref": ref, "limited": int(limited), "range": np.array(rng, dtype=np.float64)}
+        self.joints.append(j)
+        body = self.bodies[bid]
+        if body["jntnum"] == 0:
+            body["jntadr"] = jid
+        body["jntnum"] += 1
+        self.nq += {JNT_FREE: 7, JNT_BALL: 4, JNT_SLIDE: 1, JNT_HINGE: 1}[jtype]
+
+    def _geom(self, elem: ET.Element, bid: int, childclass: Optional[str]) -> None:
+        at = self._attrs(elem, childclass)
+        gtype = _GEOM_TYPES[at.get("type", "sphere")]
+        size = _floats(at.get("size", "0 0 0"))
+        size = (size + [0.0, 0.0, 0.0])[:3]
+        pos = np.array(_floats(at.get("pos", "0 0 0")), dtype=np.float64)
+        quat = self._orient(at)
+        if "fromto" in at:
+            ft = np.array(_floats(at["fromto"]), dtype=np.float64)
+            a, b = ft[:3], ft[3:]
+            pos = 0.5 * (a + b)
+            quat = _z_to_vec_quat(b - a)
+            half = 0.5 * float(np.linalg.norm(b - a))
+            if gtype in (GEOM_CAPSULE, GEOM_CYLINDER):
+                size = [size[0], half, 0.0]
+            elif gtype in (GEOM_BOX, GEOM_ELLIPSOID):
+                size = [size[0], size[0], half]
+            else:
+                raise MjcfError("fromto on unsupported geom type")
+        # canonicalise unused size slots so equal shapes compare equal
+        if gtype == GEOM_SPHERE:
+            size = [size[0], 0.0, 0.0]
+        elif gtype in (GEOM_CAPSULE, GEOM_CYLINDER):
+            size = [size[0], size[1], 0.0]
+        g = {"name": at.get("name", ""), "type": gtype, "body": bid, "size": np.array(size, dtype=np.float64),
+             "pos": pos, "quat": quat, "contype": int(at.get("contype", "1")),
+             "conaffinity": int(at.get("conaffinity", "1")), "margin": float(at.get("margin", "0")),
+             "mesh": at.get("mesh", "")}
+        self.geoms.append(g)
+
+    def _site(self, elem: ET.Element, bid: int, childclass: Optional[str]) -> None:
+        at = self._attrs(elem, childclass)
+        self.sites.append({"name": at.get("name", ""), "body": bid,
+                           "pos": np.array(_floats(at.get("pos", "0 0 0")), dtype=np.float64),
+                           "quat": self._orient(at)})
+
+    # ----------------------------------------------------------------------
+    def _finish(self) -> CompiledModel:
+        # MuJoCo lists geoms/joints/sites in body-id (DFS) order.  Elements of a
+        # body were appended while visiting it, except world-level elements
+        # which were all appended first -- i.e. already body-ordered.
+        order = sorted(range(len(self.geoms)), key=lambda i: (self.geoms[i]["body"], i))
+        geoms = [self.geoms[i] for i in order]
+        nb = len(self.bodies)
+        parent = np.array([b["parent"] for b in self.bodies], dtype=np.int32)
+        jntnum = np.array([b["jntnum"] for b in self.bodies], dtype=np.int32)
+        weld = np.zeros(nb, dtype=np.int32)
+        for b in range(1, nb):
+            weld[b] = b if jntnum[b] > 0 else weld[parent[b]]
+
+        excludes = set()
+        names = [b["name"] for b in self.bodies]
+        for c in self.root.findall("contact"):
+            for ex in c.findall("exclude"):
+                b1, b2 = names.index(ex.attrib["body1"]), names.index(ex.attrib["body2"])
+                excludes.add((min(b1, b2), max(b1, b2)))
+
+        coll = [i for i, g in enumerate(geoms) if g["contype"] != 0 or g["conaffinity"] != 0]
+        pairs: List[Tuple[int, int]] = []
+        for a in range(len(coll)):
+            for b in range(a + 1, len(coll)):
+                g1, g2 = geoms[coll[a]], geoms[coll[b]]
+                b1, b2 = g1["body"], g2["body"]
+                if b1 == b2:
+                    continue
+                if not ((g1["contype"] & g2["conaffinity"]) or (g2["contype"] & g1["conaffinity"])):
+                    continue
+                w1, w2 = int(weld[b1]), int(weld[b2])
+                if w1 == w2:
+                    continue
+                pw1, pw2 = int(weld[parent[w1]]), int(weld[parent[w2]])
+                if w1 != 0 and w2 != 0 and (w1 == pw2 or w2 == pw1):
+                    continue
+                if (min(b1, b2), max(b1, b2)) in excludes:
+                    continue
+                # MuJoCo orders the two geoms of a contact by type, then id
+                if g1["type"] > g2["type"]:
+                    pairs.append((b, a))
+                else:
+                    pairs.append((a, b))
+
+        qpos0 = np.zeros(self.nq)
+        for j in self.joints:
+            a = j["qposadr"]
+            if j["type"] == JNT_FREE:
+                body = self.bodies[j["body"]]
+                qpos0[a:a + 3] = body["pos"]
+                qpos0[a + 3:a + 7] = body["quat"]
+            elif j["type"] == JNT_BALL:
+                qpos0[a:a + 4] = [1, 0, 0, 0]
+            else:
+                qpos0[a] = j["ref"]
+
+        def arr(lst, key, dt, shape=None):
+            a = np.array([x[key] for x in lst], dtype=dt)
+            if shape is not None:
+                a = a.reshape(shape)
+            return a
+
+        cg = [geoms[i] for i in coll]
+        nj = len(self.joints)
+        jr = np.zeros((nj, 2))
+        for i, j in enumerate(self.joints):
+            if len(j["range"]) == 2:
+                jr[i] = j["range"]
+        return CompiledModel(
+            name=self.model_name, nq=self.nq,
+            body_names=names, body_parent=parent,
+            body_pos=arr(self.bodies, "pos", np.float64, (nb, 3)),
+            body_quat=arr(self.bodies, "quat", np.float64, (nb, 4)),
+            body_jntadr=arr(self.bodies, "jntadr", np.int32), body_jntnum=jntnum, body_weldid=weld,
+            jnt_names=[j["name"] for j in self.joints],
+            jnt_type=arr(self.joints, "type", np.int32), jnt_qposadr=arr(self.joints, "qposadr", np.int32),
+            jnt_body=arr(self.joints, "body", np.int32),
+            jnt_axis=arr(self.joints, "axis", np.float64, (nj, 3)),
+            jnt_pos=arr(self.joints, "pos", np.float64, (nj, 3)),
+            jnt_ref=arr(self.joints, "ref", np.float64), jnt_limited=arr(self.joints, "limited", np.int32),
+            jnt_range=jr, qpos0=qpos0,
+            all_geom_names=[g["name"] for g in geoms],
+            all_geom_body=arr(geoms, "body", np.int32),
+            geom_mjid=np.array(coll, dtype=np.int32),
+            geom_type=arr(cg, "type", np.int32), geom_body=arr(cg, "body", np.int32),
+            geom_size=arr(cg, "size", np.float64, (len(cg), 3)),
+            geom_pos=arr(cg, "pos", np.float64, (len(cg), 3)),
+            geom_quat=arr(cg, "quat", np.float64, (len(cg), 4)),
+            geom_contype=arr(cg, "contype", np.int32), geom_conaffinity=arr(cg, "conaffinity", np.int32),
+            geom_margin=arr(cg, "margin", np.float64),
+            geom_mesh=[g["mesh"] for g in cg],
+            pair_geom=np.array(pairs, dtype=np.int32).reshape(-1, 2),
+            site_names=[s["name"] for s in self.sites],
+            site_body=arr(self.sites, "body", np.int32),
+            site_pos=arr(self.sites, "pos", np.float64, (len(self.sites), 3)),
+            site_quat=arr(self.sites, "quat", np.float64, (len(self.sites), 4)),
+            meta={"source": os.path.basename(self.xml_path)},
+        )
+
+
+def compile_mjcf(xml_path: str) -> CompiledModel:
+    """Compile an MJCF file (subset, see module docstring) to flat arrays."""
+    return _Builder(xml_path).build()
+
+
+def pair_type_histogram(m: CompiledModel) -> Dict[str, int]:
+    h: Dict[str, int] = {}
+    for a, b in m.pair_geom:
+        k = f"{GEOM_TYPE_NAMES[int(m.geom_type[a])]}-{GEOM_TYPE_NAMES[int(m.geom_type[b])]}"
+        h[k] = h.get(k, 0) + 1
+    return h

@@ -1,0 +1,91 @@
+/*
+ * mopa_oracle.h -- CPU oracle for the MoPA-RL state-validity hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / reported CPU baseline.
+ *
+ * PARITY UNPINNED: the arithmetic of the reference path lives in MuJoCo 2.0
+ * (closed-source libmujoco200.so) and OMPL (unpinned git HEAD); neither is in
+ * /root/reference nor in this image, and the reference ships no tests or
+ * golden vectors.  This file restates the published
+ * algorithms those libraries implement for the functions the reference calls
+ * (file:line citations on each function in mopa_oracle.c) and is pinned only
+ * against closed-form geometry, independent numpy/scipy re-derivations and
+ * self-consistency invariants (tests/test_oracle_*.py).
+ */
+#ifndef MOPA_ORACLE_H
+#define MOPA_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* "no intersection found" sentinel returned by pair distance functions that
+ * only resolve penetration (SAT / MPR pairs) and by min_dist when no pair
+ * survives the broad phase. */
+#define ORC_FAR 1.0e10
+
+typedef struct OrcScene OrcScene;
+
+/* Flat scene description == mopa_rl_amd.mjcf.CompiledModel arrays. */
+OrcScene *orc_scene_create(
+    int nq, int nbody, const int32_t *body_parent, const double *body_pos, const double *body_quat,
+    const int32_t *body_jntadr, const int32_t *body_jntnum,
+    int njnt, const int32_t *jnt_type, const int32_t *jnt_qposadr, const double *jnt_axis,
+    const double *jnt_pos, const double *jnt_ref, const int32_t *jnt_limited, const double *jnt_range,
+    int ngeom, const int32_t *geom_type, const int32_t *geom_body, const int32_t *geom_mjid,
+    const double *geom_size, const double *geom_pos, const double *geom_quat,
+    int npair, const int32_t *pair_geom,
+    int n_passive, const int32_t *passive_qpos_idx,
+    int n_ignored, const int32_t *ignored_pairs /* [n,2] MuJoCo geom ids, ordered */,
+    double contact_threshold);
+void orc_scene_destroy(OrcScene *s);
+int orc_num_active(const OrcScene *s);
+void orc_active_idx(const OrcScene *s, int32_t *out);
+
+/* deterministic sin/cos shared (as a specification) with the HIP kernels */
+void orc_sincos(double x, double *s, double *c);
+
+/* FK: qpos[nq] -> world pose of every collidable geom */
+void orc_fk(const OrcScene *s, const double *qpos, double *geom_xpos /*[ngeom,3]*/, double *geom_xmat /*[ngeom,9]*/);
+/* FK of every body: xpos[nbody,3], xquat[nbody,4] */
+void orc_fk_bodies(const OrcScene *s, const double *qpos, double *xpos, double *xquat);
+
+/* signed distance of two posed primitives (types ordered t1<=t2) */
+double orc_geom_dist(int t1, const double *size1, const double *pos1, const double *mat1,
+                     int t2, const double *size2, const double *pos2, const double *mat2);
+
+/* per-pair distances for one state; culled pairs get ORC_FAR */
+void orc_pair_dist(const OrcScene *s, const double *qpos, double *dist /*[npair]*/);
+
+/* the validity rule; returns 1 valid / 0 invalid; *min_dist over non-ignored pairs */
+int orc_is_valid(const OrcScene *s, const double *qpos, double *min_dist);
+
+/* batch: sample i uses qpos_env[env_of(i)] with active entries replaced by q_active[i] */
+void orc_is_valid_batch(const OrcScene *s, const double *q_active /*[N,na]*/, const double *qpos_env /*[E,nq]*/,
+                        int64_t N, int64_t samples_per_env, uint8_t *valid, double *min_dist /*nullable*/,
+                        int nthreads);
+
+/* OMPL DiscreteMotionValidator restated: 1 = motion valid */
+int orc_check_motion(const OrcScene *s, const double *qpos_env, const double *qa, const double *qb,
+                     double resolution, int64_t *n_checks);
+void orc_check_motion_batch(const OrcScene *s, const double *qa /*[N,na]*/, const double *qb /*[N,na]*/,
+                            const double *qpos_env /*[E,nq]*/, int64_t N, int64_t samples_per_env,
+                            double resolution, uint8_t *valid, int nthreads);
+
+/* counter-based RNG shared (as a specification) with the HIP planner */
+uint64_t orc_rng_u64(uint64_t seed, uint64_t stream, uint64_t counter);
+double orc_rng_uniform(uint64_t seed, uint64_t stream, uint64_t counter);
+
+/* RRT-Connect restated; returns status 0 ok / -5 invalid goal / -4 no exact solution.
+ * path: [max_path, nq] rows (passive columns copied from start). */
+int orc_plan(const OrcScene *s, const double *start /*[nq]*/, const double *goal /*[nq]*/,
+             double range, double resolution, int max_iters, int max_nodes, uint64_t seed, uint64_t env_id,
+             double *path, int max_path, int *path_len, int64_t *n_checks, int *n_iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

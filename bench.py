@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""bench.py -- state-validity (collision-check) throughput of the HIP hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic planner
+states: E envs x S states/env per GPU, SawyerPushObstacle-v0 (7-DoF arm, 27
+collidable primitives, 232 non-ignored candidate pairs).  Inputs are resident
+in HBM before the timed region.  One process per GPU; envs are sharded across
+ranks (weak scaling: per-GPU work is fixed) and every step ends with an RCCL
+all-gather of the uint8 validity masks, the only exchange the path has.
+
+Prints ONE JSON line (rank 0) following the driver's contract, extended with
+  roofline      achieved algorithmic GB/s of the validity kernel vs the HBM roof
+  cpu_baseline  the CPU oracle (this repo's C restatement -- NOT MuJoCo/OMPL)
+                timed on this box's host cores on the same states
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENV = "SawyerPushObstacle-v0"
+# algorithmic bytes per validity check = 7 f64 joint values read + 1 verdict byte
+# written + the env's qpos row (nq f64) amortised over the S states that share it.
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6    # AMD datasheet vector FP64 (not in the local guide)
+
+
+def make_inputs(torch, pi, E, S, seed, device):
+    """States for E envs x S states: first half of every env's block uniform in the joint box (what the RRT
+    sampler draws), second half near the env's initial pose (what motion validation sees).  Per-env passive
+    block: gripper slides U(-0.008, 0.015), cube pose nominal + U(+-0.05) in xy."""
+    from mopa_rl_amd.scene import default_qpos
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    na = len(pi.ref_joint_pos_indexes)
+    lo = torch.tensor(pi.jnt_minimum, dtype=torch.float64, device=device)
+    hi = torch.tensor(pi.jnt_maximum, dtype=torch.float64, device=device)
+    q0 = torch.tensor(default_qpos(ENV, pi.model), dtype=torch.float64, device=device)
+    u = torch.rand(E, S, na, generator=g, dtype=torch.float64, device=device)
+    qa = lo + (hi - lo) * u
+    n = torch.randn(E, S, na, generator=g, dtype=torch.float64, device=device) * 0.3
+    near = torch.minimum(torch.maximum(q0[pi.ref_joint_pos_indexes] + n, lo), hi)
+    half = S // 2
+    qa[:, half:, :] = near[:, half:, :]
+    rows = q0.repeat(E, 1)
+    rows[:, 7:9] = -0.008 + 0.023 * torch.rand(E, 2, generator=g, dtype=torch.float64, device=device)
+    cube = pi.model.get_joint_qpos_addr("cube")
+    rows[:, cube:cube + 2] += -0.05 + 0.1 * torch.rand(E, 2, generator=g, dtype=torch.float64, device=device)
+    return qa.reshape(E * S, na).contiguous(), rows.contiguous()
+
+
+def cpu_baseline(pi, qa_host, rows_host, S, budget_states):
+    """Oracle (oracle/mopa_oracle.c, kind="port") on the host cores, on the first `budget_states` states."""
+    from oracle import oracle as O
+    orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    n = min(budget_states, len(qa_host))
+    n -= n % S
+    qa = qa_host[:n]
+    rows = rows_host[: n // S]
+    cores = os.cpu_count() or 1
+    t0 = time.perf_counter()
+    v1, _ = orc.is_valid_batch(qa, rows, samples_per_env=S, nthreads=1, want_min_dist=False)
+    t1 = time.perf_counter()
+    vN, _ = orc.is_valid_batch(qa, rows, samples_per_env=S, nthreads=cores, want_min_dist=False)
+    t2 = time.perf_counter()
+    return {"single": n / (t1 - t0), "all": n / (t2 - t1), "cores": cores, "n": n, "verdicts": vN}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--samples", type=int, default=256, help="states per env per step")
+    ap.add_argument("--cpu-states", type=int, default=1 << 20, help="states timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import planner_inputs
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)   # "nccl" == RCCL on ROCm
+
+    pi = planner_inputs(ENV)
+    scene = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold,
+                       range_=pi.spec.range, seed=0, device=local_rank)
+    bp = BatchPlanner(scene)
+    E, S = args.envs, args.samples
+    N = E * S
+    qa, rows = make_inputs(torch, pi, E, S, seed=1234 + rank, device=device)
+    valid = torch.empty(N, dtype=torch.uint8, device=device)
+    gathered = torch.empty(world * N, dtype=torch.uint8, device=device) if world > 1 else None
+
+    def step():
+        bp.is_valid(qa, rows, samples_per_env=S, out=valid)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, valid)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # kernel-only timing: HIP events on the stream the kernel is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record()
+        bp.is_valid(qa, rows, samples_per_env=S, out=valid)
+        ev[k][1].record()
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, valid)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_valid = int(valid.sum().item())
+    if rank == 0:
+        total_checks = world * N * args.steps
+        value = total_checks / elapsed
+        bytes_per_check = 7 * 8 + 1 + pi.model.nq * 8 / S
+        achieved = N * bytes_per_check / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "valid-state collision checks/sec", "value": value, "unit": "checks/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{ENV} state validity (FK + collision), {E} envs/GPU x {S} states/env per step, "
+                                   "states 50% uniform joint-box samples + 50% near-init N(0,0.3)",
+                       "envs_per_gpu": E, "states_per_env": S, "pairs_checked_per_state": scene.npair_checked,
+                       "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(uint8 masks)" if world > 1 else "")},
+            "valid_fraction": n_valid / N,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "k_is_valid<false>", "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
+                         "note": "path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see DESIGN.md"},
+        }
+        if not args.no_cpu and world == 1:
+            cb = cpu_baseline(pi, qa.cpu().numpy(), rows.cpu().numpy(), S, args.cpu_states)
+            mism = int((cb["verdicts"] != valid[: cb["n"]].cpu().numpy()).sum())
+            out["cpu_baseline"] = {
+                "value": cb["all"], "unit": "checks/s", "cores": cb["cores"], "kind": "port",
+                "sample": f"first {cb['n']} states of the step batch, OpenMP over states on all host cores; "
+                          "oracle/mopa_oracle.c = this repo's C restatement, NOT MuJoCo/OMPL (unavailable)",
+                "single_thread_value": cb["single"]}
+            out["parity_mismatches_vs_oracle"] = mism
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

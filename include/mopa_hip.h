@@ -1,0 +1,163 @@
+/*
+ * mopa_hip.h -- C ABI of libmopa_hip.so, the MI355X (gfx950) implementation of
+ * MoPA-RL's state-validity / motion-validation / RRT-Connect hot path.
+ *
+ * This is the drop-in boundary: each entry point below replaces one piece of
+ * what the reference's Cython extension binds (reference
+ * motion_planners/planner.pyx:9-52 -> motion_planners/include/KinematicPlanner.h:40-71).
+ * Plain pointers and sizes only; no C++ types, no exceptions: every function
+ * returns an int status (0 = MOPA_OK) and mopa_last_error() explains failures.
+ *
+ *   reference interface                              replaced by
+ *   -----------------------------------------------  ----------------------------
+ *   KinematicPlanner::KinematicPlanner(xml, algo,    mopa_scene_create()
+ *     ..., passive_joint_idx, glue_bodies,           (the XML is compiled to the
+ *     ignored_contacts, contact_threshold, ...)      flat MopaModel by the host
+ *     KinematicPlanner.cpp:42-120                    shim: mopa_rl_amd/mjcf.py)
+ *   KinematicPlanner::~KinematicPlanner              mopa_scene_destroy()
+ *   KinematicPlanner::isValidState(vector<double>)   mopa_is_valid_state()      (1 state, host ptr)
+ *     KinematicPlanner.cpp:253-286 ->                mopa_is_valid_batch()      (N states, device ptrs)
+ *     MujocoStateValidityChecker::isValid
+ *     mujoco_ompl_interface.cpp:909-978
+ *   si->checkMotion (OMPL DiscreteMotionValidator,   mopa_check_motion_batch()
+ *     resolution KinematicPlanner.cpp:87)
+ *   KinematicPlanner::plan(start, goal, timelimit)   mopa_plan()                (1 query, host ptrs)
+ *     KinematicPlanner.cpp:125-251 (RRTConnect)      mopa_plan_batch()          (E queries, device ptrs)
+ *   KinematicPlanner::getPlannerStatus()             mopa_planner_status()
+ *     KinematicPlanner.cpp:288-291
+ *
+ * Memory: "dev" pointers are HIP device pointers (e.g. torch tensor
+ * data_ptr() on a ROCm device), "host" pointers are ordinary memory.  The
+ * caller owns every buffer; the library never frees caller memory.  All
+ * floating point data is IEEE double, C-contiguous.  `stream` is a
+ * hipStream_t passed as void* (NULL = the default stream); batch calls are
+ * asynchronous on that stream.  A MopaScene may be used from one host thread
+ * at a time.
+ */
+#ifndef MOPA_HIP_H
+#define MOPA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOPA_OK 0
+#define MOPA_ERR_INVALID_ARG 1
+#define MOPA_ERR_UNSUPPORTED 2   /* e.g. collidable mesh / ball joint in the model */
+#define MOPA_ERR_HIP 3           /* HIP runtime error (no device, launch failure...) */
+#define MOPA_ERR_LIMIT 4         /* model exceeds a compile-time capacity */
+
+/* planner result codes == the sentinel rows of KinematicPlanner.cpp:181-184,249-250 */
+#define MOPA_PLAN_OK 0
+#define MOPA_PLAN_NO_EXACT (-4)
+#define MOPA_PLAN_INVALID_GOAL (-5)
+
+/* "no penetration found" value of min_dist outputs */
+#define MOPA_FAR 1.0e10
+
+/* geom / joint type codes (MuJoCo's mjtGeom / mjtJoint values) */
+enum { MOPA_GEOM_PLANE = 0, MOPA_GEOM_SPHERE = 2, MOPA_GEOM_CAPSULE = 3, MOPA_GEOM_CYLINDER = 5, MOPA_GEOM_BOX = 6, MOPA_GEOM_MESH = 7 };
+enum { MOPA_JNT_FREE = 0, MOPA_JNT_BALL = 1, MOPA_JNT_SLIDE = 2, MOPA_JNT_HINGE = 3 };
+
+/* Flat compiled model (host pointers; copied by mopa_scene_create).
+ * Same arrays as mopa_rl_amd.mjcf.CompiledModel. */
+typedef struct MopaModel {
+    int32_t nq, nbody, njnt, ngeom, npair;
+    const int32_t *body_parent;   /* [nbody]            */
+    const double  *body_pos;      /* [nbody,3]          */
+    const double  *body_quat;     /* [nbody,4] wxyz, normalised */
+    const int32_t *body_jntadr;   /* [nbody] first joint or -1 */
+    const int32_t *body_jntnum;   /* [nbody]            */
+    const int32_t *jnt_type;      /* [njnt]             */
+    const int32_t *jnt_qposadr;   /* [njnt]             */
+    const double  *jnt_axis;      /* [njnt,3] normalised */
+    const double  *jnt_pos;       /* [njnt,3]           */
+    const double  *jnt_ref;       /* [njnt] qpos0 of hinge/slide */
+    const int32_t *jnt_limited;   /* [njnt]             */
+    const double  *jnt_range;     /* [njnt,2]           */
+    const int32_t *geom_type;     /* [ngeom] collidable geoms only */
+    const int32_t *geom_body;     /* [ngeom]            */
+    const int32_t *geom_mjid;     /* [ngeom] id among ALL geoms of the model (for ignored_contacts) */
+    const double  *geom_size;     /* [ngeom,3]          */
+    const double  *geom_pos;      /* [ngeom,3]          */
+    const double  *geom_quat;     /* [ngeom,4]          */
+    const int32_t *pair_geom;     /* [npair,2] candidate pairs after MuJoCo's static filters, type1<=type2 */
+} MopaModel;
+
+/* Everything KinematicPlanner's constructor receives (KinematicPlanner.cpp:42-61). */
+typedef struct MopaSceneDesc {
+    MopaModel model;
+    int32_t n_passive;
+    const int32_t *passive_qpos_idx;   /* [n_passive] qpos addresses NOT planned over */
+    int32_t n_ignored;
+    const int32_t *ignored_pairs;      /* [n_ignored,2] ordered (lo,hi) MuJoCo geom ids */
+    double contact_threshold;          /* state invalid iff some non-ignored dist <= this (negative in the reference) */
+    double range;                      /* RRT-Connect maxDistance (KinematicPlanner.cpp:102-104) */
+    double resolution;                 /* validity checking resolution; the reference hard-codes 0.005 (:87) */
+    uint64_t seed;                     /* KinematicPlanner.cpp:95 */
+    int32_t device;                    /* HIP device ordinal, -1 = current */
+} MopaSceneDesc;
+
+typedef struct MopaScene MopaScene;
+
+typedef struct MopaPlanParams {
+    int32_t max_iters;     /* RRT-Connect iteration budget (replaces the wall-clock timelimit) */
+    int32_t max_nodes;     /* per-tree node capacity */
+    int32_t max_path;      /* rows available per env in `path` */
+    uint64_t seed;         /* sample-stream seed; stream id = env_id_base + env index */
+    uint64_t env_id_base;
+} MopaPlanParams;
+
+const char *mopa_last_error(void);
+const char *mopa_version(void);
+/* number of visible HIP devices (0 when none); never fails */
+int mopa_device_count(void);
+
+int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out);
+void mopa_scene_destroy(MopaScene *scene);
+/* introspection used by the host shim and the tests */
+int mopa_scene_num_active(const MopaScene *scene);
+int mopa_scene_active_idx(const MopaScene *scene, int32_t *out /*[na]*/);
+int mopa_scene_num_pairs(const MopaScene *scene);   /* non-ignored candidate pairs checked per state */
+int mopa_scene_lds_bytes(const MopaScene *scene);
+
+/* N states: state i = qpos_env[i / samples_per_env] with its active entries replaced by q_active[i].
+ * valid[i] = 1 iff no non-ignored pair has dist <= contact_threshold.
+ * min_dist (nullable): minimum signed distance over the pairs that pass the broad phase (MOPA_FAR if none);
+ * requesting it disables the wave-level early-out. */
+int mopa_is_valid_batch(MopaScene *scene, const double *q_active_dev /*[N,na]*/, const double *qpos_env_dev /*[E,nq]*/,
+                        int64_t N, int64_t samples_per_env, uint8_t *valid_dev /*[N]*/, double *min_dist_dev /*[N] or NULL*/,
+                        void *stream);
+
+/* N segments qa[i] -> qb[i] (active coordinates), OMPL DiscreteMotionValidator semantics:
+ * valid[i] = 1 iff qb[i] and every interior state interpolate(qa,qb,k/nd), k=1..nd-1, is valid,
+ * nd = max_j ceil(|d_j| / (resolution * extent_j)). */
+int mopa_check_motion_batch(MopaScene *scene, const double *qa_dev /*[N,na]*/, const double *qb_dev /*[N,na]*/,
+                            const double *qpos_env_dev /*[E,nq]*/, int64_t N, int64_t samples_per_env,
+                            uint8_t *valid_dev /*[N]*/, void *stream);
+
+/* E independent RRT-Connect queries (one per env).  path rows hold full qpos vectors with the passive
+ * columns copied from start (KinematicPlanner.cpp:236-240).  status[e] in {0,-4,-5}. */
+int mopa_plan_batch(MopaScene *scene, const double *start_dev /*[E,nq]*/, const double *goal_dev /*[E,nq]*/, int64_t E,
+                    const MopaPlanParams *params, double *path_dev /*[E,max_path,nq]*/, int32_t *path_len_dev /*[E]*/,
+                    int32_t *status_dev /*[E]*/, int64_t *n_checks_dev /*[E] or NULL*/, void *stream);
+
+/* ---- single-query convenience forms: what PyKinematicPlanner binds (host pointers, synchronous) ---- */
+int mopa_is_valid_state(MopaScene *scene, const double *qpos_host /*[nq]*/, int32_t *valid_out, double *min_dist_out /*nullable*/);
+int mopa_plan(MopaScene *scene, const double *start_host /*[nq]*/, const double *goal_host /*[nq]*/,
+              const MopaPlanParams *params, double *path_host /*[max_path,nq]*/, int32_t *path_len_out, int32_t *status_out,
+              int64_t *n_checks_out /*nullable*/);
+/* OMPL-style status string of the last mopa_plan on this scene ("none" before the first). */
+const char *mopa_planner_status(const MopaScene *scene);
+
+/* debug / parity hooks: world pose of every collidable geom for one state (host pointers, synchronous) */
+int mopa_debug_fk(MopaScene *scene, const double *qpos_host /*[nq]*/, double *geom_xpos_host /*[ngeom,3]*/,
+                  double *geom_xmat_host /*[ngeom,9]*/);
+/* per-candidate-pair distances (MOPA_FAR for culled / ignored pairs), in MopaModel.pair_geom order */
+int mopa_debug_pair_dist(MopaScene *scene, const double *qpos_host /*[nq]*/, double *dist_host /*[npair]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOPA_HIP_H */

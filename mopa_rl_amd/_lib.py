@@ -1,0 +1,217 @@
+"""ctypes binding of libmopa_hip.so (the C ABI in include/mopa_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no HIP device
+is visible when a scene is created, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmopa_hip.so")
+
+MOPA_OK = 0
+MOPA_FAR = 1.0e10
+PLAN_OK, PLAN_NO_EXACT, PLAN_INVALID_GOAL = 0, -4, -5
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+# every symbol include/mopa_hip.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = [
+    "mopa_last_error", "mopa_version", "mopa_device_count", "mopa_scene_create", "mopa_scene_destroy",
+    "mopa_scene_num_active", "mopa_scene_active_idx", "mopa_scene_num_pairs", "mopa_scene_lds_bytes",
+    "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_is_valid_state", "mopa_plan",
+    "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
+]
+
+
+class MopaError(RuntimeError):
+    pass
+
+
+class MopaModel(C.Structure):
+    _fields_ = [
+        ("nq", C.c_int32), ("nbody", C.c_int32), ("njnt", C.c_int32), ("ngeom", C.c_int32), ("npair", C.c_int32),
+        ("body_parent", _ip), ("body_pos", _dp), ("body_quat", _dp), ("body_jntadr", _ip), ("body_jntnum", _ip),
+        ("jnt_type", _ip), ("jnt_qposadr", _ip), ("jnt_axis", _dp), ("jnt_pos", _dp), ("jnt_ref", _dp),
+        ("jnt_limited", _ip), ("jnt_range", _dp),
+        ("geom_type", _ip), ("geom_body", _ip), ("geom_mjid", _ip), ("geom_size", _dp), ("geom_pos", _dp),
+        ("geom_quat", _dp), ("pair_geom", _ip),
+    ]
+
+
+class MopaSceneDesc(C.Structure):
+    _fields_ = [
+        ("model", MopaModel), ("n_passive", C.c_int32), ("passive_qpos_idx", _ip), ("n_ignored", C.c_int32),
+        ("ignored_pairs", _ip), ("contact_threshold", C.c_double), ("range", C.c_double), ("resolution", C.c_double),
+        ("seed", C.c_uint64), ("device", C.c_int32),
+    ]
+
+
+class MopaPlanParams(C.Structure):
+    _fields_ = [("max_iters", C.c_int32), ("max_nodes", C.c_int32), ("max_path", C.c_int32), ("seed", C.c_uint64),
+                ("env_id_base", C.c_uint64)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load libmopa_hip.so (built in-tree by __graft_entry__.build / csrc/Makefile)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MopaError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C mopa_rl_amd/csrc`). There is no CPU fallback.")
+    # One HIP runtime per process: torch ships its own libamdhip64.so.7 and must be loaded first so
+    # that libmopa_hip.so binds to that same copy (two runtimes in one process cannot both own the GPU).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.mopa_last_error.restype = C.c_char_p
+    L.mopa_version.restype = C.c_char_p
+    L.mopa_device_count.restype = C.c_int
+    L.mopa_scene_create.argtypes = [C.POINTER(MopaSceneDesc), C.POINTER(vp)]
+    L.mopa_scene_destroy.argtypes = [vp]
+    L.mopa_scene_destroy.restype = None
+    L.mopa_scene_num_active.argtypes = [vp]
+    L.mopa_scene_active_idx.argtypes = [vp, _ip]
+    L.mopa_scene_num_pairs.argtypes = [vp]
+    L.mopa_scene_lds_bytes.argtypes = [vp]
+    L.mopa_is_valid_batch.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp]
+    L.mopa_check_motion_batch.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, vp, vp]
+    L.mopa_plan_batch.argtypes = [vp, vp, vp, C.c_int64, C.POINTER(MopaPlanParams), vp, vp, vp, vp, vp]
+    L.mopa_is_valid_state.argtypes = [vp, _dp, C.POINTER(C.c_int32), _dp]
+    L.mopa_plan.argtypes = [vp, _dp, _dp, C.POINTER(MopaPlanParams), _dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                            C.POINTER(C.c_int64)]
+    L.mopa_planner_status.argtypes = [vp]
+    L.mopa_planner_status.restype = C.c_char_p
+    L.mopa_debug_fk.argtypes = [vp, _dp, _dp, _dp]
+    L.mopa_debug_pair_dist.argtypes = [vp, _dp, _dp]
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc != MOPA_OK:
+        raise MopaError(f"libmopa_hip error {rc}: {lib().mopa_last_error().decode()}")
+
+
+def _d(a):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a, a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a, a.ctypes.data_as(_ip)
+
+
+class Scene:
+    """Owns one MopaScene* (== one KinematicPlanner instance of the reference)."""
+
+    def __init__(self, model, passive_joint_idx, ignored_contacts, contact_threshold: float, range_: float = 0.1,
+                 resolution: float = 0.005, seed: int = 0, device: int = -1):
+        L = lib()
+        m = model
+        keep = []
+
+        def d(a):
+            a, p = _d(a); keep.append(a); return p
+
+        def i(a):
+            a, p = _i(a); keep.append(a); return p
+
+        ign = np.asarray(list(ignored_contacts), dtype=np.int32).reshape(-1, 2)
+        pas = np.asarray(list(passive_joint_idx), dtype=np.int32)
+        desc = MopaSceneDesc()
+        desc.model = MopaModel(
+            m.nq, len(m.body_names), len(m.jnt_names), len(m.geom_type), len(m.pair_geom),
+            i(m.body_parent), d(m.body_pos), d(m.body_quat), i(m.body_jntadr), i(m.body_jntnum),
+            i(m.jnt_type), i(m.jnt_qposadr), d(m.jnt_axis), d(m.jnt_pos), d(m.jnt_ref), i(m.jnt_limited), d(m.jnt_range),
+            i(m.geom_type), i(m.geom_body), i(m.geom_mjid), d(m.geom_size), d(m.geom_pos), d(m.geom_quat), i(m.pair_geom))
+        desc.n_passive = len(pas)
+        desc.passive_qpos_idx = i(pas)
+        desc.n_ignored = len(ign)
+        desc.ignored_pairs = i(ign)
+        desc.contact_threshold = float(contact_threshold)
+        desc.range = float(range_)
+        desc.resolution = float(resolution)
+        desc.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        desc.device = int(device)
+        h = C.c_void_p()
+        check(L.mopa_scene_create(C.byref(desc), C.byref(h)))
+        self._h = h
+        self.model = m
+        self.nq = m.nq
+        self.na = L.mopa_scene_num_active(h)
+        ai = np.zeros(self.na, dtype=np.int32)
+        check(L.mopa_scene_active_idx(h, ai.ctypes.data_as(_ip)))
+        self.active_idx = ai
+        self.npair_checked = L.mopa_scene_num_pairs(h)
+        self.lds_bytes = L.mopa_scene_lds_bytes(h)
+        self.ngeom = len(m.geom_type)
+        self.npair = len(m.pair_geom)
+        self.seed = int(seed)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib().mopa_scene_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # ---- single-state forms (host pointers) ----
+    def is_valid_state(self, qpos, want_min_dist: bool = False):
+        q, qp = _d(qpos)
+        if q.shape != (self.nq,):
+            raise MopaError(f"state has dimension {q.shape}, expected nq={self.nq}")
+        v = C.c_int32(0)
+        md = C.c_double(0.0)
+        check(lib().mopa_is_valid_state(self._h, qp, C.byref(v), C.byref(md) if want_min_dist else None))
+        return (bool(v.value), md.value) if want_min_dist else bool(v.value)
+
+    def plan(self, start, goal, max_iters: int, max_nodes: int = 4096, max_path: int = 512, seed: Optional[int] = None,
+             env_id: int = 0):
+        s, sp = _d(start)
+        g, gp = _d(goal)
+        prm = MopaPlanParams(int(max_iters), int(max_nodes), int(max_path),
+                             int(self.seed if seed is None else seed) & 0xFFFFFFFFFFFFFFFF, int(env_id))
+        path = np.zeros((max_path, self.nq))
+        plen, st, chk = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+        check(lib().mopa_plan(self._h, sp, gp, C.byref(prm), path.ctypes.data_as(_dp), C.byref(plen), C.byref(st),
+                              C.byref(chk)))
+        return st.value, path[:plen.value].copy(), chk.value
+
+    def planner_status(self) -> bytes:
+        return lib().mopa_planner_status(self._h)
+
+    def debug_fk(self, qpos):
+        q, qp = _d(qpos)
+        gpos = np.zeros((self.ngeom, 3)); gmat = np.zeros((self.ngeom, 9))
+        check(lib().mopa_debug_fk(self._h, qp, gpos.ctypes.data_as(_dp), gmat.ctypes.data_as(_dp)))
+        return gpos, gmat.reshape(-1, 3, 3)
+
+    def debug_pair_dist(self, qpos):
+        q, qp = _d(qpos)
+        out = np.zeros(self.npair)
+        check(lib().mopa_debug_pair_dist(self._h, qp, out.ctypes.data_as(_dp)))
+        return out

@@ -1,0 +1,89 @@
+"""Batched (device-resident) entry points over torch tensors.
+
+torch is used only for device memory and streams: every call hands raw device
+pointers to libmopa_hip.so through the C ABI (include/mopa_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+from . import _lib
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _ptr(t) -> C.c_void_p:
+    return C.c_void_p(t.data_ptr())
+
+
+def _check_f64(t, name, cols=None):
+    torch = _torch()
+    if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
+        raise _lib.MopaError(f"{name} must be a contiguous float64 tensor on the GPU")
+    if cols is not None and (t.dim() != 2 or t.shape[1] != cols):
+        raise _lib.MopaError(f"{name} must have shape [*, {cols}], got {tuple(t.shape)}")
+
+
+def _stream_handle(stream) -> C.c_void_p:
+    torch = _torch()
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+class BatchPlanner:
+    """N-state validity / motion checks and E-env RRT-Connect on one GPU."""
+
+    def __init__(self, scene: "_lib.Scene"):
+        self.scene = scene
+        self.na = scene.na
+        self.nq = scene.nq
+
+    # valid[i] for state i = qpos_env[i // samples_per_env] with active entries <- q_active[i]
+    def is_valid(self, q_active, qpos_env, samples_per_env: Optional[int] = None, want_min_dist: bool = False,
+                 out=None, stream=None):
+        torch = _torch()
+        _check_f64(q_active, "q_active", self.na)
+        _check_f64(qpos_env, "qpos_env", self.nq)
+        N = q_active.shape[0]
+        spe = int(samples_per_env) if samples_per_env is not None else max(1, N // max(1, qpos_env.shape[0]))
+        if N and (N + spe - 1) // spe > qpos_env.shape[0]:
+            raise _lib.MopaError("qpos_env has fewer rows than ceil(N / samples_per_env)")
+        valid = out if out is not None else torch.empty(N, dtype=torch.uint8, device=q_active.device)
+        md = torch.empty(N, dtype=torch.float64, device=q_active.device) if want_min_dist else None
+        _lib.check(_lib.lib().mopa_is_valid_batch(self.scene.handle, _ptr(q_active), _ptr(qpos_env), N, spe, _ptr(valid),
+                                                  _ptr(md) if md is not None else None, _stream_handle(stream)))
+        return (valid, md) if want_min_dist else valid
+
+    def check_motion(self, qa, qb, qpos_env, samples_per_env: Optional[int] = None, stream=None):
+        torch = _torch()
+        _check_f64(qa, "qa", self.na)
+        _check_f64(qb, "qb", self.na)
+        _check_f64(qpos_env, "qpos_env", self.nq)
+        N = qa.shape[0]
+        spe = int(samples_per_env) if samples_per_env is not None else max(1, N // max(1, qpos_env.shape[0]))
+        valid = torch.empty(N, dtype=torch.uint8, device=qa.device)
+        _lib.check(_lib.lib().mopa_check_motion_batch(self.scene.handle, _ptr(qa), _ptr(qb), _ptr(qpos_env), N, spe,
+                                                      _ptr(valid), _stream_handle(stream)))
+        return valid
+
+    def plan(self, start, goal, max_iters: int = 2000, max_nodes: int = 1024, max_path: int = 256, seed: int = 0,
+             env_id_base: int = 0, stream=None) -> Tuple["object", "object", "object", "object"]:
+        """E independent RRT-Connect queries.  Returns (path[E,max_path,nq], path_len[E], status[E], n_checks[E])."""
+        torch = _torch()
+        _check_f64(start, "start", self.nq)
+        _check_f64(goal, "goal", self.nq)
+        E = start.shape[0]
+        dev = start.device
+        path = torch.zeros(E, max_path, self.nq, dtype=torch.float64, device=dev)
+        plen = torch.zeros(E, dtype=torch.int32, device=dev)
+        status = torch.zeros(E, dtype=torch.int32, device=dev)
+        nchk = torch.zeros(E, dtype=torch.int64, device=dev)
+        prm = _lib.MopaPlanParams(int(max_iters), int(max_nodes), int(max_path), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                  int(env_id_base))
+        _lib.check(_lib.lib().mopa_plan_batch(self.scene.handle, _ptr(start), _ptr(goal), E, C.byref(prm), _ptr(path),
+                                              _ptr(plen), _ptr(status), _ptr(nchk), _stream_handle(stream)))
+        return path, plen, status, nchk

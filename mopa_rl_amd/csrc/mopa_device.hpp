@@ -1,0 +1,572 @@
+// mopa_device.hpp -- FP64 geometry for the state-validity kernels (gfx950).
+//
+// Numerics contract (DESIGN.md "Numerics"): IEEE double everywhere, compiled
+// with -ffp-contract=off so that the ONLY fused multiply-adds are the explicit
+// fma() calls below; sqrt and division are IEEE correctly rounded; sin/cos is
+// mopa_sincos() (Cody-Waite + minimax kernels), never a library call.  With
+// that, a state's collision verdict is a pure function of its inputs and is
+// reproduced bit-for-bit by any conforming implementation -- which is what the
+// parity tests check against the independent CPU restatement.
+//
+// What each routine stands in for in the reference stack ([3P] = third-party
+// library the reference links, source not in its tree):
+//   fk_*            [3P] MuJoCo mj_kinematics   (via mj_fwdPosition,
+//                   reference motion_planners/src/mujoco_ompl_interface.cpp:932)
+//   d_* / mpr_*     [3P] MuJoCo mj_collision narrow phase (mjc_* primitives,
+//                   mjc_Convex -> libccd ccdMPRPenetration)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#define MOPA_HD __host__ __device__ __forceinline__
+#define MOPA_D __device__ __forceinline__
+
+namespace mopa {
+
+constexpr double kFar = 1.0e10;
+constexpr double kMinVal = 1e-15;          // mjMINVAL
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kCcdEps = 2.2204460492503131e-16;
+constexpr double kMprTol = 1e-6;           // MuJoCo mpr_tolerance
+constexpr int kMprMaxIt = 50;              // MuJoCo mpr_iterations
+constexpr int kMprPortalMaxIt = 100;       // guard for libccd's two unbounded loops
+
+enum GeomType : int { G_PLANE = 0, G_SPHERE = 2, G_CAPSULE = 3, G_CYLINDER = 5, G_BOX = 6, G_MESH = 7 };
+enum JntType : int { J_FREE = 0, J_BALL = 1, J_SLIDE = 2, J_HINGE = 3 };
+
+// pair type codes, cheapest narrow phase first (the pair list is sorted by this)
+enum PairCode : int {
+    PC_PLANE_SPHERE = 0, PC_PLANE_CAPSULE, PC_PLANE_CYLINDER, PC_PLANE_BOX, PC_SPHERE_SPHERE, PC_SPHERE_CAPSULE,
+    PC_SPHERE_CYLINDER, PC_SPHERE_BOX, PC_CAPSULE_CAPSULE, PC_CAPSULE_BOX, PC_BOX_BOX, PC_CONVEX, PC_COUNT
+};
+
+struct V3 { double x, y, z; };
+struct Q4 { double w, x, y, z; };
+
+MOPA_HD double dot3(V3 a, V3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
+MOPA_HD V3 cross3(V3 a, V3 b) {
+    return V3{fma(a.y, b.z, -(a.z * b.y)), fma(a.z, b.x, -(a.x * b.z)), fma(a.x, b.y, -(a.y * b.x))};
+}
+MOPA_HD V3 sub3(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MOPA_HD V3 add3(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MOPA_HD V3 neg3(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+// a + b*s
+MOPA_HD V3 addscl3(V3 a, V3 b, double s) { return V3{fma(b.x, s, a.x), fma(b.y, s, a.y), fma(b.z, s, a.z)}; }
+MOPA_HD double norm3(V3 a) { return sqrt(dot3(a, a)); }
+MOPA_HD V3 ld3(const double *p) { return V3{p[0], p[1], p[2]}; }
+MOPA_HD void st3(double *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+// M v, M row-major 3x3
+MOPA_HD V3 mat_vec(const double *M, V3 v) {
+    return V3{fma(M[2], v.z, fma(M[1], v.y, M[0] * v.x)), fma(M[5], v.z, fma(M[4], v.y, M[3] * v.x)),
+              fma(M[8], v.z, fma(M[7], v.y, M[6] * v.x))};
+}
+// M^T v
+MOPA_HD V3 matT_vec(const double *M, V3 v) {
+    return V3{fma(M[6], v.z, fma(M[3], v.y, M[0] * v.x)), fma(M[7], v.z, fma(M[4], v.y, M[1] * v.x)),
+              fma(M[8], v.z, fma(M[5], v.y, M[2] * v.x))};
+}
+MOPA_HD V3 col3(const double *M, int j) { return V3{M[j], M[3 + j], M[6 + j]}; }
+MOPA_HD double dmin(double a, double b) { return (a < b) ? a : b; }
+MOPA_HD double dmax(double a, double b) { return (a > b) ? a : b; }
+MOPA_HD double clampd(double x, double lo, double hi) { return (x < lo) ? lo : ((x > hi) ? hi : x); }
+MOPA_HD double signd(double x) { return (x > 0.0) ? 1.0 : ((x < 0.0) ? -1.0 : 0.0); }
+
+MOPA_HD Q4 quat_mul(Q4 a, Q4 b) {
+    Q4 r;
+    r.w = fma(-a.z, b.z, fma(-a.y, b.y, fma(-a.x, b.x, a.w * b.w)));
+    r.x = fma(-a.z, b.y, fma(a.y, b.z, fma(a.x, b.w, a.w * b.x)));
+    r.y = fma(a.z, b.x, fma(a.y, b.w, fma(-a.x, b.z, a.w * b.y)));
+    r.z = fma(a.z, b.w, fma(-a.y, b.x, fma(a.x, b.y, a.w * b.z)));
+    return r;
+}
+// [3P] mju_normalize4
+MOPA_HD Q4 quat_normalize(Q4 q) {
+    double n = sqrt(fma(q.z, q.z, fma(q.y, q.y, fma(q.x, q.x, q.w * q.w))));
+    if (n < kMinVal) return Q4{1.0, 0.0, 0.0, 0.0};
+    if (fabs(n - 1.0) > kMinVal) {
+        double inv = 1.0 / n;
+        q.w *= inv; q.x *= inv; q.y *= inv; q.z *= inv;
+    }
+    return q;
+}
+// [3P] mju_quat2Mat
+MOPA_HD void quat2mat(double *M, Q4 q) {
+    double q00 = q.w * q.w, q01 = q.w * q.x, q02 = q.w * q.y, q03 = q.w * q.z;
+    double q11 = q.x * q.x, q12 = q.x * q.y, q13 = q.x * q.z;
+    double q22 = q.y * q.y, q23 = q.y * q.z, q33 = q.z * q.z;
+    M[0] = ((q00 + q11) - q22) - q33;
+    M[4] = ((q00 - q11) + q22) - q33;
+    M[8] = ((q00 - q11) - q22) + q33;
+    M[1] = 2.0 * (q12 - q03);
+    M[2] = 2.0 * (q13 + q02);
+    M[3] = 2.0 * (q12 + q03);
+    M[5] = 2.0 * (q23 - q01);
+    M[6] = 2.0 * (q13 - q02);
+    M[7] = 2.0 * (q23 + q01);
+}
+// [3P] mju_rotVecQuat
+MOPA_HD V3 rot_vec_quat(V3 v, Q4 q) {
+    double M[9];
+    quat2mat(M, q);
+    return mat_vec(M, v);
+}
+
+// Deterministic sin/cos: k = rint(x*2/pi); three-term Cody-Waite reduction;
+// degree-13/14 minimax kernels on [-pi/4, pi/4]; quadrant fix-up.
+MOPA_HD void mopa_sincos(double x, double &sout, double &cout) {
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double P1 = 1.57079632673412561417e+00, P2 = 6.07710050630396597660e-11, P3 = 2.02226624879595063154e-21;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double k = rint(x * TWO_OVER_PI);
+    double r = fma(-k, P1, x);
+    r = fma(-k, P2, r);
+    r = fma(-k, P3, r);
+    double z = r * r;
+    double ps = fma(z, fma(z, fma(z, fma(z, fma(z, S6, S5), S4), S3), S2), S1);
+    double sn = fma(r * z, ps, r);
+    double pc = fma(z, fma(z, fma(z, fma(z, fma(z, C6, C5), C4), C3), C2), C1);
+    double cs = fma(z * z, pc, fma(-0.5, z, 1.0));
+    int q = (int)((long long)k & 3);
+    if (q == 0) { sout = sn; cout = cs; }
+    else if (q == 1) { sout = cs; cout = -sn; }
+    else if (q == 2) { sout = -sn; cout = -cs; }
+    else { sout = -cs; cout = sn; }
+}
+
+// ---------------------------------------------------------------------------
+// One posed primitive as the narrow phase sees it.  `p` points at 15 doubles:
+// pos[3] mat[9] size[3] (LDS on the device, plain memory on the host).
+// ---------------------------------------------------------------------------
+constexpr int kGeomStride = 16;   // doubles per posed geom record (15 used, padded to 128 B)
+constexpr int GO_POS = 0, GO_MAT = 3, GO_SIZE = 12;
+
+MOPA_HD double d_plane_sphere(const double *P, const double *S) {
+    V3 n = col3(P + GO_MAT, 2);
+    V3 diff = sub3(ld3(S + GO_POS), ld3(P + GO_POS));
+    return dot3(diff, n) - S[GO_SIZE];
+}
+MOPA_HD double d_plane_capsule(const double *P, const double *C) {
+    V3 n = col3(P + GO_MAT, 2), a = col3(C + GO_MAT, 2);
+    V3 cp = ld3(C + GO_POS), pp = ld3(P + GO_POS);
+    V3 e = addscl3(cp, a, C[GO_SIZE + 1]);
+    double d1 = dot3(sub3(e, pp), n) - C[GO_SIZE];
+    e = addscl3(cp, a, -C[GO_SIZE + 1]);
+    double d2 = dot3(sub3(e, pp), n) - C[GO_SIZE];
+    return dmin(d1, d2);
+}
+MOPA_HD double d_plane_cylinder(const double *P, const double *C) {
+    V3 n = col3(P + GO_MAT, 2), a = col3(C + GO_MAT, 2);
+    V3 diff = sub3(ld3(C + GO_POS), ld3(P + GO_POS));
+    double d0 = dot3(diff, n);
+    double na = dot3(n, a);
+    double s2 = fma(-na, na, 1.0);
+    double sr = (s2 > 0.0) ? sqrt(s2) : 0.0;
+    return (d0 - C[GO_SIZE + 1] * fabs(na)) - C[GO_SIZE] * sr;
+}
+MOPA_HD double d_plane_box(const double *P, const double *B) {
+    V3 n = col3(P + GO_MAT, 2);
+    V3 diff = sub3(ld3(B + GO_POS), ld3(P + GO_POS));
+    double d0 = dot3(diff, n);
+    double ext = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) ext = fma(fabs(dot3(n, col3(B + GO_MAT, i))), B[GO_SIZE + i], ext);
+    return d0 - ext;
+}
+MOPA_HD double d_sphere_sphere(const double *A, const double *B) {
+    V3 diff = sub3(ld3(B + GO_POS), ld3(A + GO_POS));
+    return norm3(diff) - (A[GO_SIZE] + B[GO_SIZE]);
+}
+MOPA_HD double d_sphere_capsule(const double *S, const double *C) {
+    V3 a = col3(C + GO_MAT, 2);
+    V3 sp = ld3(S + GO_POS), cp = ld3(C + GO_POS);
+    V3 vec = sub3(sp, cp);
+    double x = clampd(dot3(a, vec), -C[GO_SIZE + 1], C[GO_SIZE + 1]);
+    V3 pt = addscl3(cp, a, x);
+    return norm3(sub3(sp, pt)) - (S[GO_SIZE] + C[GO_SIZE]);
+}
+MOPA_HD double d_capsule_capsule(const double *A, const double *B) {
+    V3 a1 = col3(A + GO_MAT, 2), a2 = col3(B + GO_MAT, 2);
+    V3 r = sub3(ld3(A + GO_POS), ld3(B + GO_POS));
+    double h1 = A[GO_SIZE + 1], h2 = B[GO_SIZE + 1];
+    double b = dot3(a1, a2), c = dot3(a1, r), f = dot3(a2, r);
+    double denom = fma(-b, b, 1.0);
+    double sp = 0.0;
+    if (denom > 1e-12) sp = clampd(fma(b, f, -c) / denom, -h1, h1);
+    double tp = fma(b, sp, f);
+    if (tp < -h2) { tp = -h2; sp = clampd(fma(b, tp, -c), -h1, h1); }
+    else if (tp > h2) { tp = h2; sp = clampd(fma(b, tp, -c), -h1, h1); }
+    V3 w = addscl3(r, a1, sp);
+    w = addscl3(w, a2, -tp);
+    return norm3(w) - (A[GO_SIZE] + B[GO_SIZE]);
+}
+MOPA_HD double d_sphere_box(const double *S, const double *B) {
+    V3 v = sub3(ld3(S + GO_POS), ld3(B + GO_POS));
+    V3 l = matT_vec(B + GO_MAT, v);
+    double hx = B[GO_SIZE], hy = B[GO_SIZE + 1], hz = B[GO_SIZE + 2];
+    V3 e{l.x - clampd(l.x, -hx, hx), l.y - clampd(l.y, -hy, hy), l.z - clampd(l.z, -hz, hz)};
+    bool inside = (e.x == 0.0) && (e.y == 0.0) && (e.z == 0.0);
+    if (inside) {
+        double m = dmin(dmin(hx - fabs(l.x), hy - fabs(l.y)), hz - fabs(l.z));
+        return -m - S[GO_SIZE];
+    }
+    return norm3(e) - S[GO_SIZE];
+}
+MOPA_HD double d_sphere_cylinder(const double *S, const double *C) {
+    V3 a = col3(C + GO_MAT, 2);
+    V3 v = sub3(ld3(S + GO_POS), ld3(C + GO_POS));
+    double z = dot3(v, a);
+    V3 w = addscl3(v, a, -z);
+    double rho = norm3(w);
+    double dr = rho - C[GO_SIZE];
+    double dz = fabs(z) - C[GO_SIZE + 1];
+    double dp;
+    if (dr <= 0.0 && dz <= 0.0) dp = dmax(dr, dz);
+    else {
+        double er = dmax(dr, 0.0), ez = dmax(dz, 0.0);
+        dp = sqrt(fma(ez, ez, er * er));
+    }
+    return dp - S[GO_SIZE];
+}
+
+// exact segment/box distance: bracket the sign change of the piecewise-linear
+// derivative of the convex function t -> |p(t) - clamp(p(t))|^2 among its knots.
+MOPA_HD double segbox_half_fprime(V3 p0, V3 d, V3 h, double t, V3 &e) {
+    double px = fma(d.x, t, p0.x), py = fma(d.y, t, p0.y), pz = fma(d.z, t, p0.z);
+    e.x = px - clampd(px, -h.x, h.x);
+    e.y = py - clampd(py, -h.y, h.y);
+    e.z = pz - clampd(pz, -h.z, h.z);
+    return dot3(e, d);
+}
+MOPA_HD void segbox_knot(V3 p0, V3 d, V3 h, double hi, double p0i, double di, double &tL, double &gL, double &tR, double &gR) {
+    if (di == 0.0) return;
+#pragma unroll
+    for (int sg = 0; sg < 2; sg++) {
+        double tk = ((sg ? hi : -hi) - p0i) / di;
+        if (!(tk > 0.0 && tk < 1.0)) continue;
+        V3 e;
+        double gk = segbox_half_fprime(p0, d, h, tk, e);
+        if (gk < 0.0) { if (tk > tL) { tL = tk; gL = gk; } }
+        else { if (tk < tR) { tR = tk; gR = gk; } }
+    }
+}
+MOPA_HD double d_capsule_box(const double *C, const double *B) {
+    V3 h = ld3(B + GO_SIZE);
+    V3 a = col3(C + GO_MAT, 2);
+    V3 v = sub3(ld3(C + GO_POS), ld3(B + GO_POS));
+    V3 cl = matT_vec(B + GO_MAT, v);
+    V3 al = matT_vec(B + GO_MAT, a);
+    double hh = C[GO_SIZE + 1];
+    V3 p0 = addscl3(cl, al, -hh);
+    V3 d{al.x * (2.0 * hh), al.y * (2.0 * hh), al.z * (2.0 * hh)};
+    V3 e;
+    double tstar;
+    double g0 = segbox_half_fprime(p0, d, h, 0.0, e);
+    if (g0 >= 0.0) tstar = 0.0;
+    else {
+        double g1 = segbox_half_fprime(p0, d, h, 1.0, e);
+        if (g1 <= 0.0) tstar = 1.0;
+        else {
+            double tL = 0.0, gL = g0, tR = 1.0, gR = g1;
+            segbox_knot(p0, d, h, h.x, p0.x, d.x, tL, gL, tR, gR);
+            segbox_knot(p0, d, h, h.y, p0.y, d.y, tL, gL, tR, gR);
+            segbox_knot(p0, d, h, h.z, p0.z, d.z, tL, gL, tR, gR);
+            tstar = fma(tR - tL, (-gL) / (gR - gL), tL);
+        }
+    }
+    segbox_half_fprime(p0, d, h, tstar, e);
+    double dseg = norm3(e);
+    if (dseg > 0.0) return dseg - C[GO_SIZE];
+    // the axis segment pierces the box: SAT depth of segment vs box (+ radius)
+    V3 m = addscl3(p0, d, 0.5);
+    V3 hd{0.5 * d.x, 0.5 * d.y, 0.5 * d.z};
+    double best = -kFar;
+    best = dmax(best, fabs(m.x) - (h.x + fabs(hd.x)));
+    best = dmax(best, fabs(m.y) - (h.y + fabs(hd.y)));
+    best = dmax(best, fabs(m.z) - (h.z + fabs(hd.z)));
+    const double mm[3] = {m.x, m.y, m.z}, aa[3] = {al.x, al.y, al.z}, hb[3] = {h.x, h.y, h.z};
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        double l2 = fma(aa[k], aa[k], aa[j] * aa[j]);
+        if (l2 < 1e-12) continue;
+        double tl = fma(mm[k], aa[j], -(mm[j] * aa[k]));
+        double ra = fma(hb[k], fabs(aa[j]), hb[j] * fabs(aa[k]));
+        best = dmax(best, (fabs(tl) - ra) / sqrt(l2));
+    }
+    return best - C[GO_SIZE];
+}
+
+// 15-axis SAT: max normalised separation (<= 0: minus the minimum translation depth)
+MOPA_HD double d_box_box(const double *A, const double *B) {
+    const double *Am = A + GO_MAT, *Bm = B + GO_MAT;
+    double R[3][3], AR[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            R[i][j] = fma(Am[6 + i], Bm[6 + j], fma(Am[3 + i], Bm[3 + j], Am[i] * Bm[j]));
+            AR[i][j] = fabs(R[i][j]);
+        }
+    V3 tv = matT_vec(Am, sub3(ld3(B + GO_POS), ld3(A + GO_POS)));
+    const double t[3] = {tv.x, tv.y, tv.z};
+    const double ha[3] = {A[GO_SIZE], A[GO_SIZE + 1], A[GO_SIZE + 2]}, hb[3] = {B[GO_SIZE], B[GO_SIZE + 1], B[GO_SIZE + 2]};
+    double best = -kFar;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double rb = fma(hb[2], AR[i][2], fma(hb[1], AR[i][1], hb[0] * AR[i][0]));
+        best = dmax(best, fabs(t[i]) - (ha[i] + rb));
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        double tb = fma(t[2], R[2][j], fma(t[1], R[1][j], t[0] * R[0][j]));
+        double ra = fma(ha[2], AR[2][j], fma(ha[1], AR[1][j], ha[0] * AR[0][j]));
+        best = dmax(best, fabs(tb) - (ra + hb[j]));
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+            double l2 = fma(R[i2][j], R[i2][j], R[i1][j] * R[i1][j]);
+            if (l2 < 1e-12) continue;
+            double tl = fma(t[i2], R[i1][j], -(t[i1] * R[i2][j]));
+            double ra = fma(ha[i2], AR[i1][j], ha[i1] * AR[i2][j]);
+            double rb = fma(hb[j2], AR[i][j1], hb[j1] * AR[i][j2]);
+            best = dmax(best, (fabs(tl) - (ra + rb)) / sqrt(l2));
+        }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------
+// [3P] libccd MPR penetration with MuJoCo's support functions
+// ---------------------------------------------------------------------------
+MOPA_HD bool is_zero(double x) { return fabs(x) < kCcdEps; }
+MOPA_HD bool ccd_eq(double a, double b) {
+    double ab = fabs(a - b);
+    if (ab < kCcdEps) return true;
+    a = fabs(a); b = fabs(b);
+    if (b > a) return ab < kCcdEps * b;
+    return ab < kCcdEps * a;
+}
+MOPA_HD bool vec_eq0(V3 a) { return ccd_eq(a.x, 0.0) && ccd_eq(a.y, 0.0) && ccd_eq(a.z, 0.0); }
+MOPA_HD V3 normalize3(V3 v) {
+    double inv = 1.0 / norm3(v);
+    return V3{v.x * inv, v.y * inv, v.z * inv};
+}
+MOPA_HD V3 support_geom(const double *g, int type, V3 dir) {
+    V3 ld = matT_vec(g + GO_MAT, dir);
+    V3 lr;
+    if (type == G_CAPSULE) {
+        lr.x = ld.x * g[GO_SIZE]; lr.y = ld.y * g[GO_SIZE];
+        lr.z = fma(ld.z, g[GO_SIZE], signd(ld.z) * g[GO_SIZE + 1]);
+    } else if (type == G_CYLINDER) {
+        double tmp = sqrt(fma(ld.y, ld.y, ld.x * ld.x));
+        if (tmp > kMinVal) {
+            double sc = g[GO_SIZE] / tmp;
+            lr.x = ld.x * sc; lr.y = ld.y * sc;
+        } else { lr.x = 0.0; lr.y = 0.0; }
+        lr.z = signd(ld.z) * g[GO_SIZE + 1];
+    } else if (type == G_BOX) {
+        lr.x = signd(ld.x) * g[GO_SIZE]; lr.y = signd(ld.y) * g[GO_SIZE + 1]; lr.z = signd(ld.z) * g[GO_SIZE + 2];
+    } else {
+        lr.x = ld.x * g[GO_SIZE]; lr.y = ld.y * g[GO_SIZE]; lr.z = ld.z * g[GO_SIZE];
+    }
+    return add3(mat_vec(g + GO_MAT, lr), ld3(g + GO_POS));
+}
+MOPA_HD V3 support_md(const double *g1, int t1, const double *g2, int t2, V3 dir) {
+    V3 s1 = support_geom(g1, t1, dir);
+    V3 s2 = support_geom(g2, t2, neg3(dir));
+    return sub3(s1, s2);
+}
+MOPA_HD V3 portal_dir(V3 v1, V3 v2, V3 v3) { return normalize3(cross3(sub3(v2, v1), sub3(v3, v1))); }
+MOPA_HD bool portal_reach_tol(V3 v1, V3 v2, V3 v3, V3 v4, V3 dir) {
+    double dv1 = dot3(v1, dir), dv2 = dot3(v2, dir), dv3 = dot3(v3, dir), dv4 = dot3(v4, dir);
+    double m = dmin(dmin(dv4 - dv1, dv4 - dv2), dv4 - dv3);
+    return ccd_eq(m, kMprTol) || m < kMprTol;
+}
+MOPA_HD void expand_portal(V3 v0, V3 &v1, V3 &v2, V3 &v3, V3 v4) {
+    V3 v4v0 = cross3(v4, v0);
+    double dot = dot3(v1, v4v0);
+    if (dot > 0.0) {
+        dot = dot3(v2, v4v0);
+        if (dot > 0.0) v1 = v4; else v3 = v4;
+    } else {
+        dot = dot3(v3, v4v0);
+        if (dot > 0.0) v2 = v4; else v1 = v4;
+    }
+}
+// squared distance of the origin to segment x0-b / triangle x0-B-C (libccd, witness form)
+MOPA_HD double origin_seg_dist2(V3 x0, V3 b) {
+    V3 d = sub3(b, x0);
+    V3 a = x0;
+    double t = -1.0 * dot3(a, d);
+    t = t / dot3(d, d);
+    if (t < 0.0 || is_zero(t)) return dot3(x0, x0);
+    if (t > 1.0 || ccd_eq(t, 1.0)) return dot3(b, b);
+    V3 w = addscl3(a, d, t);
+    return dot3(w, w);
+}
+MOPA_HD double origin_tri_dist2(V3 x0, V3 B, V3 C) {
+    V3 d1 = sub3(B, x0), d2 = sub3(C, x0), a = x0;
+    double v = dot3(d1, d1), w = dot3(d2, d2);
+    double p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
+    double s = fma(q, r, -(w * p)) / fma(w, v, -(r * r));
+    double t = (fma(-s, r, -q)) / w;
+    if ((is_zero(s) || s > 0.0) && (ccd_eq(s, 1.0) || s < 1.0) && (is_zero(t) || t > 0.0) &&
+        (ccd_eq(t, 1.0) || t < 1.0) && (ccd_eq(t + s, 1.0) || t + s < 1.0)) {
+        V3 wv = addscl3(a, d1, s);
+        wv = addscl3(wv, d2, t);
+        return dot3(wv, wv);
+    }
+    double dist = origin_seg_dist2(x0, B);
+    double dd = origin_seg_dist2(x0, C);
+    if (dd < dist) dist = dd;
+    dd = origin_seg_dist2(B, C);
+    if (dd < dist) dist = dd;
+    return dist;
+}
+// true + depth on intersection
+MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2, double &depth) {
+    V3 v0 = sub3(ld3(g1 + GO_POS), ld3(g2 + GO_POS));
+    if (vec_eq0(v0)) v0.x += kCcdEps * 10.0;
+    V3 dir = normalize3(neg3(v0));
+    V3 v1 = support_md(g1, t1, g2, t2, dir);
+    double dot = dot3(v1, dir);
+    if (is_zero(dot) || dot < 0.0) return false;
+    dir = cross3(v0, v1);
+    if (is_zero(dot3(dir, dir))) {
+        if (vec_eq0(v1)) { depth = 0.0; return true; }
+        depth = norm3(v1);
+        return true;
+    }
+    dir = normalize3(dir);
+    V3 v2 = support_md(g1, t1, g2, t2, dir);
+    dot = dot3(v2, dir);
+    if (is_zero(dot) || dot < 0.0) return false;
+    dir = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+    dot = dot3(dir, v0);
+    if (dot > 0.0) {
+        V3 tmp = v1; v1 = v2; v2 = tmp;
+        dir = neg3(dir);
+    }
+    V3 v3, v4;
+    int it = 0;
+    for (;;) {
+        if (++it > kMprPortalMaxIt) return false;
+        v3 = support_md(g1, t1, g2, t2, dir);
+        dot = dot3(v3, dir);
+        if (is_zero(dot) || dot < 0.0) return false;
+        bool cont = false;
+        dot = dot3(cross3(v1, v3), v0);
+        if (dot < 0.0 && !is_zero(dot)) { v2 = v3; cont = true; }
+        if (!cont) {
+            dot = dot3(cross3(v3, v2), v0);
+            if (dot < 0.0 && !is_zero(dot)) { v1 = v3; cont = true; }
+        }
+        if (!cont) break;
+        dir = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
+    }
+    it = 0;
+    for (;;) {
+        if (++it > kMprPortalMaxIt) return false;
+        dir = portal_dir(v1, v2, v3);
+        dot = dot3(dir, v1);
+        if (is_zero(dot) || dot > 0.0) break;
+        v4 = support_md(g1, t1, g2, t2, dir);
+        dot = dot3(v4, dir);
+        if (!(is_zero(dot) || dot > 0.0) || portal_reach_tol(v1, v2, v3, v4, dir)) return false;
+        expand_portal(v0, v1, v2, v3, v4);
+    }
+    int iterations = 0;
+    for (;;) {
+        dir = portal_dir(v1, v2, v3);
+        v4 = support_md(g1, t1, g2, t2, dir);
+        if (portal_reach_tol(v1, v2, v3, v4, dir) || iterations > kMprMaxIt) {
+            depth = sqrt(origin_tri_dist2(v1, v2, v3));
+            return true;
+        }
+        expand_portal(v0, v1, v2, v3, v4);
+        iterations++;
+    }
+}
+MOPA_HD double d_convex(const double *A, int ta, const double *B, int tb) {
+    double depth;
+    if (mpr_penetration(A, ta, B, tb, depth)) return -depth;
+    return kFar;
+}
+
+MOPA_HD int pair_code(int t1, int t2) {
+    if (t1 == G_PLANE) {
+        if (t2 == G_SPHERE) return PC_PLANE_SPHERE;
+        if (t2 == G_CAPSULE) return PC_PLANE_CAPSULE;
+        if (t2 == G_CYLINDER) return PC_PLANE_CYLINDER;
+        if (t2 == G_BOX) return PC_PLANE_BOX;
+        return -1;
+    }
+    if (t1 == G_SPHERE) {
+        if (t2 == G_SPHERE) return PC_SPHERE_SPHERE;
+        if (t2 == G_CAPSULE) return PC_SPHERE_CAPSULE;
+        if (t2 == G_CYLINDER) return PC_SPHERE_CYLINDER;
+        if (t2 == G_BOX) return PC_SPHERE_BOX;
+        return -1;
+    }
+    if (t1 == G_CAPSULE) {
+        if (t2 == G_CAPSULE) return PC_CAPSULE_CAPSULE;
+        if (t2 == G_CYLINDER) return PC_CONVEX;
+        if (t2 == G_BOX) return PC_CAPSULE_BOX;
+        return -1;
+    }
+    if (t1 == G_CYLINDER) {
+        if (t2 == G_CYLINDER || t2 == G_BOX) return PC_CONVEX;
+        return -1;
+    }
+    if (t1 == G_BOX && t2 == G_BOX) return PC_BOX_BOX;
+    return -1;
+}
+
+MOPA_HD double geom_dist(int code, const double *A, int ta, const double *B, int tb) {
+    switch (code) {
+        case PC_PLANE_SPHERE: return d_plane_sphere(A, B);
+        case PC_PLANE_CAPSULE: return d_plane_capsule(A, B);
+        case PC_PLANE_CYLINDER: return d_plane_cylinder(A, B);
+        case PC_PLANE_BOX: return d_plane_box(A, B);
+        case PC_SPHERE_SPHERE: return d_sphere_sphere(A, B);
+        case PC_SPHERE_CAPSULE: return d_sphere_capsule(A, B);
+        case PC_SPHERE_CYLINDER: return d_sphere_cylinder(A, B);
+        case PC_SPHERE_BOX: return d_sphere_box(A, B);
+        case PC_CAPSULE_CAPSULE: return d_capsule_capsule(A, B);
+        case PC_CAPSULE_BOX: return d_capsule_box(A, B);
+        case PC_BOX_BOX: return d_box_box(A, B);
+        case PC_CONVEX: return d_convex(A, ta, B, tb);
+        default: return kFar;
+    }
+}
+
+// [3P] broad phase: bounding spheres, zero margin (contact_threshold < 0)
+MOPA_HD bool bp_cull(const double *A, int ta, double rba, const double *B, double rbb) {
+    V3 diff = sub3(ld3(B + GO_POS), ld3(A + GO_POS));
+    if (ta == G_PLANE) return dot3(diff, col3(A + GO_MAT, 2)) > rbb;
+    double rs = rba + rbb;
+    return dot3(diff, diff) > rs * rs;
+}
+
+// counter-based RNG: splitmix64 finaliser over (seed, stream, counter)
+MOPA_HD uint64_t mix64(uint64_t z) {
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+    z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+    z ^= z >> 31;
+    return z;
+}
+MOPA_HD double rng_uniform(uint64_t seed, uint64_t stream, uint64_t counter) {
+    uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ULL * (stream + 1));
+    uint64_t r = mix64(k + 0x9E3779B97F4A7C15ULL * (counter + 1));
+    return (double)(r >> 11) * 0x1.0p-53;
+}
+
+}  // namespace mopa

@@ -1,0 +1,812 @@
+// mopa_hip.hip -- libmopa_hip.so: scene compilation, HIP kernels and the C ABI
+// declared in include/mopa_hip.h.  Target: gfx950 (MI355X), wave64.
+//
+// Kernel mapping (DESIGN.md "Kernels"):
+//   one wave64 per planner state.  Scene constants (kinematic chain, geom
+//   table, sorted pair list; ~10 KB) are staged once per workgroup in LDS.
+//   Per state:  lanes [0, n_moving_geoms) run forward kinematics along their
+//   geom's ancestor chain and park the posed geom in a per-wave LDS slab;
+//   all 64 lanes then sweep the candidate pair list (coalesced by pair type),
+//   bounding-sphere cull -> wave-ballot compaction into an LDS worklist ->
+//   narrow phase, with a wave-wide vote for early-out on the first pair that
+//   violates `dist <= contact_threshold`.
+//   FP64 VALU bound, no MFMA (there is no dense contraction on this path).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mopa_hip.h"
+#include "mopa_device.hpp"
+
+using namespace mopa;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(MOPA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)
+
+extern "C" const char *mopa_last_error(void) { return g_err.c_str(); }
+extern "C" const char *mopa_version(void) { return "mopa_hip 0.1.0 (gfx950)"; }
+extern "C" int mopa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+// ---------------------------------------------------------------------------
+// device scene: a header of counts/offsets (kernel argument, lives in SGPRs)
+// plus one blob of doubles and one of ints that every workgroup copies to LDS.
+// ---------------------------------------------------------------------------
+struct SceneHdr {
+    int na, nq, n_pq, nmb, nmj, nsf, ng, nmg, npair;
+    int n_dbl, n_int;            // blob sizes
+    // double-blob offsets
+    int o_mb_pos, o_mb_quat, o_sf_pos, o_sf_quat, o_sf_mat, o_mj_axis, o_mj_pos, o_mj_ref;
+    int o_g_lpos, o_g_lquat, o_g_rbound, o_g_rec, o_act_lo, o_act_hi, o_act_ext;
+    // int-blob offsets
+    int o_mb_parent, o_mb_jntadr, o_mb_jntnum, o_mj_type, o_mj_qsrc, o_g_type, o_g_slot, o_g_mb;
+    int o_mg_geom, o_chain_adr, o_chain_len, o_chain_items, o_pairs, o_pq_adr, o_act_adr, o_act_so2;
+    // per-wave LDS slab (in doubles): geom records, qbuf; then worklist (u16)
+    int wave_dbl, wave_bytes;
+    double thr, range, resolution;
+};
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+
+struct MopaScene {
+    int device = 0;
+    SceneHdr hdr{};
+    std::vector<double> h_dbl;
+    std::vector<int32_t> h_int;
+    double *d_dbl = nullptr;
+    int32_t *d_int = nullptr;
+    int lds_bytes = 0;
+    // host copies for the single-query forms
+    int nq = 0, na = 0, ngeom_model = 0, npair_model = 0;
+    std::vector<int32_t> active_idx;
+    std::vector<int32_t> pair_slot;   // model pair index -> device pair index or -1
+    std::vector<int32_t> geom_model_of_dev;  // (identity; device geoms == model collidable geoms)
+    uint64_t seed = 0;
+    std::string status = "none";
+    // scratch for single-query calls
+    double *d_q = nullptr;      // nq + na + big scratch
+    uint8_t *d_valid = nullptr;
+    double *d_md = nullptr;
+    double *d_dbg = nullptr;
+    size_t dbg_doubles = 0;
+    int n_cu = 256;
+};
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+MOPA_D void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+MOPA_D bool wave_any(bool p) { return __ballot(p) != 0ull; }
+MOPA_D double wave_min(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        double o = __shfl_xor(v, off, 64);
+        v = (o < v) ? o : v;
+    }
+    return v;
+}
+
+struct LdsView {
+    const double *dbl;   // shared scene doubles
+    const int *ints;     // shared scene ints
+    double *grec;        // per-wave posed records of moving geoms [nmg*kGeomStride]
+    double *qbuf;        // per-wave joint values: [na active][n_pq passive]
+    unsigned short *wl;  // per-wave worklist [npair]
+};
+
+MOPA_D void stage_scene(const SceneHdr &h, const double *g_dbl, const int32_t *g_int, double *s_dbl, int *s_int) {
+    for (int i = threadIdx.x; i < h.n_dbl; i += blockDim.x) s_dbl[i] = g_dbl[i];
+    for (int i = threadIdx.x; i < h.n_int; i += blockDim.x) s_int[i] = g_int[i];
+    __syncthreads();
+}
+
+MOPA_D LdsView make_view(const SceneHdr &h, unsigned char *smem) {
+    LdsView v;
+    double *s_dbl = reinterpret_cast<double *>(smem);
+    int *s_int = reinterpret_cast<int *>(s_dbl + h.n_dbl);
+    int int_pad = (h.n_int + 1) & ~1;
+    unsigned char *wave_base = reinterpret_cast<unsigned char *>(s_int + int_pad) + (threadIdx.x >> 6) * h.wave_bytes;
+    v.dbl = s_dbl;
+    v.ints = s_int;
+    v.grec = reinterpret_cast<double *>(wave_base);
+    v.qbuf = v.grec + h.nmg * kGeomStride;
+    v.wl = reinterpret_cast<unsigned short *>(v.qbuf + h.na + h.n_pq);
+    return v;
+}
+
+// posed record of geom g: moving geoms live in the wave slab, static ones in the shared blob
+MOPA_D const double *geom_rec(const SceneHdr &h, const LdsView &v, int g) {
+    int slot = v.ints[h.o_g_slot + g];
+    return (slot >= 0) ? (v.grec + slot * kGeomStride) : (v.dbl + h.o_g_rec + g * kGeomStride);
+}
+
+// Forward kinematics for the state whose joint values are in v.qbuf.
+// Lane l < nmg walks the ancestor chain of moving geom l (same operation order
+// as a parent-first sweep over the body tree) and writes the posed geom.
+MOPA_D void wave_fk(const SceneHdr &h, const LdsView &v, int lane) {
+    if (lane < h.nmg) {
+        const double *D = v.dbl;
+        const int *I = v.ints;
+        int g = I[h.o_mg_geom + lane];
+        int b = I[h.o_g_mb + g];
+        int cadr = I[h.o_chain_adr + b], clen = I[h.o_chain_len + b];
+        V3 pos{0.0, 0.0, 0.0};
+        Q4 quat{1.0, 0.0, 0.0, 0.0};
+        double mat[9];
+        for (int k = 0; k < clen; k++) {
+            int body = I[h.o_chain_items + cadr + k];
+            int ja = I[h.o_mb_jntadr + body], jn = I[h.o_mb_jntnum + body];
+            if (jn == 1 && I[h.o_mj_type + ja] == J_FREE) {
+                const double *qp = v.qbuf + I[h.o_mj_qsrc + ja];
+                pos = V3{qp[0], qp[1], qp[2]};
+                quat = quat_normalize(Q4{qp[3], qp[4], qp[5], qp[6]});
+            } else {
+                V3 ppos;
+                Q4 pquat;
+                if (k == 0) {
+                    int sf = -(I[h.o_mb_parent + body] + 1);
+                    ppos = ld3(D + h.o_sf_pos + 3 * sf);
+                    const double *sq = D + h.o_sf_quat + 4 * sf;
+                    pquat = Q4{sq[0], sq[1], sq[2], sq[3]};
+                    const double *sm = D + h.o_sf_mat + 9 * sf;
+#pragma unroll
+                    for (int i = 0; i < 9; i++) mat[i] = sm[i];
+                } else {
+                    ppos = pos;
+                    pquat = quat;
+                }
+                V3 vv = mat_vec(mat, ld3(D + h.o_mb_pos + 3 * body));
+                pos = add3(ppos, vv);
+                const double *bq = D + h.o_mb_quat + 4 * body;
+                quat = quat_mul(pquat, Q4{bq[0], bq[1], bq[2], bq[3]});
+                for (int j = ja; j < ja + jn; j++) {
+                    V3 ax = ld3(D + h.o_mj_axis + 3 * j), jp = ld3(D + h.o_mj_pos + 3 * j);
+                    V3 xaxis = rot_vec_quat(ax, quat);
+                    V3 xanchor = add3(rot_vec_quat(jp, quat), pos);
+                    double dq = v.qbuf[I[h.o_mj_qsrc + j]] - D[h.o_mj_ref + j];
+                    int jt = I[h.o_mj_type + j];
+                    if (jt == J_SLIDE) {
+                        pos = addscl3(pos, xaxis, dq);
+                    } else if (jt == J_HINGE) {
+                        double sn, cs;
+                        mopa_sincos(0.5 * dq, sn, cs);
+                        quat = quat_mul(quat, Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
+                        V3 vec = rot_vec_quat(jp, quat);
+                        pos = sub3(xanchor, vec);
+                    }
+                }
+                quat = quat_normalize(quat);
+            }
+            quat2mat(mat, quat);
+        }
+        double *rec = v.grec + lane * kGeomStride;
+        V3 gp = add3(pos, mat_vec(mat, ld3(D + h.o_g_lpos + 3 * g)));
+        const double *lq = D + h.o_g_lquat + 4 * g;
+        Q4 gq = quat_mul(quat, Q4{lq[0], lq[1], lq[2], lq[3]});
+        double gm[9];
+        quat2mat(gm, gq);
+        st3(rec + GO_POS, gp);
+#pragma unroll
+        for (int i = 0; i < 9; i++) rec[GO_MAT + i] = gm[i];
+        // size is constant: copied from the shared record
+        const double *srec = D + h.o_g_rec + g * kGeomStride;
+        rec[GO_SIZE] = srec[GO_SIZE]; rec[GO_SIZE + 1] = srec[GO_SIZE + 1]; rec[GO_SIZE + 2] = srec[GO_SIZE + 2];
+    }
+    wave_sync();
+}
+
+// Collision sweep for the posed state.  Returns the wave-uniform verdict.
+// WANT_MD: also produce the minimum distance over broad-phase survivors
+// (disables the early-out so the minimum is complete).
+template <bool WANT_MD>
+MOPA_D bool wave_collide(const SceneHdr &h, const LdsView &v, int lane, double &min_dist) {
+    const int *I = v.ints;
+    const double *D = v.dbl;
+    // 1. broad phase + ballot compaction (order-preserving => worklist stays sorted by pair type)
+    int wl_count = 0;
+    for (int base = 0; base < h.npair; base += 64) {
+        int p = base + lane;
+        bool surv = false;
+        if (p < h.npair) {
+            int pk = I[h.o_pairs + p];
+            int g1 = pk & 0xff, g2 = (pk >> 8) & 0xff;
+            const double *A = geom_rec(h, v, g1), *B = geom_rec(h, v, g2);
+            surv = !bp_cull(A, I[h.o_g_type + g1], D[h.o_g_rbound + g1], B, D[h.o_g_rbound + g2]);
+        }
+        unsigned long long mask = __ballot(surv);
+        if (surv) {
+            int idx = wl_count + __popcll(mask & ((1ull << lane) - 1ull));
+            v.wl[idx] = (unsigned short)p;
+        }
+        wl_count += __popcll(mask);
+    }
+    wave_sync();
+    // 2. narrow phase over the survivors
+    bool bad = false;
+    double md = kFar;
+    for (int base = 0; base < wl_count; base += 64) {
+        int i = base + lane;
+        if (i < wl_count) {
+            int pk = I[h.o_pairs + v.wl[i]];
+            int g1 = pk & 0xff, g2 = (pk >> 8) & 0xff, code = (pk >> 16) & 0xff;
+            const double *A = geom_rec(h, v, g1), *B = geom_rec(h, v, g2);
+            double d = geom_dist(code, A, I[h.o_g_type + g1], B, I[h.o_g_type + g2]);
+            if (d < md) md = d;
+            if (d <= h.thr) bad = true;
+        }
+        if (!WANT_MD && wave_any(bad)) break;
+    }
+    bool any_bad = wave_any(bad);
+    if (WANT_MD) min_dist = wave_min(md);
+    wave_sync();   // worklist / geom slab are about to be reused
+    return !any_bad;
+}
+
+// fill v.qbuf for (env row, active vector)
+MOPA_D void wave_load_state(const SceneHdr &h, const LdsView &v, int lane, const double *q_active, const double *qpos_row) {
+    if (lane < h.na) v.qbuf[lane] = q_active[lane];
+    else if (lane < h.na + h.n_pq) v.qbuf[lane] = qpos_row[v.ints[h.o_pq_adr + lane - h.na]];
+    // models with na + n_pq > 64 loop
+    for (int i = lane + 64; i < h.na + h.n_pq; i += 64)
+        v.qbuf[i] = (i < h.na) ? q_active[i] : qpos_row[v.ints[h.o_pq_adr + i - h.na]];
+    wave_sync();
+}
+
+// ---------------------------------------------------------------------------
+// K1: state validity, one wave per state
+// ---------------------------------------------------------------------------
+template <bool WANT_MD>
+__global__ __launch_bounds__(kBlock) void k_is_valid(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
+                                                      const double *__restrict__ q_active, const double *__restrict__ qpos_env,
+                                                      long long N, long long samples_per_env, unsigned char *__restrict__ valid,
+                                                      double *__restrict__ min_dist) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsView v = make_view(h, smem);
+    stage_scene(h, g_dbl, g_int, const_cast<double *>(v.dbl), const_cast<int *>(v.ints));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long stride = (long long)gridDim.x * kWavesPerBlock;
+    for (long long s = (long long)blockIdx.x * kWavesPerBlock + wave; s < N; s += stride) {
+        long long env = s / samples_per_env;
+        wave_load_state(h, v, lane, q_active + s * h.na, qpos_env + env * h.nq);
+        wave_fk(h, v, lane);
+        double md;
+        bool ok = wave_collide<WANT_MD>(h, v, lane, md);
+        if (lane == 0) {
+            valid[s] = ok ? 1 : 0;
+            if (WANT_MD) min_dist[s] = md;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2: discrete motion validation, one wave per segment
+// ---------------------------------------------------------------------------
+// --- OMPL state-space helpers, per 1-D subspace (RealVectorStateSpace(1) / SO2StateSpace) ---
+MOPA_D double dist_dim(const SceneHdr &h, const LdsView &v, int a, double x, double y) {
+    double d = fabs(x - y);
+    if (v.ints[h.o_act_so2 + a] && d > kPi) d = 2.0 * kPi - d;
+    return d;
+}
+MOPA_D double interp_dim(const SceneHdr &h, const LdsView &v, int a, double from, double to, double t) {
+    double diff = to - from;
+    if (!v.ints[h.o_act_so2 + a] || fabs(diff) <= kPi) return fma(diff, t, from);
+    if (diff > 0.0) diff = 2.0 * kPi - diff; else diff = -2.0 * kPi - diff;
+    double r = fma(-diff, t, from);
+    if (r > kPi) r -= 2.0 * kPi; else if (r < -kPi) r += 2.0 * kPi;
+    return r;
+}
+// CompoundStateSpace::validSegmentCount = max over subspaces of ceil(d_i / (resolution * extent_i))
+MOPA_D int valid_segment_count(const SceneHdr &h, const LdsView &v, const double *qa, const double *qb) {
+    int nd = 0;
+    for (int a = 0; a < h.na; a++) {
+        double seg = h.resolution * v.dbl[h.o_act_ext + a];
+        int c = (int)ceil(dist_dim(h, v, a, qa[a], qb[a]) / seg);
+        if (c > nd) nd = c;
+    }
+    return nd;
+}
+
+__global__ __launch_bounds__(kBlock) void k_check_motion(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
+                                                         const double *__restrict__ qa_all, const double *__restrict__ qb_all,
+                                                         const double *__restrict__ qpos_env, long long N, long long samples_per_env,
+                                                         unsigned char *__restrict__ valid) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsView v = make_view(h, smem);
+    stage_scene(h, g_dbl, g_int, const_cast<double *>(v.dbl), const_cast<int *>(v.ints));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long stride = (long long)gridDim.x * kWavesPerBlock;
+    for (long long s = (long long)blockIdx.x * kWavesPerBlock + wave; s < N; s += stride) {
+        const double *qa = qa_all + s * h.na, *qb = qb_all + s * h.na;
+        const double *row = qpos_env + (s / samples_per_env) * h.nq;
+        int nd = valid_segment_count(h, v, qa, qb);
+        bool ok = true;
+        // k == nd is the end state (tested first, as OMPL does); interior states in index order --
+        // the verdict is order independent.
+        for (int k = nd; k >= 1 && ok; k--) {
+            if (k == nd) {
+                wave_load_state(h, v, lane, qb, row);
+            } else {
+                double t = (double)k / (double)nd;
+                if (lane < h.na) v.qbuf[lane] = interp_dim(h, v, lane, qa[lane], qb[lane], t);
+                else if (lane < h.na + h.n_pq) v.qbuf[lane] = row[v.ints[h.o_pq_adr + lane - h.na]];
+                for (int i = lane + 64; i < h.na + h.n_pq; i += 64)
+                    v.qbuf[i] = (i < h.na) ? interp_dim(h, v, i, qa[i], qb[i], t) : row[v.ints[h.o_pq_adr + i - h.na]];
+                wave_sync();
+            }
+            wave_fk(h, v, lane);
+            double md;
+            ok = wave_collide<false>(h, v, lane, md);
+        }
+        if (nd == 0) {   // qa == qb: OMPL still validates the end state
+            wave_load_state(h, v, lane, qb, row);
+            wave_fk(h, v, lane);
+            double md;
+            ok = wave_collide<false>(h, v, lane, md);
+        }
+        if (lane == 0) valid[s] = ok ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// debug kernels (parity hooks): posed geoms and per-pair distances of one state
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_debug_state(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
+                                                        const double *__restrict__ q_active, const double *__restrict__ qpos_row,
+                                                        double *__restrict__ out_rec /*[ng*16]*/, double *__restrict__ out_dist /*[npair]*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    LdsView v = make_view(h, smem);
+    stage_scene(h, g_dbl, g_int, const_cast<double *>(v.dbl), const_cast<int *>(v.ints));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (wave != 0) return;
+    wave_load_state(h, v, lane, q_active, qpos_row);
+    wave_fk(h, v, lane);
+    for (int g = lane; g < h.ng; g += 64) {
+        const double *r = geom_rec(h, v, g);
+        for (int i = 0; i < kGeomStride; i++) out_rec[g * kGeomStride + i] = (i < 15) ? r[i] : 0.0;
+    }
+    for (int p = lane; p < h.npair; p += 64) {
+        int pk = v.ints[h.o_pairs + p];
+        int g1 = pk & 0xff, g2 = (pk >> 8) & 0xff, code = (pk >> 16) & 0xff;
+        const double *A = geom_rec(h, v, g1), *B = geom_rec(h, v, g2);
+        double d = kFar;
+        if (!bp_cull(A, v.ints[h.o_g_type + g1], v.dbl[h.o_g_rbound + g1], B, v.dbl[h.o_g_rbound + g2]))
+            d = geom_dist(code, A, v.ints[h.o_g_type + g1], B, v.ints[h.o_g_type + g2]);
+        out_dist[p] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host: scene compilation
+// ---------------------------------------------------------------------------
+namespace {
+
+struct Builder {
+    std::vector<double> dbl;
+    std::vector<int32_t> ints;
+    int add_d(const std::vector<double> &v) { int o = (int)dbl.size(); dbl.insert(dbl.end(), v.begin(), v.end()); return o; }
+    int add_i(const std::vector<int32_t> &v) { int o = (int)ints.size(); ints.insert(ints.end(), v.begin(), v.end()); return o; }
+};
+
+double rbound_of(int type, const double *sz) {
+    switch (type) {
+        case G_SPHERE: return sz[0];
+        case G_CAPSULE: return sz[0] + sz[1];
+        case G_CYLINDER: return sqrt(fma(sz[1], sz[1], sz[0] * sz[0]));
+        case G_BOX: return sqrt(fma(sz[2], sz[2], fma(sz[1], sz[1], sz[0] * sz[0])));
+        default: return 0.0;
+    }
+}
+
+}  // namespace
+
+extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
+    if (!desc || !out) return fail(MOPA_ERR_INVALID_ARG, "null argument");
+    const MopaModel &m = desc->model;
+    if (m.nq <= 0 || m.nbody <= 0 || m.ngeom < 0) return fail(MOPA_ERR_INVALID_ARG, "empty model");
+    if (m.ngeom > 255) return fail(MOPA_ERR_LIMIT, "more than 255 collidable geoms");
+    if (m.npair > 65535) return fail(MOPA_ERR_LIMIT, "more than 65535 candidate pairs");
+
+    MopaScene *S = new MopaScene();
+    S->nq = m.nq;
+    S->seed = desc->seed;
+    S->ngeom_model = m.ngeom;
+    S->npair_model = m.npair;
+
+    // --- active / passive split (KinematicPlanner.cpp:263-269) ---
+    std::vector<char> is_passive(m.nq, 0);
+    for (int i = 0; i < desc->n_passive; i++) {
+        int a = desc->passive_qpos_idx[i];
+        if (a < 0 || a >= m.nq) { delete S; return fail(MOPA_ERR_INVALID_ARG, "passive_qpos_idx out of range"); }
+        is_passive[a] = 1;
+    }
+    std::vector<int> qpos_jnt(m.nq, -1);
+    for (int j = 0; j < m.njnt; j++) {
+        int w = (m.jnt_type[j] == J_FREE) ? 7 : (m.jnt_type[j] == J_BALL ? 4 : 1);
+        for (int k = 0; k < w; k++)
+            if (m.jnt_qposadr[j] + k < m.nq) qpos_jnt[m.jnt_qposadr[j] + k] = j;
+    }
+    std::vector<double> act_lo, act_hi, act_ext;
+    std::vector<int32_t> act_adr, act_so2;
+    std::vector<int> active_slot(m.nq, -1);
+    for (int i = 0; i < m.nq; i++) {
+        if (is_passive[i]) continue;
+        int j = qpos_jnt[i];
+        if (j < 0) { delete S; return fail(MOPA_ERR_INVALID_ARG, "active qpos address without a joint"); }
+        if (m.jnt_type[j] == J_FREE || m.jnt_type[j] == J_BALL) {
+            delete S;
+            return fail(MOPA_ERR_UNSUPPORTED, "free/ball joints cannot be planned over (only hinge/slide are active in the reference scenes)");
+        }
+        active_slot[i] = (int)act_adr.size();
+        act_adr.push_back(i);
+        // limited hinge / slide -> R^1 with the joint range; unlimited hinge -> OMPL SO2StateSpace
+        // (mujoco_ompl_interface.cpp:227-249): samples in [-pi, pi], maximum extent pi, wrap-around metric
+        double lo = m.jnt_range[2 * j], hi = m.jnt_range[2 * j + 1];
+        bool so2 = (m.jnt_type[j] == J_HINGE) && !m.jnt_limited[j];
+        if (so2) { lo = -kPi; hi = kPi; }
+        act_lo.push_back(lo);
+        act_hi.push_back(hi);
+        act_ext.push_back(so2 ? kPi : hi - lo);
+        act_so2.push_back(so2 ? 1 : 0);
+    }
+    const int na = (int)act_adr.size();
+    S->na = na;
+    S->active_idx.assign(act_adr.begin(), act_adr.end());
+
+    // --- which bodies matter, which are static ---
+    for (int g = 0; g < m.ngeom; g++) {
+        int t = m.geom_type[g];
+        if (!(t == G_PLANE || t == G_SPHERE || t == G_CAPSULE || t == G_CYLINDER || t == G_BOX)) {
+            delete S;
+            return fail(MOPA_ERR_UNSUPPORTED, "collidable geom type " + std::to_string(t) + " (mesh/ellipsoid/hfield) is not supported yet");
+        }
+    }
+    std::vector<char> needed(m.nbody, 0), is_static(m.nbody, 0);
+    for (int g = 0; g < m.ngeom; g++) {
+        int b = m.geom_body[g];
+        while (b > 0 && !needed[b]) { needed[b] = 1; b = m.body_parent[b]; }
+    }
+    needed[0] = 1;
+    is_static[0] = 1;
+    for (int b = 1; b < m.nbody; b++) is_static[b] = (m.body_jntnum[b] == 0) && is_static[m.body_parent[b]];
+
+    // static world frames (host FK with the same arithmetic as the device path)
+    std::vector<double> xpos(3 * m.nbody, 0.0), xquat(4 * m.nbody, 0.0), xmat(9 * m.nbody, 0.0);
+    xquat[0] = 1.0;
+    quat2mat(&xmat[0], Q4{1.0, 0.0, 0.0, 0.0});
+    for (int b = 1; b < m.nbody; b++) {
+        if (!needed[b] || !is_static[b]) continue;
+        int pid = m.body_parent[b];
+        V3 v = mat_vec(&xmat[9 * pid], ld3(m.body_pos + 3 * b));
+        V3 p = add3(ld3(&xpos[3 * pid]), v);
+        const double *pq = &xquat[4 * pid], *bq = m.body_quat + 4 * b;
+        Q4 q = quat_normalize(quat_mul(Q4{pq[0], pq[1], pq[2], pq[3]}, Q4{bq[0], bq[1], bq[2], bq[3]}));
+        st3(&xpos[3 * b], p);
+        xquat[4 * b] = q.w; xquat[4 * b + 1] = q.x; xquat[4 * b + 2] = q.y; xquat[4 * b + 3] = q.z;
+        quat2mat(&xmat[9 * b], q);
+    }
+
+    // moving bodies in id (topological) order
+    std::vector<int> mb_of_body(m.nbody, -1), sf_of_body(m.nbody, -1);
+    std::vector<int> mb_body;
+    for (int b = 1; b < m.nbody; b++)
+        if (needed[b] && !is_static[b]) { mb_of_body[b] = (int)mb_body.size(); mb_body.push_back(b); }
+    const int nmb = (int)mb_body.size();
+    std::vector<double> sf_pos, sf_quat, sf_mat;
+    auto sf_index = [&](int b) {
+        if (sf_of_body[b] < 0) {
+            sf_of_body[b] = (int)sf_pos.size() / 3;
+            sf_pos.insert(sf_pos.end(), &xpos[3 * b], &xpos[3 * b] + 3);
+            sf_quat.insert(sf_quat.end(), &xquat[4 * b], &xquat[4 * b] + 4);
+            sf_mat.insert(sf_mat.end(), &xmat[9 * b], &xmat[9 * b] + 9);
+        }
+        return sf_of_body[b];
+    };
+    sf_index(0);
+
+    std::vector<double> mb_pos, mb_quat, mj_axis, mj_pos, mj_ref;
+    std::vector<int32_t> mb_parent, mb_jntadr, mb_jntnum, mj_type, mj_qsrc, pq_adr;
+    std::vector<int> pq_slot(m.nq, -1);
+    auto passive_slot = [&](int adr) {
+        if (pq_slot[adr] < 0) { pq_slot[adr] = (int)pq_adr.size(); pq_adr.push_back(adr); }
+        return na + pq_slot[adr];
+    };
+    for (int k = 0; k < nmb; k++) {
+        int b = mb_body[k];
+        int pid = m.body_parent[b];
+        mb_parent.push_back(mb_of_body[pid] >= 0 ? mb_of_body[pid] : -(sf_index(pid) + 1));
+        mb_pos.insert(mb_pos.end(), m.body_pos + 3 * b, m.body_pos + 3 * b + 3);
+        mb_quat.insert(mb_quat.end(), m.body_quat + 4 * b, m.body_quat + 4 * b + 4);
+        mb_jntadr.push_back((int)mj_type.size());
+        mb_jntnum.push_back(m.body_jntnum[b]);
+        for (int j = m.body_jntadr[b]; j < m.body_jntadr[b] + m.body_jntnum[b]; j++) {
+            int t = m.jnt_type[j];
+            if (t == J_BALL) { delete S; return fail(MOPA_ERR_UNSUPPORTED, "ball joints are not supported (the reference throws as well: mujoco_ompl_interface.cpp:217-229)"); }
+            if (t == J_FREE && m.body_jntnum[b] != 1) { delete S; return fail(MOPA_ERR_UNSUPPORTED, "free joint combined with other joints"); }
+            mj_type.push_back(t);
+            mj_axis.insert(mj_axis.end(), m.jnt_axis + 3 * j, m.jnt_axis + 3 * j + 3);
+            mj_pos.insert(mj_pos.end(), m.jnt_pos + 3 * j, m.jnt_pos + 3 * j + 3);
+            mj_ref.push_back(t == J_FREE ? 0.0 : m.jnt_ref[j]);
+            int adr = m.jnt_qposadr[j];
+            if (t == J_FREE) {
+                int first = passive_slot(adr);
+                for (int c = 1; c < 7; c++) {
+                    int sl = passive_slot(adr + c);
+                    if (sl != first + c) { delete S; return fail(MOPA_ERR_UNSUPPORTED, "free joint qpos not contiguous in the passive list"); }
+                }
+                mj_qsrc.push_back(first);
+            } else {
+                mj_qsrc.push_back(active_slot[adr] >= 0 ? active_slot[adr] : passive_slot(adr));
+            }
+        }
+    }
+    const int nmj = (int)mj_type.size();
+    const int n_pq = (int)pq_adr.size();
+
+    // ancestor chains (root-most moving ancestor first)
+    std::vector<int32_t> chain_adr(nmb), chain_len(nmb), chain_items;
+    for (int k = 0; k < nmb; k++) {
+        std::vector<int> path;
+        for (int c = k; c >= 0; c = mb_parent[c]) path.push_back(c);
+        std::reverse(path.begin(), path.end());
+        chain_adr[k] = (int)chain_items.size();
+        chain_len[k] = (int)path.size();
+        chain_items.insert(chain_items.end(), path.begin(), path.end());
+    }
+
+    // geoms
+    std::vector<double> g_lpos(3 * m.ngeom), g_lquat(4 * m.ngeom), g_rbound(m.ngeom), g_rec((size_t)kGeomStride * m.ngeom, 0.0);
+    std::vector<int32_t> g_type(m.ngeom), g_slot(m.ngeom, -1), g_mb(m.ngeom, -1), mg_geom;
+    for (int g = 0; g < m.ngeom; g++) {
+        int b = m.geom_body[g];
+        g_type[g] = m.geom_type[g];
+        g_rbound[g] = rbound_of(m.geom_type[g], m.geom_size + 3 * g);
+        std::memcpy(&g_lpos[3 * g], m.geom_pos + 3 * g, 24);
+        std::memcpy(&g_lquat[4 * g], m.geom_quat + 4 * g, 32);
+        double *rec = &g_rec[(size_t)kGeomStride * g];
+        std::memcpy(rec + GO_SIZE, m.geom_size + 3 * g, 24);
+        if (is_static[b]) {
+            V3 gp = add3(ld3(&xpos[3 * b]), mat_vec(&xmat[9 * b], ld3(m.geom_pos + 3 * g)));
+            const double *bq = &xquat[4 * b], *lq = m.geom_quat + 4 * g;
+            Q4 gq = quat_mul(Q4{bq[0], bq[1], bq[2], bq[3]}, Q4{lq[0], lq[1], lq[2], lq[3]});
+            st3(rec + GO_POS, gp);
+            quat2mat(rec + GO_MAT, gq);
+        } else {
+            g_mb[g] = mb_of_body[b];
+            g_slot[g] = (int)mg_geom.size();
+            mg_geom.push_back(g);
+        }
+    }
+    const int nmg = (int)mg_geom.size();
+    if (nmg > 64) { delete S; return fail(MOPA_ERR_LIMIT, "more than 64 moving collidable geoms"); }
+
+    // pairs: drop ignored (mujoco_ompl_interface.cpp:950-960), sort by narrow-phase cost class
+    struct PairE { int code, g1, g2, model_idx; };
+    std::vector<PairE> pairs;
+    for (int p = 0; p < m.npair; p++) {
+        int g1 = m.pair_geom[2 * p], g2 = m.pair_geom[2 * p + 1];
+        if (g1 < 0 || g1 >= m.ngeom || g2 < 0 || g2 >= m.ngeom) { delete S; return fail(MOPA_ERR_INVALID_ARG, "pair_geom out of range"); }
+        int a = m.geom_mjid[g1], b = m.geom_mjid[g2];
+        int lo = std::min(a, b), hi = std::max(a, b);
+        bool ignored = false;
+        for (int i = 0; i < desc->n_ignored; i++)
+            if (desc->ignored_pairs[2 * i] == lo && desc->ignored_pairs[2 * i + 1] == hi) ignored = true;
+        if (ignored) continue;
+        int code = pair_code(m.geom_type[g1], m.geom_type[g2]);
+        if (code < 0) { delete S; return fail(MOPA_ERR_UNSUPPORTED, "unsupported geom type pair (must be ordered type1<=type2)"); }
+        pairs.push_back(PairE{code, g1, g2, p});
+    }
+    std::stable_sort(pairs.begin(), pairs.end(), [](const PairE &a, const PairE &b) { return a.code < b.code; });
+    std::vector<int32_t> pk(pairs.size());
+    S->pair_slot.assign(m.npair, -1);
+    for (size_t i = 0; i < pairs.size(); i++) {
+        pk[i] = pairs[i].g1 | (pairs[i].g2 << 8) | (pairs[i].code << 16);
+        S->pair_slot[pairs[i].model_idx] = (int)i;
+    }
+
+    // --- assemble blobs ---
+    Builder B;
+    SceneHdr &h = S->hdr;
+    h.na = na; h.nq = m.nq; h.n_pq = n_pq; h.nmb = nmb; h.nmj = nmj; h.nsf = (int)sf_pos.size() / 3;
+    h.ng = m.ngeom; h.nmg = nmg; h.npair = (int)pairs.size();
+    h.o_mb_pos = B.add_d(mb_pos); h.o_mb_quat = B.add_d(mb_quat);
+    h.o_sf_pos = B.add_d(sf_pos); h.o_sf_quat = B.add_d(sf_quat); h.o_sf_mat = B.add_d(sf_mat);
+    h.o_mj_axis = B.add_d(mj_axis); h.o_mj_pos = B.add_d(mj_pos); h.o_mj_ref = B.add_d(mj_ref);
+    h.o_g_lpos = B.add_d(g_lpos); h.o_g_lquat = B.add_d(g_lquat); h.o_g_rbound = B.add_d(g_rbound);
+    if (B.dbl.size() & 1) B.dbl.push_back(0.0);   // 16-byte align the posed records
+    h.o_g_rec = B.add_d(g_rec);
+    h.o_act_lo = B.add_d(act_lo); h.o_act_hi = B.add_d(act_hi); h.o_act_ext = B.add_d(act_ext);
+    if (B.dbl.size() & 1) B.dbl.push_back(0.0);
+    h.o_mb_parent = B.add_i(mb_parent); h.o_mb_jntadr = B.add_i(mb_jntadr); h.o_mb_jntnum = B.add_i(mb_jntnum);
+    h.o_mj_type = B.add_i(mj_type); h.o_mj_qsrc = B.add_i(mj_qsrc);
+    h.o_g_type = B.add_i(g_type); h.o_g_slot = B.add_i(g_slot); h.o_g_mb = B.add_i(g_mb);
+    h.o_mg_geom = B.add_i(mg_geom); h.o_chain_adr = B.add_i(chain_adr); h.o_chain_len = B.add_i(chain_len);
+    h.o_chain_items = B.add_i(chain_items); h.o_pairs = B.add_i(pk); h.o_pq_adr = B.add_i(pq_adr);
+    h.o_act_adr = B.add_i(act_adr); h.o_act_so2 = B.add_i(act_so2);
+    h.n_dbl = (int)B.dbl.size();
+    h.n_int = (int)B.ints.size();
+    h.wave_dbl = nmg * kGeomStride + na + n_pq;
+    int wl_bytes = (int)((pairs.size() * 2 + 15) & ~size_t(15));
+    h.wave_bytes = ((h.wave_dbl * 8 + wl_bytes) + 15) & ~15;
+    h.thr = desc->contact_threshold;
+    h.range = desc->range;
+    h.resolution = desc->resolution > 0.0 ? desc->resolution : 0.005;
+    S->h_dbl = B.dbl;
+    S->h_int = B.ints;
+    S->lds_bytes = h.n_dbl * 8 + ((h.n_int + 1) & ~1) * 4 + kWavesPerBlock * h.wave_bytes;
+    if (S->lds_bytes > 160 * 1024) { delete S; return fail(MOPA_ERR_LIMIT, "scene does not fit the 160 KiB LDS"); }
+
+    // --- device upload ---
+    int ndev = mopa_device_count();
+    if (ndev <= 0) { delete S; return fail(MOPA_ERR_HIP, "no HIP device visible: libmopa_hip has no CPU fallback"); }
+    if (desc->device >= 0) {
+        hipError_t e = hipSetDevice(desc->device);
+        if (e != hipSuccess) { delete S; return fail(MOPA_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
+    }
+    if (hipGetDevice(&S->device) != hipSuccess) { delete S; return fail(MOPA_ERR_HIP, "hipGetDevice failed"); }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, S->device) == hipSuccess) S->n_cu = prop.multiProcessorCount;
+    auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
+        hipError_t e = hipMalloc(dst, bytes ? bytes : 8);
+        if (e != hipSuccess) return e;
+        return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+    };
+    hipError_t e1 = up((void **)&S->d_dbl, S->h_dbl.data(), S->h_dbl.size() * 8);
+    hipError_t e2 = up((void **)&S->d_int, S->h_int.data(), S->h_int.size() * 4);
+    S->dbg_doubles = (size_t)kGeomStride * m.ngeom + pairs.size() + 8;
+    hipError_t e3 = hipMalloc((void **)&S->d_q, sizeof(double) * (size_t)(m.nq + na + 8));
+    hipError_t e4 = hipMalloc((void **)&S->d_valid, 8);
+    hipError_t e5 = hipMalloc((void **)&S->d_md, 8);
+    hipError_t e6 = hipMalloc((void **)&S->d_dbg, sizeof(double) * S->dbg_doubles);
+    for (hipError_t e : {e1, e2, e3, e4, e5, e6})
+        if (e != hipSuccess) { mopa_scene_destroy(S); return fail(MOPA_ERR_HIP, std::string("device allocation: ") + hipGetErrorString(e)); }
+    // allow the dynamic LDS size
+    (void)hipFuncSetAttribute((const void *)k_is_valid<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
+    (void)hipFuncSetAttribute((const void *)k_is_valid<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
+    (void)hipFuncSetAttribute((const void *)k_check_motion, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
+    (void)hipFuncSetAttribute((const void *)k_debug_state, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
+    *out = S;
+    return MOPA_OK;
+}
+
+static void plan_ws_release(MopaScene *S);
+extern "C" void mopa_scene_destroy(MopaScene *S) {
+    if (!S) return;
+    plan_ws_release(S);
+    if (S->d_dbl) (void)hipFree(S->d_dbl);
+    if (S->d_int) (void)hipFree(S->d_int);
+    if (S->d_q) (void)hipFree(S->d_q);
+    if (S->d_valid) (void)hipFree(S->d_valid);
+    if (S->d_md) (void)hipFree(S->d_md);
+    if (S->d_dbg) (void)hipFree(S->d_dbg);
+    delete S;
+}
+
+extern "C" int mopa_scene_num_active(const MopaScene *S) { return S ? S->na : -1; }
+extern "C" int mopa_scene_active_idx(const MopaScene *S, int32_t *out) {
+    if (!S || !out) return fail(MOPA_ERR_INVALID_ARG, "null argument");
+    std::memcpy(out, S->active_idx.data(), sizeof(int32_t) * S->na);
+    return MOPA_OK;
+}
+extern "C" int mopa_scene_num_pairs(const MopaScene *S) { return S ? S->hdr.npair : -1; }
+extern "C" int mopa_scene_lds_bytes(const MopaScene *S) { return S ? S->lds_bytes : -1; }
+
+static int grid_for(const MopaScene *S, int64_t N) {
+    int64_t blocks = (N + kWavesPerBlock - 1) / kWavesPerBlock;
+    int64_t cap = (int64_t)S->n_cu * 8;
+    return (int)std::max<int64_t>(1, std::min(blocks, cap));
+}
+
+extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const double *qpos_env, int64_t N,
+                                   int64_t samples_per_env, uint8_t *valid, double *min_dist, void *stream) {
+    if (!S || !valid || (N > 0 && (!q_active || !qpos_env))) return fail(MOPA_ERR_INVALID_ARG, "null argument");
+    if (N < 0 || samples_per_env <= 0) return fail(MOPA_ERR_INVALID_ARG, "N < 0 or samples_per_env <= 0");
+    if (N == 0) return MOPA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(grid_for(S, N)), block(kBlock);
+    if (min_dist)
+        hipLaunchKernelGGL(k_is_valid<true>, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
+                           (long long)N, (long long)samples_per_env, valid, min_dist);
+    else
+        hipLaunchKernelGGL(k_is_valid<false>, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
+                           (long long)N, (long long)samples_per_env, valid, (double *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return MOPA_OK;
+}
+
+extern "C" int mopa_check_motion_batch(MopaScene *S, const double *qa, const double *qb, const double *qpos_env, int64_t N,
+                                       int64_t samples_per_env, uint8_t *valid, void *stream) {
+    if (!S || !valid || (N > 0 && (!qa || !qb || !qpos_env))) return fail(MOPA_ERR_INVALID_ARG, "null argument");
+    if (N < 0 || samples_per_env <= 0) return fail(MOPA_ERR_INVALID_ARG, "N < 0 or samples_per_env <= 0");
+    if (N == 0) return MOPA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(grid_for(S, N)), block(kBlock);
+    hipLaunchKernelGGL(k_check_motion, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, qa, qb, qpos_env, (long long)N,
+                       (long long)samples_per_env, valid);
+    HIP_TRY(hipGetLastError());
+    return MOPA_OK;
+}
+
+// split a full qpos into (active vector, env row) on the scene's scratch
+static int upload_state(MopaScene *S, const double *qpos_host) {
+    std::vector<double> buf(S->nq + S->na);
+    std::memcpy(buf.data(), qpos_host, sizeof(double) * S->nq);
+    for (int a = 0; a < S->na; a++) buf[S->nq + a] = qpos_host[S->active_idx[a]];
+    HIP_TRY(hipMemcpy(S->d_q, buf.data(), sizeof(double) * buf.size(), hipMemcpyHostToDevice));
+    return MOPA_OK;
+}
+
+extern "C" int mopa_is_valid_state(MopaScene *S, const double *qpos_host, int32_t *valid_out, double *min_dist_out) {
+    if (!S || !qpos_host || !valid_out) return fail(MOPA_ERR_INVALID_ARG, "null argument");
+    int rc = upload_state(S, qpos_host);
+    if (rc) return rc;
+    rc = mopa_is_valid_batch(S, S->d_q + S->nq, S->d_q, 1, 1, S->d_valid, min_dist_out ? S->d_md : nullptr, nullptr);
+    if (rc) return rc;
+    uint8_t v = 0;
+    HIP_TRY(hipMemcpy(&v, S->d_valid, 1, hipMemcpyDeviceToHost));
+    if (min_dist_out) HIP_TRY(hipMemcpy(min_dist_out, S->d_md, 8, hipMemcpyDeviceToHost));
+    *valid_out = v;
+    return MOPA_OK;
+}
+
+static int run_debug(MopaScene *S, const double *qpos_host) {
+    int rc = upload_state(S, qpos_host);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_debug_state, dim3(1), dim3(kBlock), S->lds_bytes, nullptr, S->hdr, S->d_dbl, S->d_int, S->d_q + S->nq,
+                       S->d_q, S->d_dbg, S->d_dbg + (size_t)kGeomStride * S->hdr.ng);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return MOPA_OK;
+}
+
+extern "C" int mopa_debug_fk(MopaScene *S, const double *qpos_host, double *gpos, double *gmat) {
+    if (!S || !qpos_host || !gpos || !gmat) return fail(MOPA_ERR_INVALID_ARG, "null argument");
+    int rc = run_debug(S, qpos_host);
+    if (rc) return rc;
+    std::vector<double> rec((size_t)kGeomStride * S->hdr.ng);
+    HIP_TRY(hipMemcpy(rec.data(), S->d_dbg, rec.size() * 8, hipMemcpyDeviceToHost));
+    for (int g = 0; g < S->hdr.ng; g++) {
+        std::memcpy(gpos + 3 * g, &rec[(size_t)kGeomStride * g + GO_POS], 24);
+        std::memcpy(gmat + 9 * g, &rec[(size_t)kGeomStride * g + GO_MAT], 72);
+    }
+    return MOPA_OK;
+}
+
+extern "C" int mopa_debug_pair_dist(MopaScene *S, const double *qpos_host, double *dist) {
+    if (!S || !qpos_host || !dist) return fail(MOPA_ERR_INVALID_ARG, "null argument");
+    int rc = run_debug(S, qpos_host);
+    if (rc) return rc;
+    std::vector<double> d(S->hdr.npair);
+    if (!d.empty()) HIP_TRY(hipMemcpy(d.data(), S->d_dbg + (size_t)kGeomStride * S->hdr.ng, d.size() * 8, hipMemcpyDeviceToHost));
+    for (int p = 0; p < S->npair_model; p++) dist[p] = (S->pair_slot[p] >= 0) ? d[S->pair_slot[p]] : MOPA_FAR;
+    return MOPA_OK;
+}
+
+extern "C" const char *mopa_planner_status(const MopaScene *S) { return S ? S->status.c_str() : "none"; }
+
+// The planner entry points are defined in mopa_planner.inc (K3).
+#include "mopa_planner.inc"

@@ -61,6 +61,7 @@ enum { G_PLANE = 0, G_HFIELD = 1, G_SPHERE = 2, G_CAPSULE = 3, G_ELLIPSOID = 4, 
 enum { J_FREE = 0, J_BALL = 1, J_SLIDE = 2, J_HINGE = 3 };
 
 #define MINVAL 1e-15 /* mjMINVAL */
+#define ORC_PI 3.14159265358979323846
 
 struct OrcScene {
     int nq, nbody, njnt, ngeom, npair, na;
@@ -73,7 +74,8 @@ struct OrcScene {
     int32_t *pair_geom;
     uint8_t *pair_ignored;
     int32_t *active_idx;   /* qpos addresses planned over */
-    double *act_lo, *act_hi;
+    double *act_lo, *act_hi, *act_ext;
+    uint8_t *act_so2;  /* unlimited hinge -> OMPL SO2StateSpace (mujoco_ompl_interface.cpp:234-239) */
     uint8_t *body_needed;  /* body has a collidable geom below it */
     double thr;
 };
@@ -247,6 +249,8 @@ OrcScene *orc_scene_create(
     s->active_idx = (int32_t *)calloc(nq ? nq : 1, sizeof(int32_t));
     s->act_lo = (double *)calloc(nq ? nq : 1, sizeof(double));
     s->act_hi = (double *)calloc(nq ? nq : 1, sizeof(double));
+    s->act_ext = (double *)calloc(nq ? nq : 1, sizeof(double));
+    s->act_so2 = (uint8_t *)calloc(nq ? nq : 1, 1);
     s->na = 0;
     for (int i = 0; i < nq; i++) {
         int passive = 0;
@@ -255,7 +259,15 @@ OrcScene *orc_scene_create(
             int a = s->na++;
             s->active_idx[a] = i;
             for (int j = 0; j < njnt; j++)
-                if (jnt_qposadr[j] == i) { s->act_lo[a] = jnt_range[2 * j]; s->act_hi[a] = jnt_range[2 * j + 1]; }
+                if (jnt_qposadr[j] == i) {
+                    if (jnt_type[j] == J_HINGE && !jnt_limited[j]) {
+                        /* SO2: samples in [-pi, pi], maximum extent pi */
+                        s->act_so2[a] = 1; s->act_lo[a] = -ORC_PI; s->act_hi[a] = ORC_PI; s->act_ext[a] = ORC_PI;
+                    } else {
+                        s->act_lo[a] = jnt_range[2 * j]; s->act_hi[a] = jnt_range[2 * j + 1];
+                        s->act_ext[a] = s->act_hi[a] - s->act_lo[a];
+                    }
+                }
         }
     }
     s->body_needed = (uint8_t *)calloc(nbody, 1);
@@ -272,7 +284,8 @@ void orc_scene_destroy(OrcScene *s) {
     free(s->jnt_type); free(s->jnt_qposadr); free(s->jnt_limited); free(s->jnt_axis); free(s->jnt_pos);
     free(s->jnt_ref); free(s->jnt_range); free(s->geom_type); free(s->geom_body); free(s->geom_mjid);
     free(s->geom_size); free(s->geom_pos); free(s->geom_quat); free(s->geom_rbound); free(s->pair_geom);
-    free(s->pair_ignored); free(s->active_idx); free(s->act_lo); free(s->act_hi); free(s->body_needed);
+    free(s->pair_ignored); free(s->active_idx); free(s->act_lo); free(s->act_hi); free(s->act_ext); free(s->act_so2);
+    free(s->body_needed);
     free(s);
 }
 int orc_num_active(const OrcScene *s) { return s->na; }
@@ -926,19 +939,35 @@ static int valid_active(const OrcScene *s, const double *qpos_env, const double 
     for (int a = 0; a < s->na; a++) qpos[s->active_idx[a]] = qa[a];
     return is_valid_ws(s, qpos, NULL, ws);
 }
+/* distance in one 1-D subspace: |d| (R^1) or the shorter arc (SO2) */
+static inline double dist_dim(const OrcScene *s, int a, double x, double y) {
+    double d = fabs(x - y);
+    if (s->act_so2[a] && d > ORC_PI) d = 2.0 * ORC_PI - d;
+    return d;
+}
 /* CompoundStateSpace::validSegmentCount = max over 1-D subspaces of
  * ceil(|d_i| / (resolution * extent_i)) */
 static int valid_segment_count(const OrcScene *s, const double *qa, const double *qb, double resolution) {
     int nd = 0;
     for (int a = 0; a < s->na; a++) {
-        double seg = resolution * (s->act_hi[a] - s->act_lo[a]);
-        int c = (int)ceil(fabs(qa[a] - qb[a]) / seg);
+        double seg = resolution * s->act_ext[a];
+        int c = (int)ceil(dist_dim(s, a, qa[a], qb[a]) / seg);
         if (c > nd) nd = c;
     }
     return nd;
 }
+/* RealVectorStateSpace / SO2StateSpace ::interpolate, per 1-D subspace */
 static inline void interpolate(const OrcScene *s, const double *from, const double *to, double t, double *out) {
-    for (int a = 0; a < s->na; a++) out[a] = fma(to[a] - from[a], t, from[a]);
+    for (int a = 0; a < s->na; a++) {
+        double diff = to[a] - from[a];
+        if (!s->act_so2[a] || fabs(diff) <= ORC_PI) out[a] = fma(diff, t, from[a]);
+        else {
+            if (diff > 0.0) diff = 2.0 * ORC_PI - diff; else diff = -2.0 * ORC_PI - diff;
+            double v = fma(-diff, t, from[a]);
+            if (v > ORC_PI) v -= 2.0 * ORC_PI; else if (v < -ORC_PI) v += 2.0 * ORC_PI;
+            out[a] = v;
+        }
+    }
 }
 static int check_motion_ws(const OrcScene *s, const double *qpos_env, const double *qa, const double *qb,
                            double resolution, int64_t *n_checks, double *qpos, double *ws) {
@@ -1020,7 +1049,7 @@ typedef struct { double *q; int *parent; int n, cap; } Tree;
 
 static double dist_l1(const OrcScene *s, const double *a, const double *b) {
     double d = 0.0;
-    for (int i = 0; i < s->na; i++) d += fabs(a[i] - b[i]);
+    for (int i = 0; i < s->na; i++) d += dist_dim(s, i, a[i], b[i]);
     return d;
 }
 static int nearest(const OrcScene *s, const Tree *t, const double *q) {
@@ -1049,7 +1078,7 @@ static int grow_tree(Grow *g, Tree *tree, int is_start, const double *rstate) {
     if (d > g->range) {
         interpolate(s, nstate, rstate, g->range / d, g->xstate);
         int same = 1;
-        for (int a = 0; a < s->na; a++) if (g->xstate[a] != nstate[a]) same = 0;
+        for (int a = 0; a < s->na; a++) if (fabs(g->xstate[a] - nstate[a]) > 2.0 * CCD_EPS) same = 0; /* StateSpace::equalStates */
         if (same) return TRAPPED;
         dstate = g->xstate;
         reach = 0;

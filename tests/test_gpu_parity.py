@@ -1,0 +1,168 @@
+"""GPU parity: HIP kernels (through the C ABI) vs the CPU oracle, bit-exact.
+
+Tolerances: collision verdicts, FK poses, per-pair signed distances, minimum
+distances, motion verdicts and planner outputs must be IDENTICAL (== on the
+float64 bit patterns) -- both sides follow the same IEEE-754 numerics contract
+(DESIGN.md "Numerics"), so any difference is a bug, not round-off.
+"""
+import numpy as np
+import pytest
+
+from conftest import SUPPORTED_ENVS, sample_states
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(env, oracle_mod):
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(env)
+    sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold,
+                    range_=pi.spec.range, seed=7)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    return pi, sc, orc
+
+
+def _full(pi, qa, row):
+    q = row.copy()
+    q[pi.ref_joint_pos_indexes] = qa
+    return q
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_fk_bit_exact(env, oracle_mod):
+    pi, sc, orc = _mk(env, oracle_mod)
+    for mode in ("uniform", "near"):
+        qa, rows = sample_states(pi, 64, 11, mode)
+        for i in range(len(qa)):
+            q = _full(pi, qa[i], rows[0])
+            gp, gm = sc.debug_fk(q)
+            op, om = orc.fk(q)
+            assert np.array_equal(_bits(gp), _bits(op)), f"geom pos differs, state {i}"
+            assert np.array_equal(_bits(gm), _bits(om)), f"geom mat differs, state {i}"
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_pair_dist_bit_exact(env, oracle_mod):
+    pi, sc, orc = _mk(env, oracle_mod)
+    ignored = set(pi.ignored_contacts)
+    m = pi.model
+    ign_mask = np.array([(min(m.geom_mjid[a], m.geom_mjid[b]), max(m.geom_mjid[a], m.geom_mjid[b])) in ignored
+                         for a, b in m.pair_geom])
+    nbad = 0
+    for mode in ("uniform", "near"):
+        qa, rows = sample_states(pi, 96, 5, mode)
+        for i in range(len(qa)):
+            q = _full(pi, qa[i], rows[0])
+            dg = sc.debug_pair_dist(q)
+            do = orc.pair_dist(q)
+            do[ign_mask] = 1.0e10   # the HIP scene drops ignored pairs altogether
+            if not np.array_equal(_bits(dg), _bits(do)):
+                bad = np.where(_bits(dg) != _bits(do))[0]
+                nbad += len(bad)
+                p = bad[0]
+                print("mismatch", env, mode, i, "pair", p, m.pair_geom[p], m.geom_type[m.pair_geom[p]], dg[p], do[p])
+    assert nbad == 0
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+@pytest.mark.parametrize("mode", ["uniform", "near"])
+def test_is_valid_batch_matches_oracle(env, mode, oracle_mod):
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk(env, oracle_mod)
+    bp = BatchPlanner(sc)
+    E, S = 8, 512
+    rng = np.random.default_rng(3)
+    qa, row = sample_states(pi, E * S, 17, mode)
+    rows = np.repeat(row, E, axis=0)
+    # perturb passive entries per env where the scene has them (gripper slides / object pose)
+    if "Sawyer" in env:
+        rows[:, 7:9] = rng.uniform(-0.008, 0.015, size=(E, 2))
+    ov, omd = orc.is_valid_batch(qa, rows, samples_per_env=S, nthreads=0)
+    tq = torch.from_numpy(qa).cuda()
+    tr = torch.from_numpy(rows).cuda()
+    v, md = bp.is_valid(tq, tr, samples_per_env=S, want_min_dist=True)
+    v2 = bp.is_valid(tq, tr, samples_per_env=S)
+    torch.cuda.synchronize()
+    v, md, v2 = v.cpu().numpy(), md.cpu().numpy(), v2.cpu().numpy()
+    assert np.array_equal(v, ov), f"{(v != ov).sum()} verdicts differ (min-dist kernel)"
+    assert np.array_equal(v2, ov), f"{(v2 != ov).sum()} verdicts differ (early-out kernel)"
+    assert np.array_equal(_bits(md), _bits(omd)), f"{(_bits(md) != _bits(omd)).sum()} min distances differ"
+    # both classes must be exercised
+    assert 0 < ov.sum() < len(ov) or mode == "uniform"
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_single_state_api(env, oracle_mod):
+    pi, sc, orc = _mk(env, oracle_mod)
+    qa, rows = sample_states(pi, 32, 23, "near")
+    for i in range(len(qa)):
+        q = _full(pi, qa[i], rows[0])
+        v, md = sc.is_valid_state(q, want_min_dist=True)
+        ov, omd = orc.is_valid(q)
+        assert v == ov and md == omd
+        assert sc.is_valid_state(q) == ov
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_check_motion_matches_oracle(env, oracle_mod):
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk(env, oracle_mod)
+    bp = BatchPlanner(sc)
+    n = 2048
+    qa, row = sample_states(pi, n, 31, "near")
+    rng = np.random.default_rng(9)
+    step = rng.normal(0, 0.05, size=qa.shape)
+    step[: n // 8] = 0.0   # degenerate zero-length segments
+    qb = np.clip(qa + step, pi.jnt_minimum, pi.jnt_maximum)
+    ov = orc.check_motion_batch(qa, qb, row, samples_per_env=n, nthreads=0)
+    v = bp.check_motion(torch.from_numpy(qa).cuda(), torch.from_numpy(qb).cuda(), torch.from_numpy(row).cuda(),
+                        samples_per_env=n)
+    torch.cuda.synchronize()
+    assert np.array_equal(v.cpu().numpy(), ov), f"{(v.cpu().numpy() != ov).sum()} motion verdicts differ"
+    assert 0 < ov.sum() < n
+
+
+@pytest.mark.parametrize("env", ["SawyerPushObstacle-v0", "PusherObstacle-v0"])
+def test_plan_matches_oracle(env, oracle_mod):
+    """Same (seed, env id) sample stream => identical tree growth, path, status and check count."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk(env, oracle_mod)
+    bp = BatchPlanner(sc)
+    E = 16
+    qa, row = sample_states(pi, 4000, 41, "near")
+    ov, _ = orc.is_valid_batch(qa, row, samples_per_env=len(qa))
+    good = qa[ov == 1]
+    assert len(good) >= 2 * E
+    starts = np.repeat(row, E, axis=0)
+    goals = starts.copy()
+    starts[:, pi.ref_joint_pos_indexes] = good[:E]
+    goals[:, pi.ref_joint_pos_indexes] = good[E:2 * E]
+    # one query with an invalid goal
+    bad = qa[ov == 0]
+    if len(bad):
+        goals[0, pi.ref_joint_pos_indexes] = bad[0]
+    max_iters, max_nodes, max_path = 300, 512, 256
+    path, plen, status, nchk = bp.plan(torch.from_numpy(starts).cuda(), torch.from_numpy(goals).cuda(),
+                                       max_iters=max_iters, max_nodes=max_nodes, max_path=max_path, seed=123, env_id_base=5)
+    torch.cuda.synchronize()
+    path, plen, status, nchk = path.cpu().numpy(), plen.cpu().numpy(), status.cpu().numpy(), nchk.cpu().numpy()
+    n_ok = 0
+    for e in range(E):
+        st, opath, ochk, _ = orc.plan(starts[e], goals[e], pi.spec.range, 0.005, max_iters, max_nodes, seed=123,
+                                      env_id=5 + e, max_path=max_path)
+        assert status[e] == st, f"env {e}: status {status[e]} vs oracle {st}"
+        assert plen[e] == len(opath)
+        assert nchk[e] == ochk, f"env {e}: n_checks {nchk[e]} vs oracle {ochk}"
+        assert np.array_equal(_bits(path[e, :plen[e]]), _bits(opath)), f"env {e}: path differs"
+        n_ok += int(st == 0)
+    if len(bad):
+        assert status[0] == -5
+    assert n_ok >= 1

@@ -1,0 +1,72 @@
+"""Multi-GPU plumbing: env sharding + the collectives of the hot path.
+
+One process per GPU (torchrun); `torch.distributed` backend "nccl" is RCCL on ROCm.  The validity /
+planning work itself needs no communication -- every (env, state) is independent -- so envs are block
+partitioned over ranks and the only exchange per step is an all-gather of the uint8 validity masks (and,
+for rollouts, of the transition records).  The reference's only distributed code is host-side mpi4py
+(util/mpi.py:1-33, util/pytorch.py:107-159); `all_reduce_mean_` is the device-side stand-in for its
+`sync_grads` Allreduce(SUM)/size.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+
+def shard_range(n_items: int, world: int, rank: int) -> Tuple[int, int]:
+    """Block partition [lo, hi) of n_items over `world` ranks (first n % world ranks get one extra)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def world_info() -> Tuple[int, int]:
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def all_gather_concat(local, sizes=None):
+    """Concatenate a per-rank tensor along dim 0 on every rank.  Equal sizes use one
+    all_gather_into_tensor; ragged shards (uneven env partition) fall back to padded gather."""
+    import torch
+    dist = _dist()
+    world, _ = world_info()
+    if world == 1:
+        return local
+    n = local.shape[0]
+    if sizes is None:
+        t = torch.tensor([n], dtype=torch.int64, device=local.device)
+        all_n = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(all_n, t)
+        sizes = [int(x.item()) for x in all_n]
+    if len(set(sizes)) == 1:
+        out = torch.empty((world * n,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        try:
+            dist.all_gather_into_tensor(out, local.contiguous())
+            return out
+        except (RuntimeError, NotImplementedError):
+            pass
+    m = max(sizes)
+    pad = torch.zeros((m,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[:n] = local
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+def all_reduce_mean_(flat):
+    """In-place mean over ranks of a flat gradient buffer (reference util/pytorch.py:153-159)."""
+    dist = _dist()
+    world, _ = world_info()
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat /= world
+    return flat

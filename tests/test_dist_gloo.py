@@ -1,0 +1,88 @@
+"""world_size-2 `gloo` test of the env-sharded path (runs on CPU).
+
+Each rank owns a block of envs, computes its validity masks (the oracle stands in for the GPU kernel:
+this is a test of the sharding/gather plumbing in mopa_rl_amd/dist.py, not of the kernel), and the
+all-gathered result must equal the unsharded computation, independent of the number of ranks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, E, S, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import sample_states
+    from mopa_rl_amd.dist import all_gather_concat, all_reduce_mean_, shard_range
+    from mopa_rl_amd.scene import planner_inputs
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pi = planner_inputs("SawyerPushObstacle-v0")
+    orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    qa, row = sample_states(pi, E * S, 5, "near")       # every rank can regenerate the global batch
+    rows = np.repeat(row, E, axis=0)
+    rows[:, 7] = np.linspace(-0.008, 0.015, E)           # per-env passive state
+    lo, hi = shard_range(E, world, rank)
+    v, _ = orc.is_valid_batch(qa[lo * S:hi * S], rows[lo:hi], samples_per_env=S)
+    full = all_gather_concat(torch.from_numpy(v))
+    g = torch.full((10,), float(rank + 1))
+    all_reduce_mean_(g)
+    if rank == 0:
+        q.put((full.numpy(), g.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,E", [(2, 8), (2, 7)])
+def test_sharded_validity_matches_unsharded(world, E, oracle_mod):
+    import torch.multiprocessing as mp
+    from conftest import sample_states
+    from mopa_rl_amd.scene import planner_inputs
+    S = 32
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, E, S, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    full, g = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pi = planner_inputs("SawyerPushObstacle-v0")
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    qa, row = sample_states(pi, E * S, 5, "near")
+    rows = np.repeat(row, E, axis=0)
+    rows[:, 7] = np.linspace(-0.008, 0.015, E)
+    want, _ = orc.is_valid_batch(qa, rows, samples_per_env=S)
+    assert np.array_equal(full, want)
+    np.testing.assert_allclose(g, np.mean(np.arange(1, world + 1)))
+
+
+def test_shard_range_partition():
+    from mopa_rl_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 4096, 4099):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(n, w, k) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [b - a for a, b in r]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(4, 2, 2)

@@ -166,3 +166,66 @@ def test_plan_matches_oracle(env, oracle_mod):
     if len(bad):
         assert status[0] == -5
     assert n_ok >= 1
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_hip_matches_committed_golden(env):
+    """HIP path vs the committed fixtures (tests/golden/*.npz, generated by tools/gen_golden.py) -- no oracle
+    in the loop, so this also runs where the oracle cannot be built."""
+    import os
+    import torch
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(env)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", pi.spec.scene + ".npz"))
+    sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+    bp = BatchPlanner(sc)
+    qa, row = torch.from_numpy(g["q_active"]).cuda(), torch.from_numpy(g["qpos_env"]).cuda()
+    v, md = bp.is_valid(qa, row, samples_per_env=len(qa), want_min_dist=True)
+    mv = bp.check_motion(qa, torch.from_numpy(g["motion_qb"]).cuda(), row, samples_per_env=len(qa))
+    torch.cuda.synchronize()
+    assert np.array_equal(v.cpu().numpy(), g["valid"])
+    assert np.array_equal(_bits(md.cpu().numpy()), _bits(g["min_dist"]))
+    assert np.array_equal(mv.cpu().numpy(), g["motion_valid"])
+    for q, gp, gm in zip(g["fk_qpos"], g["fk_geom_pos"], g["fk_geom_mat"]):
+        p, m = sc.debug_fk(q)
+        assert np.array_equal(_bits(p), _bits(gp)) and np.array_equal(_bits(m.reshape(-1, 9)), _bits(gm.reshape(-1, 9)))
+    it, nodes, mp, seed = (int(x) for x in g["plan_params"])
+    path, plen, status, nchk = bp.plan(torch.from_numpy(g["plan_start"]).cuda(), torch.from_numpy(g["plan_goal"]).cuda(),
+                                       max_iters=it, max_nodes=nodes, max_path=mp, seed=seed, env_id_base=0)
+    torch.cuda.synchronize()
+    assert np.array_equal(status.cpu().numpy(), g["plan_status"]) and np.array_equal(plen.cpu().numpy(), g["plan_len"])
+    assert np.array_equal(nchk.cpu().numpy(), g["plan_checks"])
+    assert np.array_equal(_bits(path.cpu().numpy()), _bits(g["plan_path"]))
+
+
+def test_reference_api_end_to_end():
+    """PlannerAgent.plan()/isValidState() exactly as rl/sac_agent.py:84-110 constructs and calls them."""
+    import types
+    from mopa_rl_amd.planner_agent import PlannerAgent
+    from mopa_rl_amd.scene import default_qpos, planner_inputs
+    env = "SawyerPushObstacle-v0"
+    pi = planner_inputs(env)
+    cfg = types.SimpleNamespace(planner_type="rrt_connect", range=pi.spec.range, planner_objective="path_length",
+                                threshold=0.0, seed=3, _xml_path="sawyer_push_obstacle.xml",
+                                contact_threshold=pi.spec.contact_threshold, timelimit=1.0)
+    agent = PlannerAgent(cfg, 7, pi.non_limited_idx, passive_joint_idx=pi.passive_joint_idx,
+                         ignored_contacts=pi.ignored_contacts, planner_type="rrt_connect", range_=pi.spec.range)
+    q = default_qpos(env, pi.model)
+    assert agent.isValidState(q) is True
+    assert agent.get_planner_status() == "none"
+    goal = q.copy()
+    goal[:7] += [0.3, -0.2, 0.1, 0.2, -0.1, 0.2, 0.3]
+    assert agent.isValidState(goal)
+    traj, success, valid, exact = agent.plan(q, goal, timelimit=1.0)
+    assert success and valid and exact
+    np.testing.assert_array_equal(traj[-1], goal)
+    assert np.all(np.abs(np.diff(np.vstack([q, traj])[:, :7], axis=0)).sum(axis=1) <= pi.spec.range + 1e-12)
+    assert agent.get_planner_status() == "Exact solution"
+    # invalid goal: arm folded into the pedestal
+    bad = q.copy()
+    bad[:7] = [0.0, 1.2, 0.0, 3.0, 0.0, 0.0, 0.0]
+    if not agent.isValidState(bad):
+        traj, success, valid, exact = agent.plan(q, bad)
+        assert not success and not valid and traj.shape == (1, pi.model.nq) and np.all(traj == -5)

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -61,6 +62,9 @@ struct SceneHdr {
     // int-blob offsets
     int o_mb_parent, o_mb_jntadr, o_mb_jntnum, o_mj_type, o_mj_qsrc, o_g_type, o_g_slot, o_g_mb;
     int o_mg_geom, o_chain_adr, o_chain_len, o_chain_items, o_pairs, o_pq_adr, o_act_adr, o_act_so2;
+    // second-generation validity kernel (mopa_valid_v2.inc): DFS program + per-geom pair lists
+    int n_save, n_gp;
+    int o_mb_load, o_mb_save, o_mb_mgadr, o_mb_mgnum, o_mg_padr, o_mg_pnum, o_mg_store, o_gp_word;
     // per-wave LDS slab (in doubles): geom records, qbuf; then worklist (u16)
     int wave_dbl, wave_bytes;
     double thr, range, resolution;
@@ -91,6 +95,11 @@ struct MopaScene {
     double *d_dbg = nullptr;
     size_t dbg_doubles = 0;
     int n_cu = 256;
+    // v2 kernel resources
+    double *d_slab = nullptr;
+    size_t slab_waves = 0;
+    int v2_lds_bytes = 0;
+    int use_v2 = 1;
 };
 
 // ---------------------------------------------------------------------------
@@ -400,6 +409,8 @@ __global__ __launch_bounds__(kBlock) void k_debug_state(SceneHdr h, const double
     }
 }
 
+#include "mopa_valid_v2.inc"
+
 // ---------------------------------------------------------------------------
 // host: scene compilation
 // ---------------------------------------------------------------------------
@@ -628,6 +639,56 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         S->pair_slot[pairs[i].model_idx] = (int)i;
     }
 
+    // --- second-generation kernel: DFS program over the moving bodies + per-geom pair lists ---
+    std::vector<int32_t> mb_load(nmb, -1), mb_save(nmb, -1), mb_mgadr(nmb, 0), mb_mgnum(nmb, 0);
+    int n_save = 0;
+    {
+        std::vector<char> need_save(nmb, 0);
+        for (int k = 0; k < nmb; k++) {
+            int pk = mb_parent[k];
+            if (pk >= 0 && pk != k - 1) need_save[pk] = 1;
+        }
+        std::vector<int> save_depth(nmb, 0);   // number of saved proper ancestors
+        for (int k = 0; k < nmb; k++) {
+            int pk = mb_parent[k];
+            save_depth[k] = (pk >= 0) ? save_depth[pk] + (need_save[pk] ? 1 : 0) : 0;
+            if (need_save[k]) { mb_save[k] = save_depth[k]; n_save = std::max(n_save, save_depth[k] + 1); }
+            if (pk < 0) mb_load[k] = -2;
+            else if (pk == k - 1) mb_load[k] = -1;
+            else mb_load[k] = mb_save[pk];
+        }
+    }
+    // moving geoms are in geom-id order == body order, so each body's geoms are a contiguous slot range
+    for (int mslot = 0; mslot < nmg; mslot++) {
+        int k = g_mb[mg_geom[mslot]];
+        if (mb_mgnum[k] == 0) mb_mgadr[k] = mslot;
+        else if (mb_mgadr[k] + mb_mgnum[k] != mslot) { delete S; return fail(MOPA_ERR_UNSUPPORTED, "moving geoms of a body are not contiguous"); }
+        mb_mgnum[k]++;
+    }
+    for (int k = 1; k < nmb; k++)   // slots must follow body order for the "earlier partner" rule
+        if (mb_mgnum[k] && mb_mgnum[k - 1] && mb_mgadr[k] < mb_mgadr[k - 1]) { delete S; return fail(MOPA_ERR_UNSUPPORTED, "geom order does not follow body order"); }
+    std::vector<int32_t> mg_padr(nmg, 0), mg_pnum(nmg, 0), mg_store(nmg, 0), gp_word;
+    {
+        std::vector<std::vector<PairE>> own(nmg);
+        for (const PairE &e : pairs) {   // already sorted by cost class
+            int s1 = g_slot[e.g1], s2 = g_slot[e.g2];
+            int owner = (s2 > s1) ? s2 : s1;
+            own[owner].push_back(e);
+        }
+        for (int mslot = 0; mslot < nmg; mslot++) {
+            mg_padr[mslot] = (int)gp_word.size();
+            mg_pnum[mslot] = (int)own[mslot].size();
+            for (const PairE &e : own[mslot]) {
+                int cur = mg_geom[mslot];
+                int cur_is_g2 = (e.g2 == cur) ? 1 : 0;
+                int partner = cur_is_g2 ? e.g1 : e.g2;
+                int pslot = g_slot[partner];
+                if (pslot >= 0) mg_store[pslot] = 1;
+                gp_word.push_back(partner | (e.code << 8) | (cur_is_g2 << 12) | ((pslot >= 0 ? 1 : 0) << 13) | ((pslot >= 0 ? pslot : 0) << 14));
+            }
+        }
+    }
+
     // --- assemble blobs ---
     Builder B;
     SceneHdr &h = S->hdr;
@@ -647,6 +708,9 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.o_mg_geom = B.add_i(mg_geom); h.o_chain_adr = B.add_i(chain_adr); h.o_chain_len = B.add_i(chain_len);
     h.o_chain_items = B.add_i(chain_items); h.o_pairs = B.add_i(pk); h.o_pq_adr = B.add_i(pq_adr);
     h.o_act_adr = B.add_i(act_adr); h.o_act_so2 = B.add_i(act_so2);
+    h.n_save = n_save; h.n_gp = (int)gp_word.size();
+    h.o_mb_load = B.add_i(mb_load); h.o_mb_save = B.add_i(mb_save); h.o_mb_mgadr = B.add_i(mb_mgadr); h.o_mb_mgnum = B.add_i(mb_mgnum);
+    h.o_mg_padr = B.add_i(mg_padr); h.o_mg_pnum = B.add_i(mg_pnum); h.o_mg_store = B.add_i(mg_store); h.o_gp_word = B.add_i(gp_word);
     h.n_dbl = (int)B.dbl.size();
     h.n_int = (int)B.ints.size();
     h.wave_dbl = nmg * kGeomStride + na + n_pq;
@@ -659,6 +723,12 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     S->h_int = B.ints;
     S->lds_bytes = h.n_dbl * 8 + ((h.n_int + 1) & ~1) * 4 + kWavesPerBlock * h.wave_bytes;
     if (S->lds_bytes > 160 * 1024) { delete S; return fail(MOPA_ERR_LIMIT, "scene does not fit the 160 KiB LDS"); }
+    {
+        const int per_wave_v2 = ((2 * 7 * kQCapV2 * 8) + kQCapV2 * 4 + 8 + 64 * 8 + 15) & ~15;
+        S->v2_lds_bytes = S->lds_bytes + kWavesPerBlock * per_wave_v2;   // the v2 queues sit behind the v1 slabs
+        const char *ev = std::getenv("MOPA_VALID_KERNEL");
+        S->use_v2 = !(ev && std::string(ev) == "v1") && S->v2_lds_bytes <= 160 * 1024;
+    }
 
     // --- device upload ---
     int ndev = mopa_device_count();
@@ -689,6 +759,8 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     (void)hipFuncSetAttribute((const void *)k_is_valid<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
     (void)hipFuncSetAttribute((const void *)k_check_motion, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
     (void)hipFuncSetAttribute((const void *)k_debug_state, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
+    (void)hipFuncSetAttribute((const void *)k_is_valid_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S->v2_lds_bytes);
+    (void)hipFuncSetAttribute((const void *)k_is_valid_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S->v2_lds_bytes);
     *out = S;
     return MOPA_OK;
 }
@@ -703,6 +775,7 @@ extern "C" void mopa_scene_destroy(MopaScene *S) {
     if (S->d_valid) (void)hipFree(S->d_valid);
     if (S->d_md) (void)hipFree(S->d_md);
     if (S->d_dbg) (void)hipFree(S->d_dbg);
+    if (S->d_slab) (void)hipFree(S->d_slab);
     delete S;
 }
 
@@ -727,7 +800,30 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
     if (N < 0 || samples_per_env <= 0) return fail(MOPA_ERR_INVALID_ARG, "N < 0 or samples_per_env <= 0");
     if (N == 0) return MOPA_OK;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid(grid_for(S, N)), block(kBlock);
+    dim3 block(kBlock);
+    if (S->use_v2 && N >= 64) {
+        // one lane per state, 64-state tiles; 2 workgroups per CU keep the pose slab small and L2 resident
+        int64_t tiles = (N + 63) / 64;
+        int64_t blocks = std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)S->n_cu * 2);
+        size_t waves = (size_t)blocks * kWavesPerBlock;
+        if (waves > S->slab_waves) {
+            if (S->d_slab) (void)hipFree(S->d_slab);
+            S->d_slab = nullptr; S->slab_waves = 0;
+            size_t want = std::max(waves, (size_t)S->n_cu * 2 * kWavesPerBlock);
+            HIP_TRY(hipMalloc((void **)&S->d_slab, want * (size_t)(S->hdr.nmg + S->hdr.n_save) * kSlabStride * sizeof(double)));
+            S->slab_waves = want;
+        }
+        dim3 grid((unsigned)blocks);
+        if (min_dist)
+            hipLaunchKernelGGL(k_is_valid_v2<true>, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
+                               (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, S->lds_bytes);
+        else
+            hipLaunchKernelGGL(k_is_valid_v2<false>, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
+                               (long long)N, (long long)samples_per_env, valid, (double *)nullptr, S->d_slab, S->lds_bytes);
+        HIP_TRY(hipGetLastError());
+        return MOPA_OK;
+    }
+    dim3 grid(grid_for(S, N));
     if (min_dist)
         hipLaunchKernelGGL(k_is_valid<true>, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
                            (long long)N, (long long)samples_per_env, valid, min_dist);

@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmopa_hip.so")
+LIB_PATH = os.environ.get("MOPA_HIP_LIB", os.path.join(_HERE, "csrc", "libmopa_hip.so"))   # env override: A/B builds
 
 MOPA_OK = 0
 MOPA_FAR = 1.0e10

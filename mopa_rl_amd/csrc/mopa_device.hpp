@@ -249,8 +249,11 @@ MOPA_HD void segbox_knot(V3 p0, V3 d, V3 h, double hi, double p0i, double di, do
         if (!(tk > 0.0 && tk < 1.0)) continue;
         V3 e;
         double gk = segbox_half_fprime(p0, d, h, tk, e);
-        if (gk < 0.0) { if (tk > tL) { tL = tk; gL = gk; } }
-        else { if (tk < tR) { tR = tk; gR = gk; } }
+        // branch-free update of the bracket (keeps the four values in registers)
+        const bool upL = (gk < 0.0) && (tk > tL);
+        const bool upR = !(gk < 0.0) && (tk < tR);
+        tL = upL ? tk : tL; gL = upL ? gk : gL;
+        tR = upR ? tk : tR; gR = upR ? gk : gR;
     }
 }
 MOPA_HD double d_capsule_box(const double *C, const double *B) {

@@ -810,10 +810,14 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
             if (S->d_slab) (void)hipFree(S->d_slab);
             S->d_slab = nullptr; S->slab_waves = 0;
             size_t want = std::max(waves, (size_t)S->n_cu * 2 * kWavesPerBlock);
-            HIP_TRY(hipMalloc((void **)&S->d_slab, want * (size_t)(S->hdr.nmg + S->hdr.n_save) * kSlabStride * sizeof(double)));
+            HIP_TRY(hipMalloc((void **)&S->d_slab, (want * (size_t)(S->hdr.nmg + S->hdr.n_save) * kSlabStride + 16) * sizeof(double)));
             S->slab_waves = want;
         }
         dim3 grid((unsigned)blocks);
+#ifdef MOPA_V2_PROFILE
+        unsigned long long *d_prof = (unsigned long long *)(S->d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride);
+        (void)hipMemsetAsync(d_prof, 0, 6 * 8, st);
+#endif
         if (min_dist)
             hipLaunchKernelGGL(k_is_valid_v2<true>, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
                                (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, S->lds_bytes);
@@ -821,6 +825,15 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
             hipLaunchKernelGGL(k_is_valid_v2<false>, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
                                (long long)N, (long long)samples_per_env, valid, (double *)nullptr, S->d_slab, S->lds_bytes);
         HIP_TRY(hipGetLastError());
+#ifdef MOPA_V2_PROFILE
+        {
+            unsigned long long hp[6];
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(hp, d_prof, 48, hipMemcpyDeviceToHost);
+            if (hp[5]) fprintf(stderr, "[v2 profile] per tile cycles: body %.0f geom %.0f cull+push %.0f flush %.0f total %.0f (tiles %llu)\n",
+                               (double)hp[0] / hp[5], (double)hp[1] / hp[5], (double)hp[2] / hp[5], (double)hp[3] / hp[5], (double)hp[4] / hp[5], hp[5]);
+        }
+#endif
         return MOPA_OK;
     }
     dim3 grid(grid_for(S, N));

@@ -65,6 +65,7 @@ struct SceneHdr {
     // second-generation validity kernel (mopa_valid_v2.inc): DFS program + per-geom pair lists
     int n_save, n_gp;
     int o_mb_load, o_mb_save, o_mb_mgadr, o_mb_mgnum, o_mg_padr, o_mg_pnum, o_mg_store, o_gp_word;
+    int o_mbr, o_mbd, o_mgr, o_mgd;   // packed per-body / per-geom records (ints: 8 / 4, doubles: 16 / 8)
     // per-wave LDS slab (in doubles): geom records, qbuf; then worklist (u16)
     int wave_dbl, wave_bytes;
     double thr, range, resolution;
@@ -689,6 +690,33 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         }
     }
 
+    std::vector<int32_t> mbr(8 * (size_t)nmb, 0), mgr(4 * (size_t)nmg, 0);
+    std::vector<double> mbd(16 * (size_t)nmb, 0.0), mgd(8 * (size_t)nmg, 0.0);
+    for (int k = 0; k < nmb; k++) {
+        int ja = mb_jntadr[k], jn = mb_jntnum[k];
+        int32_t *r = &mbr[8 * (size_t)k];
+        r[0] = jn; r[1] = ja; r[2] = mb_load[k]; r[3] = (mb_parent[k] < 0) ? -(mb_parent[k] + 1) : 0;
+        r[4] = mb_save[k]; r[5] = mb_mgadr[k]; r[6] = mb_mgnum[k];
+        r[7] = (jn > 0) ? ((mj_type[ja] & 0xff) | (mj_qsrc[ja] << 8)) : 0xff;
+        double *d = &mbd[16 * (size_t)k];
+        std::memcpy(d, &mb_pos[3 * (size_t)k], 24);
+        std::memcpy(d + 3, &mb_quat[4 * (size_t)k], 32);
+        if (jn > 0) {
+            std::memcpy(d + 7, &mj_axis[3 * (size_t)ja], 24);
+            std::memcpy(d + 10, &mj_pos[3 * (size_t)ja], 24);
+            d[13] = mj_ref[ja];
+        }
+    }
+    for (int ms = 0; ms < nmg; ms++) {
+        int g = mg_geom[ms];
+        int32_t *r = &mgr[4 * (size_t)ms];
+        r[0] = g; r[1] = mg_store[ms]; r[2] = mg_padr[ms]; r[3] = mg_pnum[ms];
+        double *d = &mgd[8 * (size_t)ms];
+        std::memcpy(d, &g_lpos[3 * (size_t)g], 24);
+        std::memcpy(d + 3, &g_lquat[4 * (size_t)g], 32);
+        d[7] = g_rbound[g];
+    }
+
     // --- assemble blobs ---
     Builder B;
     SceneHdr &h = S->hdr;
@@ -702,6 +730,8 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.o_g_rec = B.add_d(g_rec);
     h.o_act_lo = B.add_d(act_lo); h.o_act_hi = B.add_d(act_hi); h.o_act_ext = B.add_d(act_ext);
     if (B.dbl.size() & 1) B.dbl.push_back(0.0);
+    h.o_mbd = B.add_d(mbd); h.o_mgd = B.add_d(mgd);
+    if (B.dbl.size() & 1) B.dbl.push_back(0.0);
     h.o_mb_parent = B.add_i(mb_parent); h.o_mb_jntadr = B.add_i(mb_jntadr); h.o_mb_jntnum = B.add_i(mb_jntnum);
     h.o_mj_type = B.add_i(mj_type); h.o_mj_qsrc = B.add_i(mj_qsrc);
     h.o_g_type = B.add_i(g_type); h.o_g_slot = B.add_i(g_slot); h.o_g_mb = B.add_i(g_mb);
@@ -711,6 +741,8 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.n_save = n_save; h.n_gp = (int)gp_word.size();
     h.o_mb_load = B.add_i(mb_load); h.o_mb_save = B.add_i(mb_save); h.o_mb_mgadr = B.add_i(mb_mgadr); h.o_mb_mgnum = B.add_i(mb_mgnum);
     h.o_mg_padr = B.add_i(mg_padr); h.o_mg_pnum = B.add_i(mg_pnum); h.o_mg_store = B.add_i(mg_store); h.o_gp_word = B.add_i(gp_word);
+    while (B.ints.size() & 7) B.ints.push_back(0);   // 32-byte align the packed records (scalar dwordx8 loads)
+    h.o_mbr = B.add_i(mbr); h.o_mgr = B.add_i(mgr);
     h.n_dbl = (int)B.dbl.size();
     h.n_int = (int)B.ints.size();
     h.wave_dbl = nmg * kGeomStride + na + n_pq;
@@ -724,8 +756,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     S->lds_bytes = h.n_dbl * 8 + ((h.n_int + 1) & ~1) * 4 + kWavesPerBlock * h.wave_bytes;
     if (S->lds_bytes > 160 * 1024) { delete S; return fail(MOPA_ERR_LIMIT, "scene does not fit the 160 KiB LDS"); }
     {
-        const int per_wave_v2 = ((2 * 7 * kQCapV2 * 8) + kQCapV2 * 4 + 8 + 64 * 8 + 15) & ~15;
-        S->v2_lds_bytes = S->lds_bytes + kWavesPerBlock * per_wave_v2;   // the v2 queues sit behind the v1 slabs
+        S->v2_lds_bytes = h.n_dbl * 8 + ((h.n_int + 1) & ~1) * 4 + kWavesPerBlock * kV2LdsPerWave;
         const char *ev = std::getenv("MOPA_VALID_KERNEL");
         S->use_v2 = !(ev && std::string(ev) == "v1") && S->v2_lds_bytes <= 160 * 1024;
     }
@@ -814,16 +845,19 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
             S->slab_waves = want;
         }
         dim3 grid((unsigned)blocks);
+        // [6 profile words | 2 pad | tile counter] live right behind the slabs of this launch's waves
+        double *d_tail = S->d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride;
+        HIP_TRY(hipMemsetAsync(d_tail + 8, 0, 8, st));
 #ifdef MOPA_V2_PROFILE
         unsigned long long *d_prof = (unsigned long long *)(S->d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride);
         (void)hipMemsetAsync(d_prof, 0, 6 * 8, st);
 #endif
         if (min_dist)
             hipLaunchKernelGGL(k_is_valid_v2<true>, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
-                               (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, S->lds_bytes);
+                               (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab);
         else
             hipLaunchKernelGGL(k_is_valid_v2<false>, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
-                               (long long)N, (long long)samples_per_env, valid, (double *)nullptr, S->d_slab, S->lds_bytes);
+                               (long long)N, (long long)samples_per_env, valid, (double *)nullptr, S->d_slab);
         HIP_TRY(hipGetLastError());
 #ifdef MOPA_V2_PROFILE
         {

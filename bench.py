@@ -59,6 +59,44 @@ def make_inputs(torch, pi, E, S, seed, device):
     return qa.reshape(E * S, na).contiguous(), rows.contiguous()
 
 
+def plan_section(torch, bp, pi, E, device):
+    """BASELINE.json configs[2]: E envs, each one RRT-Connect query (K3, one wave per env).  start = init_qpos +
+    N(0, 0.02) (as `_reset`, env/sawyer/sawyer_push_obstacle.py:36-41), goal = a valid state with |dq|_inf <= 0.5
+    (action_range).  Reported next to, not inside, the headline metric."""
+    import time as _t
+    from mopa_rl_amd.scene import default_qpos
+    g = torch.Generator(device=device)
+    g.manual_seed(99)
+    q0 = torch.tensor(default_qpos(ENV, pi.model), dtype=torch.float64, device=device)
+    lo = torch.tensor(pi.jnt_minimum, dtype=torch.float64, device=device)
+    hi = torch.tensor(pi.jnt_maximum, dtype=torch.float64, device=device)
+    start = q0.repeat(E, 1)
+    start[:, :7] += 0.02 * torch.randn(E, 7, generator=g, dtype=torch.float64, device=device)
+    # rejection-sample goals: 8 candidates per env, keep the first valid one (else the start itself)
+    C = 8
+    cand = start[:, None, :7] + (torch.rand(E, C, 7, generator=g, dtype=torch.float64, device=device) - 0.5)
+    cand = torch.minimum(torch.maximum(cand, lo), hi).reshape(E * C, 7).contiguous()
+    ok = bp.is_valid(cand, start.contiguous(), samples_per_env=C).reshape(E, C).bool()
+    first = torch.argmax(ok.int(), dim=1)
+    goal = start.clone()
+    pick = cand.reshape(E, C, 7)[torch.arange(E, device=device), first]
+    goal[:, :7] = torch.where(ok.any(dim=1, keepdim=True), pick, start[:, :7])
+    prm = dict(max_iters=2000, max_nodes=1024, max_path=256, seed=7)
+    bp.plan(start, goal, **prm)
+    torch.cuda.synchronize()
+    reps = 3
+    t0 = _t.perf_counter()
+    for _ in range(reps):
+        path, plen, status, nchk = bp.plan(start, goal, **prm)
+    torch.cuda.synchronize()
+    dt = (_t.perf_counter() - t0) / reps
+    return {"config": f"{ENV}, {E} envs, one RRT-Connect query each (range {pi.spec.range}, resolution 0.005, "
+                      f"{prm['max_iters']} iterations, {prm['max_nodes']} nodes/tree)",
+            "plans_per_s": E / dt, "ms_per_batch": dt * 1e3, "consumed_checks_per_s": float(nchk.sum().item()) / dt,
+            "success_rate": float((status == 0).float().mean().item()), "mean_path_len": float(plen.float().mean().item()),
+            "mean_checks_per_plan": float(nchk.float().mean().item())}
+
+
 def cpu_baseline(pi, qa_host, rows_host, S, budget_states):
     """Oracle (oracle/mopa_oracle.c, kind="port") on the host cores, on the first `budget_states` states."""
     from oracle import oracle as O
@@ -85,6 +123,8 @@ def main():
     ap.add_argument("--samples", type=int, default=256, help="states per env per step")
     ap.add_argument("--cpu-states", type=int, default=1 << 20, help="states timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-plan", action="store_true", help="skip the RRT-Connect section (config 3)")
+    ap.add_argument("--plan-envs", type=int, default=4096)
     args = ap.parse_args()
 
     import torch
@@ -165,6 +205,8 @@ def main():
                          "kernel": "k_is_valid<false>", "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
                          "note": "path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see DESIGN.md"},
         }
+        if not args.no_plan and world == 1:
+            out["planner"] = plan_section(torch, bp, pi, args.plan_envs, device)
         if not args.no_cpu and world == 1:
             cb = cpu_baseline(pi, qa.cpu().numpy(), rows.cpu().numpy(), S, args.cpu_states)
             mism = int((cb["verdicts"] != valid[: cb["n"]].cpu().numpy()).sum())

@@ -145,7 +145,7 @@ MOPA_D LdsView make_view(const SceneHdr &h, unsigned char *smem) {
     v.ints = s_int;
     v.grec = reinterpret_cast<double *>(wave_base);
     v.qbuf = v.grec + h.nmg * kGeomStride;
-    v.wl = reinterpret_cast<unsigned short *>(v.qbuf + h.na + h.n_pq);
+    v.wl = reinterpret_cast<unsigned short *>(v.qbuf + h.na + h.n_pq + h.na);
     return v;
 }
 
@@ -341,6 +341,9 @@ MOPA_D int valid_segment_count(const SceneHdr &h, const LdsView &v, const double
     return nd;
 }
 
+__device__ __noinline__ bool plan_state_valid_impl(const SceneHdr *hp, const double *dbl, const int *ints, double *grec,
+                                                   double *qbuf, unsigned short *wl, int lane, const double *qa, const double *row);
+
 __global__ __launch_bounds__(kBlock) void k_check_motion(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
                                                          const double *__restrict__ qa_all, const double *__restrict__ qb_all,
                                                          const double *__restrict__ qpos_env, long long N, long long samples_per_env,
@@ -355,28 +358,15 @@ __global__ __launch_bounds__(kBlock) void k_check_motion(SceneHdr h, const doubl
         const double *row = qpos_env + (s / samples_per_env) * h.nq;
         int nd = valid_segment_count(h, v, qa, qb);
         bool ok = true;
-        // k == nd is the end state (tested first, as OMPL does); interior states in index order --
-        // the verdict is order independent.
-        for (int k = nd; k >= 1 && ok; k--) {
-            if (k == nd) {
-                wave_load_state(h, v, lane, qb, row);
-            } else {
-                double t = (double)k / (double)nd;
-                if (lane < h.na) v.qbuf[lane] = interp_dim(h, v, lane, qa[lane], qb[lane], t);
-                else if (lane < h.na + h.n_pq) v.qbuf[lane] = row[v.ints[h.o_pq_adr + lane - h.na]];
-                for (int i = lane + 64; i < h.na + h.n_pq; i += 64)
-                    v.qbuf[i] = (i < h.na) ? interp_dim(h, v, i, qa[i], qb[i], t) : row[v.ints[h.o_pq_adr + i - h.na]];
-                wave_sync();
-            }
-            wave_fk(h, v, lane);
-            double md;
-            ok = wave_collide<false>(h, v, lane, md);
-        }
-        if (nd == 0) {   // qa == qb: OMPL still validates the end state
-            wave_load_state(h, v, lane, qb, row);
-            wave_fk(h, v, lane);
-            double md;
-            ok = wave_collide<false>(h, v, lane, md);
+        // k == nd is the end state (tested first, as OMPL does; also the only test when qa == qb); interior
+        // states in index order -- the verdict is order independent.  One call site -> one copy of FK+collision.
+        double *tst = v.qbuf + h.na + h.n_pq;   // spare [na] doubles behind the joint-value buffer
+        for (int k = nd; k >= (nd > 0 ? 1 : 0) && ok; k--) {
+            const double t = (nd > 0) ? (double)k / (double)nd : 1.0;
+            if (lane < h.na) tst[lane] = (k == nd) ? qb[lane] : interp_dim(h, v, lane, qa[lane], qb[lane], t);
+            for (int i = lane + 64; i < h.na; i += 64) tst[i] = (k == nd) ? qb[i] : interp_dim(h, v, i, qa[i], qb[i], t);
+            wave_sync();
+            ok = plan_state_valid_impl(&h, v.dbl, v.ints, v.grec, v.qbuf, v.wl, lane, tst, row);
         }
         if (lane == 0) valid[s] = ok ? 1 : 0;
     }
@@ -745,7 +735,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.o_mbr = B.add_i(mbr); h.o_mgr = B.add_i(mgr);
     h.n_dbl = (int)B.dbl.size();
     h.n_int = (int)B.ints.size();
-    h.wave_dbl = nmg * kGeomStride + na + n_pq;
+    h.wave_dbl = nmg * kGeomStride + na + n_pq + na;   // geom records, joint values, one spare state vector
     int wl_bytes = (int)((pairs.size() * 2 + 15) & ~size_t(15));
     h.wave_bytes = ((h.wave_dbl * 8 + wl_bytes) + 15) & ~15;
     h.thr = desc->contact_threshold;

@@ -53,7 +53,7 @@ extern "C" {
 #define MOPA_PLAN_NO_EXACT (-4)
 #define MOPA_PLAN_INVALID_GOAL (-5)
 
-/* "no penetration found" value of min_dist outputs */
+/* "culled / ignored / no intersection found" value of mopa_debug_pair_dist outputs */
 #define MOPA_FAR 1.0e10
 
 /* geom / joint type codes (MuJoCo's mjtGeom / mjtJoint values) */
@@ -124,8 +124,8 @@ int mopa_scene_lds_bytes(const MopaScene *scene);
 
 /* N states: state i = qpos_env[i / samples_per_env] with its active entries replaced by q_active[i].
  * valid[i] = 1 iff no non-ignored pair has dist <= contact_threshold.
- * min_dist (nullable): minimum signed distance over the pairs that pass the broad phase (MOPA_FAR if none);
- * requesting it disables the wave-level early-out. */
+ * min_dist (nullable): deepest penetration = min(0, minimum signed distance over the non-ignored pairs), i.e. 0.0 for
+ * a state in which nothing penetrates; requesting it disables the per-state early-out. */
 int mopa_is_valid_batch(MopaScene *scene, const double *q_active_dev /*[N,na]*/, const double *qpos_env_dev /*[E,nq]*/,
                         int64_t N, int64_t samples_per_env, uint8_t *valid_dev /*[N]*/, double *min_dist_dev /*[N] or NULL*/,
                         void *stream);

@@ -258,7 +258,7 @@ MOPA_D bool wave_collide(const SceneHdr &h, const LdsView &v, int lane, double &
     wave_sync();
     // 2. narrow phase over the survivors
     bool bad = false;
-    double md = kFar;
+    double md = 0.0;   // deepest penetration: min(0, min over pairs)
     for (int base = 0; base < wl_count; base += 64) {
         int i = base + lane;
         if (i < wl_count) {
@@ -700,7 +700,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     for (int ms = 0; ms < nmg; ms++) {
         int g = mg_geom[ms];
         int32_t *r = &mgr[4 * (size_t)ms];
-        r[0] = g; r[1] = mg_store[ms]; r[2] = mg_padr[ms]; r[3] = mg_pnum[ms];
+        r[0] = g; r[1] = mg_store[ms] | ((m.geom_type[g] == G_BOX ? 1 : 0) << 1); r[2] = mg_padr[ms]; r[3] = mg_pnum[ms];
         double *d = &mgd[8 * (size_t)ms];
         std::memcpy(d, &g_lpos[3 * (size_t)g], 24);
         std::memcpy(d + 3, &g_lquat[4 * (size_t)g], 32);

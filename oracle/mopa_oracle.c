@@ -884,7 +884,7 @@ static int is_valid_ws(const OrcScene *s, const double *qpos, double *min_dist, 
     double *xpos = gmat + 9 * s->ngeom, *xquat = xpos + 3 * s->nbody, *xmat = xquat + 4 * s->nbody;
     fk_bodies(s, qpos, xpos, xquat, xmat, 1);
     fk_geoms(s, xpos, xquat, xmat, gpos, gmat);
-    double md = ORC_FAR;
+    double md = 0.0;   /* deepest penetration: min(0, min over pairs) -- independent of how much the broad phase culls */
     int valid = 1;
     for (int p = 0; p < s->npair; p++) {
         if (s->pair_ignored[p]) continue;

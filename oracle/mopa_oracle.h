@@ -60,7 +60,8 @@ double orc_geom_dist(int t1, const double *size1, const double *pos1, const doub
 /* per-pair distances for one state; culled pairs get ORC_FAR */
 void orc_pair_dist(const OrcScene *s, const double *qpos, double *dist /*[npair]*/);
 
-/* the validity rule; returns 1 valid / 0 invalid; *min_dist over non-ignored pairs */
+/* the validity rule; returns 1 valid / 0 invalid; *min_dist = min(0, min signed distance over the non-ignored
+ * pairs) = deepest penetration (0 when nothing penetrates) */
 int orc_is_valid(const OrcScene *s, const double *qpos, double *min_dist);
 
 /* batch: sample i uses qpos_env[env_of(i)] with active entries replaced by q_active[i] */

@@ -35,7 +35,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6    # AMD datasheet vector FP64 (not in the local guide)
 
 
-def make_inputs(torch, pi, E, S, seed, device):
+def make_inputs(torch, pi, E, S, seed, device, mode="mixed"):
     """States for E envs x S states: first half of every env's block uniform in the joint box (what the RRT
     sampler draws), second half near the env's initial pose (what motion validation sees).  Per-env passive
     block: gripper slides U(-0.008, 0.015), cube pose nominal + U(+-0.05) in xy."""
@@ -50,7 +50,7 @@ def make_inputs(torch, pi, E, S, seed, device):
     qa = lo + (hi - lo) * u
     n = torch.randn(E, S, na, generator=g, dtype=torch.float64, device=device) * 0.3
     near = torch.minimum(torch.maximum(q0[pi.ref_joint_pos_indexes] + n, lo), hi)
-    half = S // 2
+    half = {"mixed": S // 2, "near": 0, "uniform": S}[mode]
     qa[:, half:, :] = near[:, half:, :]
     rows = q0.repeat(E, 1)
     rows[:, 7:9] = -0.008 + 0.023 * torch.rand(E, 2, generator=g, dtype=torch.float64, device=device)
@@ -122,6 +122,8 @@ def main():
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--samples", type=int, default=256, help="states per env per step")
     ap.add_argument("--cpu-states", type=int, default=1 << 20, help="states timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--mode", default="mixed", choices=["mixed", "near", "uniform"],
+                    help="state distribution: the headline workload is `mixed` (50%% uniform joint-box, 50%% near-init)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-plan", action="store_true", help="skip the RRT-Connect section (config 3)")
     ap.add_argument("--plan-envs", type=int, default=4096)
@@ -150,7 +152,7 @@ def main():
     bp = BatchPlanner(scene)
     E, S = args.envs, args.samples
     N = E * S
-    qa, rows = make_inputs(torch, pi, E, S, seed=1234 + rank, device=device)
+    qa, rows = make_inputs(torch, pi, E, S, seed=1234 + rank, device=device, mode=args.mode)
     valid = torch.empty(N, dtype=torch.uint8, device=device)
     gathered = torch.empty(world * N, dtype=torch.uint8, device=device) if world > 1 else None
 
@@ -196,7 +198,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{ENV} state validity (FK + collision), {E} envs/GPU x {S} states/env per step, "
-                                   "states 50% uniform joint-box samples + 50% near-init N(0,0.3)",
+                                   + {"mixed": "states 50% uniform joint-box samples + 50% near-init N(0,0.3)", "near": "states near-init N(0,0.3)",
+                                      "uniform": "states uniform in the joint box"}[args.mode],
                        "envs_per_gpu": E, "states_per_env": S, "pairs_checked_per_state": scene.npair_checked,
                        "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(uint8 masks)" if world > 1 else "")},
             "valid_fraction": n_valid / N,

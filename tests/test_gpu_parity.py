@@ -97,6 +97,40 @@ def test_is_valid_batch_matches_oracle(env, mode, oracle_mod):
     assert 0 < ov.sum() < len(ov) or mode == "uniform"
 
 
+def test_plane_pairs_and_per_env_objects(oracle_mod):
+    """The ground plane only ever touches the free-floating cube in these scenes: park the cube of some envs in the
+    floor / in the arm's way so that plane-box and moving-vs-moving pairs decide the verdict."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    env = "SawyerPushObstacle-v0"
+    pi, sc, orc = _mk(env, oracle_mod)
+    bp = BatchPlanner(sc)
+    E, S = 16, 128
+    qa, row = sample_states(pi, E * S, 91, "near")
+    rows = np.repeat(row, E, axis=0)
+    cube = pi.model.get_joint_qpos_addr("cube")
+    rng = np.random.default_rng(5)
+    rows[0:4, cube:cube + 3] = [1.6, 0.9, 0.02]          # 1 cm into the floor, away from everything else
+    rows[4:8, cube:cube + 3] = [1.6, 0.9, 0.0305]        # 0.5 mm above the -2 mm threshold... still penetrating < 2 mm
+    rows[8:12, cube:cube + 3] = [0.6, 0.1, 1.25] + rng.normal(0, 0.05, (4, 3))   # floating inside the arm's workspace
+    q = rng.normal(size=(4, 4))
+    rows[8:12, cube + 3:cube + 7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    ov, omd = orc.is_valid_batch(qa, rows, samples_per_env=S, nthreads=0)
+    assert ov[:4 * S].sum() == 0 and np.all(omd[:4 * S] <= -0.0099)            # plane-box decides
+    assert 0 < ov[8 * S:12 * S].sum() < 4 * S
+    tq, tr = torch.from_numpy(qa).cuda(), torch.from_numpy(rows).cuda()
+    v, md = bp.is_valid(tq, tr, samples_per_env=S, want_min_dist=True)
+    v2 = bp.is_valid(tq, tr, samples_per_env=S)
+    torch.cuda.synchronize()
+    assert np.array_equal(v.cpu().numpy(), ov) and np.array_equal(v2.cpu().numpy(), ov)
+    assert np.array_equal(_bits(md.cpu().numpy()), _bits(omd))
+    # the single-state (wave-per-state) path must agree as well
+    for e in (0, 5, 9):
+        qf = rows[e].copy()
+        qf[:7] = qa[e * S + 3]
+        assert sc.is_valid_state(qf, want_min_dist=True) == (bool(ov[e * S + 3]), omd[e * S + 3])
+
+
 @pytest.mark.parametrize("env", SUPPORTED_ENVS)
 def test_single_state_api(env, oracle_mod):
     pi, sc, orc = _mk(env, oracle_mod)

@@ -150,3 +150,20 @@ def default_qpos(env: str, model: Optional[CompiledModel] = None) -> np.ndarray:
     if pi.spec.init_qpos:
         q[pi.ref_joint_pos_indexes] = pi.spec.init_qpos
     return q
+
+
+def qpos_joint_arrays(model: CompiledModel, float32_limits: bool = False):
+    """The per-qpos joint bookkeeping of reference env/base.py:62-88: `jnt_indices` (joint id of every qpos
+    address; free joints repeat 7x, ball joints 4x), `jnt_minimum` / `jnt_maximum` per joint (unlimited joints get
+    +-3.14) and `is_jnt_limited`.  `float32_limits=True` reproduces what the SAC/TD3 agents actually hold: they take
+    the limits from `joint_space['default'].low/high`, a float32 gym Box (rl/sac_agent.py:56-57)."""
+    from .mjcf import JNT_BALL, JNT_FREE
+    idx = []
+    for j, t in enumerate(model.jnt_type):
+        idx.extend([j] * (7 if t == JNT_FREE else 4 if t == JNT_BALL else 1))
+    lim = model.jnt_limited.astype(bool)
+    lo = np.where(lim, model.jnt_range[:, 0], -3.14)
+    hi = np.where(lim, model.jnt_range[:, 1], 3.14)
+    if float32_limits:
+        lo, hi = lo.astype(np.float32), hi.astype(np.float32)
+    return np.array(idx, dtype=np.int64), lo, hi, lim

@@ -215,6 +215,13 @@ def main():
             t = json.load(open(tj))
             out["roofline"]["traffic"] = t["traffic_bytes_per_launch"]
             out["roofline"]["traffic_note"] = t["note"]
+            if "valu_insts_per_launch" in t:
+                # FP64 issue roof: a wave64 FP64 op holds a 16-lane SIMD for 4 cycles -> CUs*4*clk/4 wave-instr/s
+                peak = torch.cuda.get_device_properties(device).multi_processor_count * 4 * 2.4e9 / 4
+                ach = t["valu_insts_per_launch"] / (kern_ms * 1e-3)
+                out["roofline"]["valu"] = {"achieved": ach, "peak": peak, "unit": "wave-instr/s", "frac": ach / peak,
+                                           "insts_per_check": t["valu_insts_per_launch"] / t["states_per_launch"],
+                                           "note": "SQ_INSTS_VALU from the committed PMC pass / live kernel time"}
         if not args.no_plan and world == 1:
             out["planner"] = plan_section(torch, bp, pi, args.plan_envs, device)
         if not args.no_cpu and world == 1:

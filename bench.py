@@ -35,6 +35,19 @@ HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 FP64_VALU_PEAK_TFLOPS = 78.6    # AMD datasheet vector FP64 (not in the local guide)
 
 
+def host_cores():
+    """CPU threads this process may really use: min(visible CPUs, cgroup v2 quota) -- the GPU boxes show 256 CPUs
+    but run the container under a 16-CPU quota, and oversubscribed OpenMP teams are slower than 1 thread."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def make_inputs(torch, pi, E, S, seed, device, mode="mixed"):
     """States for E envs x S states: first half of every env's block uniform in the joint box (what the RRT
     sampler draws), second half near the env's initial pose (what motion validation sees).  Per-env passive
@@ -97,6 +110,54 @@ def plan_section(torch, bp, pi, E, device):
             "mean_checks_per_plan": float(nchk.float().mean().item())}
 
 
+def env_step_section(torch, pi, E, device, steps, with_cpu):
+    """The "env-steps/sec" half of BASELINE.json's metric: E kinematic SawyerPushObstacle envs (K4 `k_env_step`),
+    KINEMATIC -- the physics of the reference env.step is replaced by its kinematic limit (mopa_rl_amd/kinematic_env.py),
+    so this is NOT dynamics parity.  Two rates: the bare step, and the step gated by the planner's validity rule on the
+    desired state (block_invalid: one K1 launch + one K4 launch + torch glue per step)."""
+    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
+    out = {"config": f"{ENV} kinematic env.step, {E} envs, uniform policy actions in [-1,1]^7 (ac_scale {pi.spec.ac_scale})",
+           "label": "kinematic limit of the position servo; NOT dynamics parity (no contact forces, cube never moves)"}
+    g = torch.Generator(device=device)
+    g.manual_seed(5)
+    acts = (torch.rand(steps + 2, E, 7, generator=g, dtype=torch.float64, device=device) * 2 - 1).contiguous()
+    for key, block in (("steps_per_s", False), ("steps_per_s_collision_gated", True)):
+        env = BatchKinematicPushEnv(E, device=device, seed=11, block_invalid=block, max_episode_steps=1 << 30)
+        env.reset()
+        q_init = env.qpos.clone()
+        env.step(acts[0]); env.step(acts[1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in range(steps):
+            env.step(acts[2 + t])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[key] = E * steps / dt
+        out[key.replace("steps_per_s", "us_per_batch")] = dt / steps * 1e6
+        if not block and with_cpu:
+            # parity + CPU baseline: replay the same rollout through the CPU checker from the same reset state
+            from oracle import oracle as O
+            orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+            ref = O.OraclePushEnv(orc, env.facts, E, ac_scale=env.ac_scale, max_episode_steps=1 << 30)
+            ref.set_state(q_init.cpu().numpy())
+            a_host = acts.cpu().numpy()
+            cores = host_cores()
+            t0 = time.perf_counter()
+            for t in range(steps + 2):
+                ref.step(a_host[t], nthreads=cores)
+            dt_cpu = time.perf_counter() - t0
+            out["parity_mismatches_vs_oracle"] = int((env.obs.cpu().numpy().view(np.uint64) != ref.obs.view(np.uint64)).sum()
+                                                     + (env.reward.cpu().numpy().view(np.uint64) != ref.reward.view(np.uint64)).sum())
+            t0 = time.perf_counter()
+            ref.step(a_host[0], nthreads=1)
+            dt_1 = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": E * (steps + 2) / dt_cpu, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                                   "single_thread_value": E / dt_1,
+                                   "sample": f"the same {steps + 2} x {E} steps through the oracle's orc_env_step_batch "
+                                             "(OpenMP over envs); our C restatement, not MuJoCo"}
+    return out
+
+
 def cpu_baseline(pi, qa_host, rows_host, S, budget_states):
     """Oracle (oracle/mopa_oracle.c, kind="port") on the host cores, on the first `budget_states` states."""
     from oracle import oracle as O
@@ -105,7 +166,7 @@ def cpu_baseline(pi, qa_host, rows_host, S, budget_states):
     n -= n % S
     qa = qa_host[:n]
     rows = rows_host[: n // S]
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     t0 = time.perf_counter()
     v1, _ = orc.is_valid_batch(qa, rows, samples_per_env=S, nthreads=1, want_min_dist=False)
     t1 = time.perf_counter()
@@ -127,6 +188,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-plan", action="store_true", help="skip the RRT-Connect section (config 3)")
     ap.add_argument("--plan-envs", type=int, default=4096)
+    ap.add_argument("--no-env", action="store_true", help="skip the kinematic env.step section")
     args = ap.parse_args()
 
     import torch
@@ -224,6 +286,8 @@ def main():
                                            "note": "SQ_INSTS_VALU from the committed PMC pass / live kernel time"}
         if not args.no_plan and world == 1:
             out["planner"] = plan_section(torch, bp, pi, args.plan_envs, device)
+        if not args.no_env and world == 1:
+            out["env_step"] = env_step_section(torch, pi, args.envs, device, 50, not args.no_cpu)
         if not args.no_cpu and world == 1:
             cb = cpu_baseline(pi, qa.cpu().numpy(), rows.cpu().numpy(), S, args.cpu_states)
             mism = int((cb["verdicts"] != valid[: cb["n"]].cpu().numpy()).sum())

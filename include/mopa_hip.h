@@ -157,6 +157,59 @@ int mopa_debug_fk(MopaScene *scene, const double *qpos_host /*[nq]*/, double *ge
 /* per-candidate-pair distances (MOPA_FAR for culled / ignored pairs), in MopaModel.pair_geom order */
 int mopa_debug_pair_dist(MopaScene *scene, const double *qpos_host /*[nq]*/, double *dist_host /*[npair]*/);
 
+/* ======================================================================================================
+ *  batched KINEMATIC env.step for the Sawyer push family -- the "env-steps/sec" half
+ * of the metric.  Restates what SawyerPushObstacleEnv computes around the physics:
+ *   action scaling / desired joint state     env/sawyer/sawyer_push_obstacle.py:162-208
+ *   joint-limit clamp + episode bookkeeping  env/base.py:269-314
+ *   reward / success                         env/sawyer/sawyer_push_obstacle.py:71-104
+ *   observation (40 numbers, dict order)     env/sawyer/sawyer.py:317-338, sawyer_push_obstacle.py:106-119
+ * and REPLACES the physics (`_do_simulation`, 75 MuJoCo sub-steps of a position servo) by its kinematic
+ * limit: the arm reaches `desired_state` exactly, velocities are zero, nothing else moves (no contact
+ * forces: the cube never moves).  NOT dynamics parity -- labelled as such wherever it is reported.
+ * ====================================================================================================== */
+#define MOPA_ENV_OBS_DIM 40
+
+typedef struct MopaEnvDesc {
+    MopaModel model;                 /* only the body / joint arrays are read */
+    int32_t n_arm;                   /* env.ref_joint_pos_indexes (7) */
+    const int32_t *arm_qpos_idx;
+    int32_t n_grip;                  /* env.ref_gripper_joint_pos_indexes (2) */
+    const int32_t *grip_qpos_idx;
+    /* frames the obs / reward read, each as (body id, offset in the body frame): */
+    int32_t eef_body;     double eef_off[3];       /* site "grip_site"  (sawyer.py:199) */
+    int32_t rfinger_body; double rfinger_off[3];   /* site "right_eef"  (sawyer_push_obstacle.py:76-79) */
+    int32_t lfinger_body; double lfinger_off[3];   /* site "left_eef" */
+    int32_t ee_quat_body;            /* body "right_ee_attchment" (sawyer.py:334) */
+    int32_t cube_body, target_body;  /* sawyer_push_obstacle.py:27-28 */
+    const double  *qpos_min;         /* [nq] per-qpos joint limits: _jnt_minimum[jnt_indices] (env/base.py:62-88) */
+    const double  *qpos_max;         /* [nq] */
+    const int32_t *qpos_limited;     /* [nq] */
+    double ac_scale;                 /* config/sawyer.py (0.05) */
+    double distance_threshold;       /* 0.06 */
+    double success_reward;           /* 150 */
+    int32_t max_episode_steps;       /* 250 */
+    int32_t device;                  /* HIP device ordinal, -1 = current */
+} MopaEnvDesc;
+
+typedef struct MopaEnv MopaEnv;
+
+int mopa_env_create(const MopaEnvDesc *desc, MopaEnv **out);
+void mopa_env_destroy(MopaEnv *env);
+
+/* One step of E envs (all pointers device, f64 unless noted).  Per env e:
+ *   prev = (is_planner && has_prev[e]) ? prev_state[e] : qpos[e, arm]
+ *   desired = prev + clip(is_planner ? action[e] : action[e]*ac_scale, -ac_scale, +ac_scale)
+ *   if (move_mask == NULL || move_mask[e]) qpos[e, arm] = desired       -- kinematic servo
+ *   prev_state[e] = desired, has_prev[e] = 1; limited qpos entries clipped to their range
+ *   FK -> reward, success, obs; ep_len[e] += 1; done[e] = success || ep_len[e] == max_episode_steps
+ * action == NULL: no step, only FK -> obs (reward/done/success untouched; used after a reset). */
+int mopa_env_step_batch(MopaEnv *env, int64_t E, double *qpos_dev /*[E,nq] in/out*/, double *prev_state_dev /*[E,n_arm] in/out*/,
+                        uint8_t *has_prev_dev /*[E] in/out*/, int32_t *ep_len_dev /*[E] in/out*/,
+                        const double *action_dev /*[E,n_arm] or NULL*/, int32_t is_planner,
+                        const uint8_t *move_mask_dev /*[E] or NULL*/, double *obs_dev /*[E,40]*/,
+                        double *reward_dev /*[E]*/, uint8_t *done_dev /*[E]*/, uint8_t *success_dev /*[E]*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

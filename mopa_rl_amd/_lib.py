@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "mopa_scene_num_active", "mopa_scene_active_idx", "mopa_scene_num_pairs", "mopa_scene_lds_bytes",
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
+    "mopa_env_create", "mopa_env_destroy", "mopa_env_step_batch",
 ]
 
 
@@ -50,6 +51,17 @@ class MopaSceneDesc(C.Structure):
         ("model", MopaModel), ("n_passive", C.c_int32), ("passive_qpos_idx", _ip), ("n_ignored", C.c_int32),
         ("ignored_pairs", _ip), ("contact_threshold", C.c_double), ("range", C.c_double), ("resolution", C.c_double),
         ("seed", C.c_uint64), ("device", C.c_int32),
+    ]
+
+
+class MopaEnvDesc(C.Structure):
+    _fields_ = [
+        ("model", MopaModel), ("n_arm", C.c_int32), ("arm_qpos_idx", _ip), ("n_grip", C.c_int32), ("grip_qpos_idx", _ip),
+        ("eef_body", C.c_int32), ("eef_off", C.c_double * 3), ("rfinger_body", C.c_int32), ("rfinger_off", C.c_double * 3),
+        ("lfinger_body", C.c_int32), ("lfinger_off", C.c_double * 3), ("ee_quat_body", C.c_int32),
+        ("cube_body", C.c_int32), ("target_body", C.c_int32), ("qpos_min", _dp), ("qpos_max", _dp), ("qpos_limited", _ip),
+        ("ac_scale", C.c_double), ("distance_threshold", C.c_double), ("success_reward", C.c_double),
+        ("max_episode_steps", C.c_int32), ("device", C.c_int32),
     ]
 
 
@@ -98,6 +110,10 @@ def lib() -> C.CDLL:
     L.mopa_planner_status.restype = C.c_char_p
     L.mopa_debug_fk.argtypes = [vp, _dp, _dp, _dp]
     L.mopa_debug_pair_dist.argtypes = [vp, _dp, _dp]
+    L.mopa_env_create.argtypes = [C.POINTER(MopaEnvDesc), C.POINTER(vp)]
+    L.mopa_env_destroy.argtypes = [vp]
+    L.mopa_env_destroy.restype = None
+    L.mopa_env_step_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -115,6 +131,21 @@ def _d(a):
 def _i(a):
     a = np.ascontiguousarray(a, dtype=np.int32)
     return a, a.ctypes.data_as(_ip)
+
+
+def model_struct(m, keep: list) -> MopaModel:
+    """MopaModel view of a CompiledModel; the numpy buffers it points at are appended to `keep`."""
+    def d(a):
+        a, p = _d(a); keep.append(a); return p
+
+    def i(a):
+        a, p = _i(a); keep.append(a); return p
+
+    return MopaModel(
+        m.nq, len(m.body_names), len(m.jnt_names), len(m.geom_type), len(m.pair_geom),
+        i(m.body_parent), d(m.body_pos), d(m.body_quat), i(m.body_jntadr), i(m.body_jntnum),
+        i(m.jnt_type), i(m.jnt_qposadr), d(m.jnt_axis), d(m.jnt_pos), d(m.jnt_ref), i(m.jnt_limited), d(m.jnt_range),
+        i(m.geom_type), i(m.geom_body), i(m.geom_mjid), d(m.geom_size), d(m.geom_pos), d(m.geom_quat), i(m.pair_geom))
 
 
 class Scene:

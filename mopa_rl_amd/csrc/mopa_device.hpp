@@ -137,6 +137,38 @@ MOPA_HD void mopa_sincos(double x, double &sout, double &cout) {
     else { sout = -cs; cout = sn; }
 }
 
+// Deterministic exp / tanh for the env reward (never libm / OCML, so CPU oracle and GPU agree bit for bit):
+// k = rint(x*log2(e)); two-term Cody-Waite reduction (fdlibm's ln2 split); degree-13 Taylor kernel in Horner
+// form on |r| <= ln2/2 (truncation error 4e-18); scaling by 2^k through the exponent bits (|x| < 700).
+MOPA_HD double mopa_exp(double x) {
+    const double LOG2E = 1.44269504088896338700e+00, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double k = rint(x * LOG2E);
+    double r = fma(-k, LN2_HI, x);
+    r = fma(-k, LN2_LO, r);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 0.0001984126984126984);
+    p = fma(p, r, 0.001388888888888889);
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    union { unsigned long long u; double d; } sc;
+    sc.u = (unsigned long long)((long long)k + 1023) << 52;
+    return p * sc.d;
+}
+// tanh(x) for x >= 0 (absolute error < 3e-16): (1 - e^-2x) / (1 + e^-2x)
+MOPA_HD double mopa_tanh_pos(double x) {
+    const double t = mopa_exp(-2.0 * x);
+    return (1.0 - t) / (1.0 + t);
+}
+
 // ---------------------------------------------------------------------------
 // One posed primitive as the narrow phase sees it.  `p` points at 15 doubles:
 // pos[3] mat[9] size[3] (LDS on the device, plain memory on the host).

@@ -101,6 +101,7 @@ struct MopaScene {
     size_t slab_waves = 0;
     int v2_lds_bytes = 0;
     int use_v2 = 1;
+    bool v2_forced = false;   // MOPA_VALID_KERNEL=v2: lane-per-state kernel for every N >= 64 (tests, A/B runs)
 };
 
 // ---------------------------------------------------------------------------
@@ -749,6 +750,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         S->v2_lds_bytes = h.n_dbl * 8 + ((h.n_int + 1) & ~1) * 4 + kWavesPerBlock * kV2LdsPerWave;
         const char *ev = std::getenv("MOPA_VALID_KERNEL");
         S->use_v2 = !(ev && std::string(ev) == "v1") && S->v2_lds_bytes <= 160 * 1024;
+        S->v2_forced = ev && std::string(ev) == "v2";
     }
 
     // --- device upload ---
@@ -822,7 +824,12 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
     if (N == 0) return MOPA_OK;
     hipStream_t st = (hipStream_t)stream;
     dim3 block(kBlock);
-    if (S->use_v2 && N >= 64) {
+    // Kernel choice: the lane-per-state kernel needs ~175 us for a 64-state tile however few tiles there are, the
+    // wave-per-state kernel ~23 us per state-wave with 8+ waves per CU in flight -- so small batches (one state per
+    // env, e.g. the collision gate of the kinematic env.step) go to the latter.  Measured crossover on MI355X
+    // (tools/crossover.py): 8192 states 155 vs 171 us, 12288 states 202 vs 168 us  =>  ~36 states per CU.
+    const int64_t v2_min = S->v2_forced ? 64 : std::max<int64_t>(64, (int64_t)S->n_cu * 36);
+    if (S->use_v2 && N >= v2_min) {
         // one lane per state, 64-state tiles; 2 workgroups per CU keep the pose slab small and L2 resident
         int64_t tiles = (N + 63) / 64;
         int64_t blocks = std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)S->n_cu * 2);
@@ -943,3 +950,4 @@ extern "C" const char *mopa_planner_status(const MopaScene *S) { return S ? S->s
 
 // The planner entry points are defined in mopa_planner.inc (K3).
 #include "mopa_planner.inc"
+#include "mopa_env.inc"

@@ -184,6 +184,35 @@ void orc_sincos(double x, double *sout, double *cout) {
     }
 }
 
+/* deterministic exp / tanh shared (as a specification) with the HIP env kernel: see mopa_device.hpp */
+double orc_exp(double x) {
+    const double LOG2E = 1.44269504088896338700e+00, LN2_HI = 6.93147180369123816490e-01, LN2_LO = 1.90821492927058770002e-10;
+    const double k = rint(x * LOG2E);
+    double r = fma(-k, LN2_HI, x);
+    r = fma(-k, LN2_LO, r);
+    double p = 1.6059043836821613e-10;
+    p = fma(p, r, 2.08767569878681e-09);
+    p = fma(p, r, 2.505210838544172e-08);
+    p = fma(p, r, 2.755731922398589e-07);
+    p = fma(p, r, 2.7557319223985893e-06);
+    p = fma(p, r, 2.48015873015873e-05);
+    p = fma(p, r, 0.0001984126984126984);
+    p = fma(p, r, 0.001388888888888889);
+    p = fma(p, r, 0.008333333333333333);
+    p = fma(p, r, 0.041666666666666664);
+    p = fma(p, r, 0.16666666666666666);
+    p = fma(p, r, 0.5);
+    p = fma(p, r, 1.0);
+    p = fma(p, r, 1.0);
+    union { uint64_t u; double d; } sc;
+    sc.u = (uint64_t)((long long)k + 1023) << 52;
+    return p * sc.d;
+}
+double orc_tanh_pos(double x) {
+    const double t = orc_exp(-2.0 * x);
+    return (1.0 - t) / (1.0 + t);
+}
+
 /* ------------------------------------------------------------------ */
 /* scene                                                               */
 /* ------------------------------------------------------------------ */
@@ -1184,4 +1213,94 @@ done:
     if (status != 0 && n_iters_out && status == -5) *n_iters_out = 0;
     free(ws);
     return status;
+}
+
+/* ------------------------------------------------------------------ */
+/*  kinematic env.step of SawyerPushObstacleEnv       */
+/* ------------------------------------------------------------------ */
+/* Restates the arithmetic AROUND the physics of the reference env:
+ *   _step          env/sawyer/sawyer_push_obstacle.py:162-208 (action scaling, desired_state, prev_state)
+ *   _after_step    env/base.py:269-314 (joint-limit clamp, episode length, terminal)
+ *   compute_reward env/sawyer/sawyer_push_obstacle.py:71-104
+ *   _get_obs       env/sawyer/sawyer.py:317-338 + sawyer_push_obstacle.py:106-119 (dict order)
+ * with `_do_simulation` (MuJoCo position servo, 75 sub-steps) replaced by its kinematic limit: the arm reaches
+ * desired_state, velocities are 0, nothing else moves.  NOT dynamics parity.  One deliberate re-ordering: the
+ * joint-limit clamp is applied BEFORE obs/reward (in the reference MuJoCo's limit constraint acts inside the
+ * physics, and the explicit clamp of _after_step runs after the obs was taken). */
+static inline void frame_pos(double *out, const double *xpos, const double *xmat, int b, const double *off) {
+    double v[3];
+    mat_vec(v, xmat + 9 * b, off);
+    add3(out, xpos + 3 * b, v);
+}
+
+void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *prev_state, uint8_t *has_prev,
+                  int32_t *ep_len, const double *action, int is_planner, int move, double *obs, double *reward,
+                  uint8_t *done, uint8_t *success) {
+    const int na = d->n_arm;
+    if (action) {
+        for (int j = 0; j < na; j++) {
+            const int adr = d->arm_qpos_idx[j];
+            const double prev = (is_planner && *has_prev) ? prev_state[j] : qpos[adr];
+            const double a = is_planner ? action[j] : action[j] * d->ac_scale;
+            const double desired = prev + clampd(a, -d->ac_scale, d->ac_scale);
+            if (move) qpos[adr] = desired;
+            prev_state[j] = desired;
+        }
+        *has_prev = 1;
+        for (int i = 0; i < s->nq; i++)
+            if (d->qpos_limited[i]) qpos[i] = clampd(qpos[i], d->qpos_min[i], d->qpos_max[i]);
+    }
+    double *buf = (double *)malloc(sizeof(double) * 16 * s->nbody);
+    double *xpos = buf, *xquat = buf + 3 * s->nbody, *xmat = buf + 7 * s->nbody;
+    fk_bodies(s, qpos, xpos, xquat, xmat, 0);
+    double eef[3], rf[3], lf[3], grip[3], g2c[3];
+    frame_pos(eef, xpos, xmat, d->eef_body, d->eef_off);
+    frame_pos(rf, xpos, xmat, d->rfinger_body, d->rfinger_off);
+    frame_pos(lf, xpos, xmat, d->lfinger_body, d->lfinger_off);
+    const double *cube = xpos + 3 * d->cube_body, *target = xpos + 3 * d->target_body;
+    const double *cq = xquat + 4 * d->cube_body, *eq = xquat + 4 * d->ee_quat_body;
+    for (int i = 0; i < 3; i++) grip[i] = (rf[i] + lf[i]) / 2.0;
+    sub3(g2c, cube, grip);
+    const double gripper_to_cube = norm3(g2c);
+    const double c2t0 = cube[0] - target[0], c2t1 = cube[1] - target[1];
+    const double cube_to_target = sqrt(fma(c2t1, c2t1, c2t0 * c2t0));
+    if (action) {
+        double reward_reach = 0.0, reward_push = 0.0;
+        if (gripper_to_cube < 0.1) reward_reach = 0.1 * (1.0 - orc_tanh_pos(10.0 * gripper_to_cube));
+        if (cube_to_target < 0.1) reward_push = 0.5 * (1.0 - orc_tanh_pos(5.0 * cube_to_target));
+        double r = reward_push + reward_reach;
+        int succ = 0;
+        if (cube_to_target < d->distance_threshold) { r += d->success_reward; succ = 1; }
+        *ep_len += 1;
+        *reward = r;
+        *success = (uint8_t)succ;
+        *done = (uint8_t)(succ || *ep_len == d->max_episode_steps);
+    }
+    int o = 0;
+    for (int j = 0; j < na; j++) obs[o++] = qpos[d->arm_qpos_idx[j]];          /* joint_pos */
+    for (int j = 0; j < na; j++) obs[o++] = 0.0;                               /* joint_vel */
+    for (int j = 0; j < d->n_grip; j++) obs[o++] = qpos[d->grip_qpos_idx[j]];  /* gripper_qpos */
+    for (int j = 0; j < d->n_grip; j++) obs[o++] = 0.0;                        /* gripper_qvel */
+    for (int i = 0; i < 3; i++) obs[o++] = eef[i];                             /* eef_pos */
+    obs[o++] = eq[1]; obs[o++] = eq[2]; obs[o++] = eq[3]; obs[o++] = eq[0];    /* eef_quat, xyzw */
+    for (int i = 0; i < 3; i++) obs[o++] = target[i];                          /* target_pos */
+    for (int i = 0; i < 3; i++) obs[o++] = cube[i];                            /* cube_pos */
+    obs[o++] = cq[1]; obs[o++] = cq[2]; obs[o++] = cq[3]; obs[o++] = cq[0];    /* cube_quat, xyzw */
+    for (int i = 0; i < 3; i++) obs[o++] = eef[i] - cube[i];                   /* gripper_to_cube */
+    obs[o++] = c2t0; obs[o++] = c2t1;                                          /* cube_to_target */
+    free(buf);
+}
+
+/* E envs, rows contiguous; OpenMP across envs (bench.py cpu_baseline of the env-step metric) */
+void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, double *qpos, double *prev_state, uint8_t *has_prev,
+                        int32_t *ep_len, const double *action, int is_planner, const uint8_t *move_mask, double *obs,
+                        double *reward, uint8_t *done, uint8_t *success, int nthreads) {
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (int64_t e = 0; e < E; e++)
+        orc_env_step(s, d, qpos + e * s->nq, prev_state + e * d->n_arm, has_prev + e, ep_len + e,
+                     action ? action + e * d->n_arm : NULL, is_planner, move_mask ? move_mask[e] : 1, obs + e * 40,
+                     reward + e, done + e, success + e);
 }

@@ -86,6 +86,31 @@ int orc_plan(const OrcScene *s, const double *start /*[nq]*/, const double *goal
              double range, double resolution, int max_iters, int max_nodes, uint64_t seed, uint64_t env_id,
              double *path, int max_path, int *path_len, int64_t *n_checks, int *n_iters);
 
+/* deterministic exp / tanh(x>=0) shared (as a specification) with the HIP env kernel */
+double orc_exp(double x);
+double orc_tanh_pos(double x);
+
+/*  kinematic env.step restated -- see the comment on orc_env_step in mopa_oracle.c.
+ * Same fields as MopaEnvDesc (include/mopa_hip.h) without the model. */
+typedef struct OrcEnvDesc {
+    int32_t n_arm; const int32_t *arm_qpos_idx;
+    int32_t n_grip; const int32_t *grip_qpos_idx;
+    int32_t eef_body; double eef_off[3];
+    int32_t rfinger_body; double rfinger_off[3];
+    int32_t lfinger_body; double lfinger_off[3];
+    int32_t ee_quat_body, cube_body, target_body;
+    const double *qpos_min, *qpos_max; const int32_t *qpos_limited;
+    double ac_scale, distance_threshold, success_reward;
+    int32_t max_episode_steps;
+} OrcEnvDesc;
+/* one env, in place; action == NULL: obs only */
+void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos /*[nq]*/, double *prev_state /*[n_arm]*/,
+                  uint8_t *has_prev, int32_t *ep_len, const double *action /*[n_arm] or NULL*/, int is_planner, int move,
+                  double *obs /*[40]*/, double *reward, uint8_t *done, uint8_t *success);
+void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, double *qpos, double *prev_state, uint8_t *has_prev,
+                        int32_t *ep_len, const double *action, int is_planner, const uint8_t *move_mask, double *obs,
+                        double *reward, uint8_t *done, uint8_t *success, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,16 @@ def lib():
         L.orc_plan.restype = C.c_int
         L.orc_plan.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                _dp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        L.orc_exp.restype = C.c_double
+        L.orc_exp.argtypes = [C.c_double]
+        L.orc_tanh_pos.restype = C.c_double
+        L.orc_tanh_pos.argtypes = [C.c_double]
+        L.orc_env_step.restype = None
+        L.orc_env_step.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), _dp, _dp, _u8p, _ip, _dp, C.c_int, C.c_int, _dp, _dp,
+                                   _u8p, _u8p]
+        L.orc_env_step_batch.restype = None
+        L.orc_env_step_batch.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), C.c_int64, _dp, _dp, _u8p, _ip, _dp, C.c_int, _u8p,
+                                         _dp, _dp, _u8p, _u8p, C.c_int]
         _lib = L
     return _lib
 
@@ -78,6 +88,91 @@ def _d(a):
 def _i(a):
     a = np.ascontiguousarray(a, dtype=np.int32)
     return a, a.ctypes.data_as(_ip)
+
+
+class OrcEnvDesc(C.Structure):
+    _fields_ = [
+        ("n_arm", C.c_int32), ("arm_qpos_idx", _ip), ("n_grip", C.c_int32), ("grip_qpos_idx", _ip),
+        ("eef_body", C.c_int32), ("eef_off", C.c_double * 3), ("rfinger_body", C.c_int32), ("rfinger_off", C.c_double * 3),
+        ("lfinger_body", C.c_int32), ("lfinger_off", C.c_double * 3), ("ee_quat_body", C.c_int32),
+        ("cube_body", C.c_int32), ("target_body", C.c_int32), ("qpos_min", _dp), ("qpos_max", _dp), ("qpos_limited", _ip),
+        ("ac_scale", C.c_double), ("distance_threshold", C.c_double), ("success_reward", C.c_double),
+        ("max_episode_steps", C.c_int32),
+    ]
+
+
+def exp_(x: float) -> float:
+    return lib().orc_exp(float(x))
+
+
+def tanh_pos(x: float) -> float:
+    return lib().orc_tanh_pos(float(x))
+
+
+class OraclePushEnv:
+    """E kinematic SawyerPushObstacle envs stepped one by one through orc_env_step (the checker of K4).
+    `facts` is mopa_rl_amd.kinematic_env.PushEnvFacts (plain name->id data, no product code runs here)."""
+
+    def __init__(self, scene: "OracleScene", facts, E: int, ac_scale=0.05, distance_threshold=0.06, success_reward=150.0,
+                 max_episode_steps=250):
+        self.scene, self.E, self.nq = scene, int(E), scene.nq
+        self._keep = []
+        d = OrcEnvDesc()
+
+        def ip(a):
+            a, p = _i(a); self._keep.append(a); return p
+
+        def dp(a):
+            a, p = _d(a); self._keep.append(a); return p
+
+        d.n_arm, d.arm_qpos_idx = len(facts.arm_qpos_idx), ip(facts.arm_qpos_idx)
+        d.n_grip, d.grip_qpos_idx = len(facts.grip_qpos_idx), ip(facts.grip_qpos_idx)
+        d.eef_body, d.eef_off = facts.eef_body, (C.c_double * 3)(*facts.eef_off)
+        d.rfinger_body, d.rfinger_off = facts.rfinger_body, (C.c_double * 3)(*facts.rfinger_off)
+        d.lfinger_body, d.lfinger_off = facts.lfinger_body, (C.c_double * 3)(*facts.lfinger_off)
+        d.ee_quat_body, d.cube_body, d.target_body = facts.ee_quat_body, facts.cube_body, facts.target_body
+        d.qpos_min, d.qpos_max, d.qpos_limited = dp(facts.qpos_min), dp(facts.qpos_max), ip(facts.qpos_limited)
+        d.ac_scale, d.distance_threshold, d.success_reward = ac_scale, distance_threshold, success_reward
+        d.max_episode_steps = max_episode_steps
+        self.desc = d
+        self.n_arm = d.n_arm
+        self.qpos = np.zeros((self.E, self.nq))
+        self.prev_state = np.zeros((self.E, self.n_arm))
+        self.has_prev = np.zeros(self.E, dtype=np.uint8)
+        self.ep_len = np.zeros(self.E, dtype=np.int32)
+        self.obs = np.zeros((self.E, 40))
+        self.reward = np.zeros(self.E)
+        self.done = np.zeros(self.E, dtype=np.uint8)
+        self.success = np.zeros(self.E, dtype=np.uint8)
+
+    def _call(self, e, action, is_planner, move):
+        L = lib()
+        ap = None
+        if action is not None:
+            a, ap = _d(action[e])
+        L.orc_env_step(self.scene._h, C.byref(self.desc), self.qpos[e].ctypes.data_as(_dp),
+                       self.prev_state[e].ctypes.data_as(_dp), self.has_prev[e:e + 1].ctypes.data_as(_u8p),
+                       self.ep_len[e:e + 1].ctypes.data_as(_ip), ap, int(is_planner), int(move),
+                       self.obs[e].ctypes.data_as(_dp), self.reward[e:e + 1].ctypes.data_as(_dp),
+                       self.done[e:e + 1].ctypes.data_as(_u8p), self.success[e:e + 1].ctypes.data_as(_u8p))
+
+    def set_state(self, qpos):
+        self.qpos[:] = qpos
+        self.has_prev[:] = 0
+        self.ep_len[:] = 0
+        for e in range(self.E):
+            self._call(e, None, 0, 1)
+        return self.obs
+
+    def step(self, action, is_planner=False, move_mask=None, nthreads: int = 1):
+        action = np.ascontiguousarray(action, dtype=np.float64)
+        mm = None if move_mask is None else np.ascontiguousarray(move_mask, dtype=np.uint8)
+        lib().orc_env_step_batch(
+            self.scene._h, C.byref(self.desc), self.E, self.qpos.ctypes.data_as(_dp), self.prev_state.ctypes.data_as(_dp),
+            self.has_prev.ctypes.data_as(_u8p), self.ep_len.ctypes.data_as(_ip), action.ctypes.data_as(_dp), int(is_planner),
+            mm.ctypes.data_as(_u8p) if mm is not None else None, self.obs.ctypes.data_as(_dp),
+            self.reward.ctypes.data_as(_dp), self.done.ctypes.data_as(_u8p), self.success.ctypes.data_as(_u8p), int(nthreads))
+        return self.obs, self.reward, self.done, self.success
 
 
 def sincos(x: float) -> Tuple[float, float]:

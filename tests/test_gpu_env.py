@@ -1,0 +1,146 @@
+"""GPU parity of K4 (`k_env_step`, the batched kinematic env.step) against oracle/mopa_oracle.c:orc_env_step:
+observations, rewards, flags, counters and the carried state must be equal BIT FOR BIT over whole rollouts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ENV = "SawyerPushObstacle-v0"
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "the gpu-marked tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def setup(oracle_mod):
+    from mopa_rl_amd.kinematic_env import push_env_facts
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(ENV)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    return pi, orc, push_env_facts(pi.model)
+
+
+def _random_states(pi, f, E, seed):
+    from mopa_rl_amd.scene import default_qpos
+    m = pi.model
+    rng = np.random.default_rng(seed)
+    q = np.tile(default_qpos(ENV, m), (E, 1))
+    q[:, f.arm_qpos_idx] = np.clip(q[:, f.arm_qpos_idx] + rng.normal(0, 0.4, size=(E, 7)), pi.jnt_minimum, pi.jnt_maximum)
+    q[:, f.grip_qpos_idx] = rng.uniform(-0.008, 0.015, size=(E, 2))
+    ca = m.get_joint_qpos_addr("cube")
+    q[:, ca:ca + 2] += rng.uniform(-0.25, 0.05, size=(E, 2))      # some cubes end up next to the target
+    quat = rng.normal(size=(E, 4))
+    q[:, ca + 3:ca + 7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    q[:, f.target_qpos_idx] += rng.uniform(-0.01, 0.01, size=(E, 2))
+    # every 5th env: cube within 8 cm of the target (push reward / success branches); target = body pos + its 2 slides
+    tgt = m.body_pos[f.target_body][:2] + (q[:, f.target_qpos_idx] - m.qpos0[f.target_qpos_idx])
+    near = np.arange(E) % 5 == 0
+    q[near, ca:ca + 2] = tgt[near] + rng.uniform(-0.055, 0.055, size=(int(near.sum()), 2))
+    return q
+
+
+def _compare(env, ref, what):
+    assert np.array_equal(_bits(env.obs.cpu().numpy()), _bits(ref.obs)), f"{what}: obs"
+    assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(ref.qpos)), f"{what}: qpos"
+    assert np.array_equal(_bits(env.prev_state.cpu().numpy()), _bits(ref.prev_state)), f"{what}: prev_state"
+    assert np.array_equal(env.ep_len.cpu().numpy(), ref.ep_len), f"{what}: ep_len"
+    assert np.array_equal(env.has_prev.cpu().numpy(), ref.has_prev), f"{what}: has_prev"
+
+
+@pytest.mark.parametrize("E", [1, 63, 257, 2048])
+def test_rollout_bit_identical_to_oracle(setup, oracle_mod, torch_mod, E):
+    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
+    torch = torch_mod
+    pi, orc, f = setup
+    env = BatchKinematicPushEnv(E, max_episode_steps=7)
+    ref = oracle_mod.OraclePushEnv(orc, f, E, ac_scale=pi.spec.ac_scale, max_episode_steps=7)
+    q = _random_states(pi, f, E, seed=E)
+    env.set_state(torch.tensor(q, device=env.device))
+    ref.set_state(q)
+    _compare(env, ref, "after set_state")
+    rng = np.random.default_rng(100 + E)
+    n_succ = 0
+    for t in range(9 if E <= 257 else 3):
+        is_planner = bool(t % 3 == 1)
+        a = rng.uniform(-0.12, 0.12, size=(E, 7)) if is_planner else rng.uniform(-1.5, 1.5, size=(E, 7))
+        obs, rew, done, info = env.step(torch.tensor(a, device=env.device), is_planner=is_planner)
+        ref.step(a, is_planner=is_planner)
+        _compare(env, ref, f"step {t}")
+        assert np.array_equal(_bits(rew.cpu().numpy()), _bits(ref.reward)), f"step {t}: reward"
+        assert np.array_equal(done.cpu().numpy(), ref.done), f"step {t}: done"
+        assert np.array_equal(info["success"].cpu().numpy(), ref.success), f"step {t}: success"
+        n_succ += int(ref.success.sum())
+    if E >= 257:
+        assert n_succ > 0 and (ref.reward > 0).any() and ref.done.any()      # the interesting branches were exercised
+
+
+def test_move_mask_and_block_invalid(setup, oracle_mod, torch_mod):
+    """block_invalid = K1 verdict of the desired state decides whether the arm moves; the result must equal the oracle
+    env stepped with the oracle's own validity verdicts as move mask."""
+    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
+    torch = torch_mod
+    pi, orc, f = setup
+    E = 512
+    env = BatchKinematicPushEnv(E, block_invalid=True)
+    ref = oracle_mod.OraclePushEnv(orc, f, E, ac_scale=pi.spec.ac_scale)
+    q = _random_states(pi, f, E, seed=7)
+    env.set_state(torch.tensor(q, device=env.device))
+    ref.set_state(q)
+    rng = np.random.default_rng(8)
+    blocked_total = 0
+    for t in range(4):
+        a = rng.uniform(-1.0, 1.0, size=(E, 7))
+        s = pi.spec.ac_scale
+        desired = ref.qpos[:, f.arm_qpos_idx] + np.clip(a * s, -s, s)
+        desired = np.clip(desired, pi.jnt_minimum, pi.jnt_maximum)
+        want_move, _ = orc.is_valid_batch(desired, ref.qpos, samples_per_env=1)
+        _, _, _, info = env.step(torch.tensor(a, device=env.device))
+        ref.step(a, move_mask=want_move)
+        assert np.array_equal(info["blocked"].cpu().numpy(), 1 - want_move)
+        _compare(env, ref, f"step {t}")
+        blocked_total += int((1 - want_move).sum())
+    assert 0 < blocked_total < 4 * E
+
+
+def test_reset_and_single_env_facade(torch_mod):
+    from mopa_rl_amd.kinematic_env import OBS_LAYOUT, BatchKinematicPushEnv, SawyerPushObstacleKinematicEnv
+    from mopa_rl_amd.scene import ENV_SPECS
+    torch = torch_mod
+    env = BatchKinematicPushEnv(300, seed=3)
+    obs = env.reset().cpu().numpy()
+    init = np.array(ENV_SPECS[ENV].init_qpos)
+    assert obs.shape == (300, 40) and np.abs(obs[:, :7] - init).max() < 0.12 and np.abs(obs[:, :7] - init).std() > 0.005
+    assert (env.ep_len == 0).all() and (env.has_prev == 0).all()
+    a = torch.zeros(300, 7, dtype=torch.float64, device=env.device)
+    env.step(a)
+    mask = torch.zeros(300, dtype=torch.bool, device=env.device)
+    mask[::2] = True
+    env.reset(mask)
+    assert (env.ep_len.cpu().numpy() == np.tile([0, 1], 150)).all()
+
+    one = SawyerPushObstacleKinematicEnv(seed=0)
+    ob = one.reset()
+    assert list(ob.keys()) == list(OBS_LAYOUT.keys()) and all(len(ob[k]) == n for k, n in OBS_LAYOUT.items())
+    ob2, r, d, info = one.step(np.full(7, 0.5))
+    assert isinstance(r, float) and isinstance(d, bool) and info["episode_length"] == 1
+    np.testing.assert_allclose(ob2["joint_pos"], ob["joint_pos"] + 0.5 * 0.05, rtol=0, atol=1e-15)
+
+
+def test_env_abi_argument_errors(torch_mod):
+    import ctypes as C
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
+    env = BatchKinematicPushEnv(4)
+    L = _lib.lib()
+    rc = L.mopa_env_step_batch(env._h, 4, None, None, None, None, None, 0, None, None, None, None, None, None)
+    assert rc == 1 and b"null" in L.mopa_last_error()
+    with pytest.raises(_lib.MopaError):
+        env.step(torch_mod.zeros(4, 6, dtype=torch_mod.float64, device=env.device))

@@ -13,12 +13,30 @@ from conftest import SUPPORTED_ENVS, sample_states
 pytestmark = pytest.mark.gpu
 
 
-def _mk(env, oracle_mod):
+KERNELS = ["v1", "v2"]   # K1 generations: wave-per-state / lane-per-state (the library picks by batch size)
+
+
+def _scene_with_kernel(kernel, *args, **kw):
+    """Create a Scene with MOPA_VALID_KERNEL pinned (read once, at scene creation)."""
+    import os
     from mopa_rl_amd import _lib
+    old = os.environ.get("MOPA_VALID_KERNEL")
+    if kernel is not None:
+        os.environ["MOPA_VALID_KERNEL"] = kernel
+    try:
+        return _lib.Scene(*args, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("MOPA_VALID_KERNEL", None)
+        else:
+            os.environ["MOPA_VALID_KERNEL"] = old
+
+
+def _mk(env, oracle_mod, kernel=None):
     from mopa_rl_amd.scene import planner_inputs
     pi = planner_inputs(env)
-    sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold,
-                    range_=pi.spec.range, seed=7)
+    sc = _scene_with_kernel(kernel, pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold,
+                            range_=pi.spec.range, seed=7)
     orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
     return pi, sc, orc
 
@@ -71,10 +89,11 @@ def test_pair_dist_bit_exact(env, oracle_mod):
 
 @pytest.mark.parametrize("env", SUPPORTED_ENVS)
 @pytest.mark.parametrize("mode", ["uniform", "near"])
-def test_is_valid_batch_matches_oracle(env, mode, oracle_mod):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_is_valid_batch_matches_oracle(env, mode, kernel, oracle_mod):
     import torch
     from mopa_rl_amd.batch import BatchPlanner
-    pi, sc, orc = _mk(env, oracle_mod)
+    pi, sc, orc = _mk(env, oracle_mod, kernel)
     bp = BatchPlanner(sc)
     E, S = 8, 512
     rng = np.random.default_rng(3)
@@ -97,13 +116,14 @@ def test_is_valid_batch_matches_oracle(env, mode, oracle_mod):
     assert 0 < ov.sum() < len(ov) or mode == "uniform"
 
 
-def test_plane_pairs_and_per_env_objects(oracle_mod):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_plane_pairs_and_per_env_objects(kernel, oracle_mod):
     """The ground plane only ever touches the free-floating cube in these scenes: park the cube of some envs in the
     floor / in the arm's way so that plane-box and moving-vs-moving pairs decide the verdict."""
     import torch
     from mopa_rl_amd.batch import BatchPlanner
     env = "SawyerPushObstacle-v0"
-    pi, sc, orc = _mk(env, oracle_mod)
+    pi, sc, orc = _mk(env, oracle_mod, kernel)
     bp = BatchPlanner(sc)
     E, S = 16, 128
     qa, row = sample_states(pi, E * S, 91, "near")
@@ -129,6 +149,24 @@ def test_plane_pairs_and_per_env_objects(oracle_mod):
         qf = rows[e].copy()
         qf[:7] = qa[e * S + 3]
         assert sc.is_valid_state(qf, want_min_dist=True) == (bool(ov[e * S + 3]), omd[e * S + 3])
+
+
+def test_kernel_auto_selection_is_result_invariant(oracle_mod):
+    """Default scene: small batches take the wave-per-state kernel, large ones the lane-per-state kernel; the verdicts
+    and depths of the same states must not depend on which one ran."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk("SawyerPushObstacle-v0", oracle_mod)
+    bp = BatchPlanner(sc)
+    n_big = 64 * 1024
+    qa, row = sample_states(pi, n_big, 23, "near")
+    tq, tr = torch.from_numpy(qa).cuda(), torch.from_numpy(row).cuda()
+    v_big, md_big = bp.is_valid(tq, tr, samples_per_env=n_big, want_min_dist=True)
+    v_small, md_small = bp.is_valid(tq[:1000].contiguous(), tr, samples_per_env=1000, want_min_dist=True)
+    torch.cuda.synchronize()
+    ov, omd = orc.is_valid_batch(qa[:1000], row, samples_per_env=1000, nthreads=0)
+    assert np.array_equal(v_small.cpu().numpy(), ov) and np.array_equal(v_big[:1000].cpu().numpy(), ov)
+    assert np.array_equal(_bits(md_small.cpu().numpy()), _bits(omd)) and np.array_equal(_bits(md_big[:1000].cpu().numpy()), _bits(omd))
 
 
 @pytest.mark.parametrize("env", SUPPORTED_ENVS)
@@ -203,7 +241,8 @@ def test_plan_matches_oracle(env, oracle_mod):
 
 
 @pytest.mark.parametrize("env", SUPPORTED_ENVS)
-def test_hip_matches_committed_golden(env):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_hip_matches_committed_golden(env, kernel):
     """HIP path vs the committed fixtures (tests/golden/*.npz, generated by tools/gen_golden.py) -- no oracle
     in the loop, so this also runs where the oracle cannot be built."""
     import os
@@ -213,7 +252,8 @@ def test_hip_matches_committed_golden(env):
     from mopa_rl_amd.scene import planner_inputs
     pi = planner_inputs(env)
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", pi.spec.scene + ".npz"))
-    sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+    sc = _scene_with_kernel(kernel, pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold,
+                            range_=pi.spec.range)
     bp = BatchPlanner(sc)
     qa, row = torch.from_numpy(g["q_active"]).cuda(), torch.from_numpy(g["qpos_env"]).cuda()
     v, md = bp.is_valid(qa, row, samples_per_env=len(qa), want_min_dist=True)

@@ -210,6 +210,13 @@ int mopa_env_step_batch(MopaEnv *env, int64_t E, double *qpos_dev /*[E,nq] in/ou
                         const uint8_t *move_mask_dev /*[E] or NULL*/, double *obs_dev /*[E,40]*/,
                         double *reward_dev /*[E]*/, uint8_t *done_dev /*[E]*/, uint8_t *success_dev /*[E]*/, void *stream);
 
+/* The limit-clamped arm state the NEXT mopa_env_step_batch call with the same arguments would command
+ * (desired_state of sawyer_push_obstacle.py:186), without stepping: input of a collision gate
+ * (mopa_is_valid_batch with samples_per_env = 1 -> move_mask). */
+int mopa_env_desired_batch(MopaEnv *env, int64_t E, const double *qpos_dev /*[E,nq]*/, const double *prev_state_dev /*[E,n_arm]*/,
+                           const uint8_t *has_prev_dev /*[E]*/, const double *action_dev /*[E,n_arm]*/, int32_t is_planner,
+                           double *desired_dev /*[E,n_arm]*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,15 +1,15 @@
 // mopa_hip.hip -- libmopa_hip.so: scene compilation, HIP kernels and the C ABI
 // declared in include/mopa_hip.h.  Target: gfx950 (MI355X), wave64.
 //
-// Kernel mapping (DESIGN.md "Kernels"):
-//   one wave64 per planner state.  Scene constants (kinematic chain, geom
-//   table, sorted pair list; ~10 KB) are staged once per workgroup in LDS.
-//   Per state:  lanes [0, n_moving_geoms) run forward kinematics along their
-//   geom's ancestor chain and park the posed geom in a per-wave LDS slab;
-//   all 64 lanes then sweep the candidate pair list (coalesced by pair type),
-//   bounding-sphere cull -> wave-ballot compaction into an LDS worklist ->
-//   narrow phase, with a wave-wide vote for early-out on the first pair that
-//   violates `dist <= contact_threshold`.
+// Kernels:
+//   K1 state validity, two generations
+//      k_is_valid_v2 (mopa_valid_v2.inc, production for large batches): one LANE per state, 64-state tiles,
+//        FK per lane, cull while the pose is in registers, wave-wide narrow phase from an LDS ring queue;
+//      k_is_valid (this file): one wave64 per state -- small batches, single-state API calls and the device
+//        routine the planner kernels call.  Scene constants (~10 KB) are staged once per workgroup in LDS.
+//   K2 k_check_motion  one wave per segment (OMPL DiscreteMotionValidator semantics)
+//   K3 k_rrt_connect   (mopa_planner.inc) one wave per env
+//   K4 k_env_step      (mopa_env.inc) one lane per env, kinematic env.step
 //   FP64 VALU bound, no MFMA (there is no dense contraction on this path).
 #include <hip/hip_runtime.h>
 

@@ -144,9 +144,8 @@ class BatchKinematicPushEnv:
         self._target_idx = torch.tensor(f.target_qpos_idx, dtype=torch.long, device=dev)
         self._planner = None
         self._scene = None
-        lim = f.qpos_limited[f.arm_qpos_idx].astype(bool)
-        self._arm_lo = torch.tensor(np.where(lim, f.qpos_min[f.arm_qpos_idx], -np.inf), dtype=f64, device=dev)
-        self._arm_hi = torch.tensor(np.where(lim, f.qpos_max[f.arm_qpos_idx], np.inf), dtype=f64, device=dev)
+        self._desired = torch.zeros(self.E, self.n_arm, dtype=f64, device=dev)
+        self._move = torch.zeros(self.E, dtype=torch.uint8, device=dev)
         if block_invalid:
             pi = planner_inputs(self.env_name, self.model)
             self._scene = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, self.spec.contact_threshold,
@@ -213,13 +212,12 @@ class BatchKinematicPushEnv:
         info = {}
         move = None
         if self._planner is not None:
-            # desired state exactly as the kernel will form it, then the planner's validity rule on it
-            arm = self.qpos[:, self._arm_idx]
-            prev = torch.where((self.has_prev.bool() & bool(is_planner)).unsqueeze(1), self.prev_state, arm)
-            a = action if is_planner else action * self.ac_scale
-            desired = prev + a.clamp(-self.ac_scale, self.ac_scale)
-            desired = torch.minimum(torch.maximum(desired, self._arm_lo), self._arm_hi).contiguous()   # limit clamp
-            move = self._planner.is_valid(desired, self.qpos, samples_per_env=1, stream=stream)
+            # desired (limit-clamped) state exactly as the step kernel will form it, then the planner's validity rule
+            desired = self._desired
+            _lib.check(_lib.lib().mopa_env_desired_batch(self._h, self.E, _ptr(self.qpos), _ptr(self.prev_state),
+                                                         _ptr(self.has_prev), _ptr(action), int(bool(is_planner)),
+                                                         _ptr(desired), _stream_handle(stream)))
+            move = self._planner.is_valid(desired, self.qpos, samples_per_env=1, out=self._move, stream=stream)
             info["blocked"] = move ^ 1
         self._launch(action, is_planner, move, stream)
         info["success"] = self.success

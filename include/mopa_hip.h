@@ -44,7 +44,7 @@ extern "C" {
 
 #define MOPA_OK 0
 #define MOPA_ERR_INVALID_ARG 1
-#define MOPA_ERR_UNSUPPORTED 2   /* e.g. collidable mesh / ball joint in the model */
+#define MOPA_ERR_UNSUPPORTED 2   /* e.g. ellipsoid / height-field geom, ball joint in the model */
 #define MOPA_ERR_HIP 3           /* HIP runtime error (no device, launch failure...) */
 #define MOPA_ERR_LIMIT 4         /* model exceeds a compile-time capacity */
 
@@ -83,6 +83,13 @@ typedef struct MopaModel {
     const double  *geom_pos;      /* [ngeom,3]          */
     const double  *geom_quat;     /* [ngeom,4]          */
     const int32_t *pair_geom;     /* [npair,2] candidate pairs after MuJoCo's static filters, type1<=type2 */
+    /* convex hulls of mesh geoms (MuJoCo collides a mesh geom through the convex hull of its vertices):
+     * vertices in the geom frame.  nmesh == 0 / NULL pointers for models without collidable meshes. */
+    int32_t nmesh, nmeshvert;
+    const int32_t *mesh_vertadr;  /* [nmesh] first vertex */
+    const int32_t *mesh_vertnum;  /* [nmesh] */
+    const double  *mesh_vert;     /* [nmeshvert,3] */
+    const int32_t *geom_dataid;   /* [ngeom] mesh id of a MOPA_GEOM_MESH geom, -1 otherwise (may be NULL when nmesh == 0) */
 } MopaModel;
 
 /* Everything KinematicPlanner's constructor receives (KinematicPlanner.cpp:42-61). */

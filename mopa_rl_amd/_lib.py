@@ -43,6 +43,8 @@ class MopaModel(C.Structure):
         ("jnt_limited", _ip), ("jnt_range", _dp),
         ("geom_type", _ip), ("geom_body", _ip), ("geom_mjid", _ip), ("geom_size", _dp), ("geom_pos", _dp),
         ("geom_quat", _dp), ("pair_geom", _ip),
+        ("nmesh", C.c_int32), ("nmeshvert", C.c_int32), ("mesh_vertadr", _ip), ("mesh_vertnum", _ip), ("mesh_vert", _dp),
+        ("geom_dataid", _ip),
     ]
 
 
@@ -146,7 +148,8 @@ def model_struct(m, keep: list) -> MopaModel:
         m.nq, len(m.body_names), len(m.jnt_names), len(m.geom_type), len(m.pair_geom),
         i(m.body_parent), d(m.body_pos), d(m.body_quat), i(m.body_jntadr), i(m.body_jntnum),
         i(m.jnt_type), i(m.jnt_qposadr), d(m.jnt_axis), d(m.jnt_pos), d(m.jnt_ref), i(m.jnt_limited), d(m.jnt_range),
-        i(m.geom_type), i(m.geom_body), i(m.geom_mjid), d(m.geom_size), d(m.geom_pos), d(m.geom_quat), i(m.pair_geom))
+        i(m.geom_type), i(m.geom_body), i(m.geom_mjid), d(m.geom_size), d(m.geom_pos), d(m.geom_quat), i(m.pair_geom),
+        len(m.mesh_vertnum), len(m.mesh_vert), i(m.mesh_vertadr), i(m.mesh_vertnum), d(m.mesh_vert), i(m.geom_dataid))
 
 
 class Scene:
@@ -167,11 +170,7 @@ class Scene:
         ign = np.asarray(list(ignored_contacts), dtype=np.int32).reshape(-1, 2)
         pas = np.asarray(list(passive_joint_idx), dtype=np.int32)
         desc = MopaSceneDesc()
-        desc.model = MopaModel(
-            m.nq, len(m.body_names), len(m.jnt_names), len(m.geom_type), len(m.pair_geom),
-            i(m.body_parent), d(m.body_pos), d(m.body_quat), i(m.body_jntadr), i(m.body_jntnum),
-            i(m.jnt_type), i(m.jnt_qposadr), d(m.jnt_axis), d(m.jnt_pos), d(m.jnt_ref), i(m.jnt_limited), d(m.jnt_range),
-            i(m.geom_type), i(m.geom_body), i(m.geom_mjid), d(m.geom_size), d(m.geom_pos), d(m.geom_quat), i(m.pair_geom))
+        desc.model = model_struct(m, keep)
         desc.n_passive = len(pas)
         desc.passive_qpos_idx = i(pas)
         desc.n_ignored = len(ign)

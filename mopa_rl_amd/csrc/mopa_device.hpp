@@ -38,7 +38,8 @@ enum JntType : int { J_FREE = 0, J_BALL = 1, J_SLIDE = 2, J_HINGE = 3 };
 // pair type codes, cheapest narrow phase first (the pair list is sorted by this)
 enum PairCode : int {
     PC_PLANE_SPHERE = 0, PC_PLANE_CAPSULE, PC_PLANE_CYLINDER, PC_PLANE_BOX, PC_SPHERE_SPHERE, PC_SPHERE_CAPSULE,
-    PC_SPHERE_CYLINDER, PC_SPHERE_BOX, PC_CAPSULE_CAPSULE, PC_CAPSULE_BOX, PC_BOX_BOX, PC_CONVEX, PC_COUNT
+    PC_SPHERE_CYLINDER, PC_SPHERE_BOX, PC_CAPSULE_CAPSULE, PC_CAPSULE_BOX, PC_BOX_BOX, PC_CONVEX, PC_PLANE_MESH, PC_CONVEX_MESH,
+    PC_COUNT
 };
 
 struct V3 { double x, y, z; };
@@ -394,10 +395,29 @@ MOPA_HD V3 normalize3(V3 v) {
     double inv = 1.0 / norm3(v);
     return V3{v.x * inv, v.y * inv, v.z * inv};
 }
-MOPA_HD V3 support_geom(const double *g, int type, V3 dir) {
+// A mesh geom's record carries, instead of a size, where its convex hull lives: size[0] = offset (in doubles) of the
+// vertex array inside the scene's double blob `aux`, size[1] = number of vertices.
+// [3P] mjccd_support for a mesh: exhaustive search over the hull vertices, first maximum wins.
+MOPA_HD V3 mesh_support_local(const double *g, V3 ld, const double *aux) {
+    const double *V = aux + (int)g[GO_SIZE];
+    const int n = (int)g[GO_SIZE + 1];
+    int best = 0;
+    double bd = dot3(ld, ld3(V));
+    for (int i = 1; i < n; i++) {
+        const double d = dot3(ld, ld3(V + 3 * i));
+        if (d > bd) { bd = d; best = i; }
+    }
+    return ld3(V + 3 * best);
+}
+// MESH = true: the instantiation used for primitive-vs-mesh pairs (kept apart so that scenes without meshes run
+// exactly the code they ran before)
+template <bool MESH = false>
+MOPA_HD V3 support_geom(const double *g, int type, V3 dir, const double *aux = nullptr) {
     V3 ld = matT_vec(g + GO_MAT, dir);
     V3 lr;
-    if (type == G_CAPSULE) {
+    if (MESH && type == G_MESH) {
+        lr = mesh_support_local(g, ld, aux);
+    } else if (type == G_CAPSULE) {
         lr.x = ld.x * g[GO_SIZE]; lr.y = ld.y * g[GO_SIZE];
         lr.z = fma(ld.z, g[GO_SIZE], signd(ld.z) * g[GO_SIZE + 1]);
     } else if (type == G_CYLINDER) {
@@ -414,9 +434,10 @@ MOPA_HD V3 support_geom(const double *g, int type, V3 dir) {
     }
     return add3(mat_vec(g + GO_MAT, lr), ld3(g + GO_POS));
 }
-MOPA_HD V3 support_md(const double *g1, int t1, const double *g2, int t2, V3 dir) {
-    V3 s1 = support_geom(g1, t1, dir);
-    V3 s2 = support_geom(g2, t2, neg3(dir));
+template <bool MESH = false>
+MOPA_HD V3 support_md(const double *g1, int t1, const double *g2, int t2, V3 dir, const double *aux = nullptr) {
+    V3 s1 = support_geom<false>(g1, t1, dir);          // meshes have the highest type code: always geom 2
+    V3 s2 = support_geom<MESH>(g2, t2, neg3(dir), aux);
     return sub3(s1, s2);
 }
 MOPA_HD V3 portal_dir(V3 v1, V3 v2, V3 v3) { return normalize3(cross3(sub3(v2, v1), sub3(v3, v1))); }
@@ -467,11 +488,12 @@ MOPA_HD double origin_tri_dist2(V3 x0, V3 B, V3 C) {
     return dist;
 }
 // true + depth on intersection
-MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2, double &depth) {
+template <bool MESH = false>
+MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2, double &depth, const double *aux = nullptr) {
     V3 v0 = sub3(ld3(g1 + GO_POS), ld3(g2 + GO_POS));
     if (vec_eq0(v0)) v0.x += kCcdEps * 10.0;
     V3 dir = normalize3(neg3(v0));
-    V3 v1 = support_md(g1, t1, g2, t2, dir);
+    V3 v1 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
     double dot = dot3(v1, dir);
     if (is_zero(dot) || dot < 0.0) return false;
     dir = cross3(v0, v1);
@@ -481,7 +503,7 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
         return true;
     }
     dir = normalize3(dir);
-    V3 v2 = support_md(g1, t1, g2, t2, dir);
+    V3 v2 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
     dot = dot3(v2, dir);
     if (is_zero(dot) || dot < 0.0) return false;
     dir = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
@@ -494,7 +516,7 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
     int it = 0;
     for (;;) {
         if (++it > kMprPortalMaxIt) return false;
-        v3 = support_md(g1, t1, g2, t2, dir);
+        v3 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
         dot = dot3(v3, dir);
         if (is_zero(dot) || dot < 0.0) return false;
         bool cont = false;
@@ -513,7 +535,7 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
         dir = portal_dir(v1, v2, v3);
         dot = dot3(dir, v1);
         if (is_zero(dot) || dot > 0.0) break;
-        v4 = support_md(g1, t1, g2, t2, dir);
+        v4 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
         dot = dot3(v4, dir);
         if (!(is_zero(dot) || dot > 0.0) || portal_reach_tol(v1, v2, v3, v4, dir)) return false;
         expand_portal(v0, v1, v2, v3, v4);
@@ -521,7 +543,7 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
     int iterations = 0;
     for (;;) {
         dir = portal_dir(v1, v2, v3);
-        v4 = support_md(g1, t1, g2, t2, dir);
+        v4 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
         if (portal_reach_tol(v1, v2, v3, v4, dir) || iterations > kMprMaxIt) {
             depth = sqrt(origin_tri_dist2(v1, v2, v3));
             return true;
@@ -530,18 +552,36 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
         iterations++;
     }
 }
-MOPA_HD double d_convex(const double *A, int ta, const double *B, int tb) {
+template <bool MESH = false>
+MOPA_HD double d_convex(const double *A, int ta, const double *B, int tb, const double *aux = nullptr) {
     double depth;
-    if (mpr_penetration(A, ta, B, tb, depth)) return -depth;
+    if (mpr_penetration<MESH>(A, ta, B, tb, depth, aux)) return -depth;
     return kFar;
+}
+// [3P] mjc_PlaneConvex for a mesh: the hull vertex deepest along -n (first one on ties)
+MOPA_HD double d_plane_mesh(const double *P, const double *M, const double *aux) {
+    const V3 n = col3(P + GO_MAT, 2);
+    const V3 ln = matT_vec(M + GO_MAT, n);
+    const double *V = aux + (int)M[GO_SIZE];
+    const int nv = (int)M[GO_SIZE + 1];
+    int best = 0;
+    double bd = dot3(ln, ld3(V));
+    for (int i = 1; i < nv; i++) {
+        const double d = dot3(ln, ld3(V + 3 * i));
+        if (d < bd) { bd = d; best = i; }
+    }
+    const V3 w = add3(mat_vec(M + GO_MAT, ld3(V + 3 * best)), ld3(M + GO_POS));
+    return dot3(sub3(w, ld3(P + GO_POS)), n);
 }
 
 MOPA_HD int pair_code(int t1, int t2) {
+    if (t2 == G_MESH && (t1 == G_SPHERE || t1 == G_CAPSULE || t1 == G_CYLINDER || t1 == G_BOX)) return PC_CONVEX_MESH;
     if (t1 == G_PLANE) {
         if (t2 == G_SPHERE) return PC_PLANE_SPHERE;
         if (t2 == G_CAPSULE) return PC_PLANE_CAPSULE;
         if (t2 == G_CYLINDER) return PC_PLANE_CYLINDER;
         if (t2 == G_BOX) return PC_PLANE_BOX;
+        if (t2 == G_MESH) return PC_PLANE_MESH;
         return -1;
     }
     if (t1 == G_SPHERE) {
@@ -565,7 +605,11 @@ MOPA_HD int pair_code(int t1, int t2) {
     return -1;
 }
 
-MOPA_HD double geom_dist(int code, const double *A, int ta, const double *B, int tb) {
+// `aux`: the scene's double blob (mesh hull vertices live in it); only the *_MESH codes read it, and only the
+// MESH = true instantiation contains them: scenes without a collidable mesh keep running exactly the code (and
+// register budget) they had before mesh support existed.
+template <bool MESH = false>
+MOPA_HD double geom_dist(int code, const double *A, int ta, const double *B, int tb, const double *aux = nullptr) {
     switch (code) {
         case PC_PLANE_SPHERE: return d_plane_sphere(A, B);
         case PC_PLANE_CAPSULE: return d_plane_capsule(A, B);
@@ -578,7 +622,9 @@ MOPA_HD double geom_dist(int code, const double *A, int ta, const double *B, int
         case PC_CAPSULE_CAPSULE: return d_capsule_capsule(A, B);
         case PC_CAPSULE_BOX: return d_capsule_box(A, B);
         case PC_BOX_BOX: return d_box_box(A, B);
-        case PC_CONVEX: return d_convex(A, ta, B, tb);
+        case PC_CONVEX: return d_convex<false>(A, ta, B, tb);
+        case PC_PLANE_MESH: return MESH ? d_plane_mesh(A, B, aux) : kFar;
+        case PC_CONVEX_MESH: return MESH ? d_convex<MESH>(A, ta, B, tb, aux) : kFar;
         default: return kFar;
     }
 }

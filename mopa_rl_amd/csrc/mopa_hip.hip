@@ -64,6 +64,7 @@ struct SceneHdr {
     int o_mg_geom, o_chain_adr, o_chain_len, o_chain_items, o_pairs, o_pq_adr, o_act_adr, o_act_so2;
     // second-generation validity kernel (mopa_valid_v2.inc): DFS program + per-geom pair lists
     int n_save, n_gp;
+    int o_mesh, has_mesh;   // mesh hull vertices (doubles); has_mesh selects the MESH kernel instantiations
     int o_mb_load, o_mb_save, o_mb_mgadr, o_mb_mgnum, o_mg_padr, o_mg_pnum, o_mg_store, o_gp_word;
     int o_mbr, o_mbd, o_mgr, o_mgd;   // packed per-body / per-geom records (ints: 8 / 4, doubles: 16 / 8)
     // per-wave LDS slab (in doubles): geom records, qbuf; then worklist (u16)
@@ -234,7 +235,7 @@ MOPA_D void wave_fk(const SceneHdr &h, const LdsView &v, int lane) {
 // Collision sweep for the posed state.  Returns the wave-uniform verdict.
 // WANT_MD: also produce the minimum distance over broad-phase survivors
 // (disables the early-out so the minimum is complete).
-template <bool WANT_MD>
+template <bool WANT_MD, bool MESH = false>
 MOPA_D bool wave_collide(const SceneHdr &h, const LdsView &v, int lane, double &min_dist) {
     const int *I = v.ints;
     const double *D = v.dbl;
@@ -266,7 +267,7 @@ MOPA_D bool wave_collide(const SceneHdr &h, const LdsView &v, int lane, double &
             int pk = I[h.o_pairs + v.wl[i]];
             int g1 = pk & 0xff, g2 = (pk >> 8) & 0xff, code = (pk >> 16) & 0xff;
             const double *A = geom_rec(h, v, g1), *B = geom_rec(h, v, g2);
-            double d = geom_dist(code, A, I[h.o_g_type + g1], B, I[h.o_g_type + g2]);
+            double d = geom_dist<MESH>(code, A, I[h.o_g_type + g1], B, I[h.o_g_type + g2], v.dbl);
             if (d < md) md = d;
             if (d <= h.thr) bad = true;
         }
@@ -291,7 +292,7 @@ MOPA_D void wave_load_state(const SceneHdr &h, const LdsView &v, int lane, const
 // ---------------------------------------------------------------------------
 // K1: state validity, one wave per state
 // ---------------------------------------------------------------------------
-template <bool WANT_MD>
+template <bool WANT_MD, bool MESH>
 __global__ __launch_bounds__(kBlock) void k_is_valid(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
                                                       const double *__restrict__ q_active, const double *__restrict__ qpos_env,
                                                       long long N, long long samples_per_env, unsigned char *__restrict__ valid,
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(kBlock) void k_is_valid(SceneHdr h, const double *_
         wave_load_state(h, v, lane, q_active + s * h.na, qpos_env + env * h.nq);
         wave_fk(h, v, lane);
         double md;
-        bool ok = wave_collide<WANT_MD>(h, v, lane, md);
+        bool ok = wave_collide<WANT_MD, MESH>(h, v, lane, md);
         if (lane == 0) {
             valid[s] = ok ? 1 : 0;
             if (WANT_MD) min_dist[s] = md;
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(kBlock) void k_check_motion(SceneHdr h, const doubl
 // ---------------------------------------------------------------------------
 // debug kernels (parity hooks): posed geoms and per-pair distances of one state
 // ---------------------------------------------------------------------------
+template <bool MESH>
 __global__ __launch_bounds__(kBlock) void k_debug_state(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
                                                         const double *__restrict__ q_active, const double *__restrict__ qpos_row,
                                                         double *__restrict__ out_rec /*[ng*16]*/, double *__restrict__ out_dist /*[npair]*/) {
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_state(SceneHdr h, const double
         const double *A = geom_rec(h, v, g1), *B = geom_rec(h, v, g2);
         double d = kFar;
         if (!bp_cull(A, v.ints[h.o_g_type + g1], v.dbl[h.o_g_rbound + g1], B, v.dbl[h.o_g_rbound + g2]))
-            d = geom_dist(code, A, v.ints[h.o_g_type + g1], B, v.ints[h.o_g_type + g2]);
+            d = geom_dist<MESH>(code, A, v.ints[h.o_g_type + g1], B, v.ints[h.o_g_type + g2], v.dbl);
         out_dist[p] = d;
     }
 }
@@ -483,9 +485,16 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     // --- which bodies matter, which are static ---
     for (int g = 0; g < m.ngeom; g++) {
         int t = m.geom_type[g];
-        if (!(t == G_PLANE || t == G_SPHERE || t == G_CAPSULE || t == G_CYLINDER || t == G_BOX)) {
+        if (t == G_MESH) {
+            const int id = (m.nmesh > 0 && m.geom_dataid) ? m.geom_dataid[g] : -1;
+            if (id < 0 || id >= m.nmesh || !m.mesh_vert || m.mesh_vertnum[id] <= 0 ||
+                m.mesh_vertadr[id] < 0 || m.mesh_vertadr[id] + m.mesh_vertnum[id] > m.nmeshvert) {
+                delete S;
+                return fail(MOPA_ERR_INVALID_ARG, "mesh geom " + std::to_string(g) + " without a convex hull (MopaModel.geom_dataid / mesh_vert)");
+            }
+        } else if (!(t == G_PLANE || t == G_SPHERE || t == G_CAPSULE || t == G_CYLINDER || t == G_BOX)) {
             delete S;
-            return fail(MOPA_ERR_UNSUPPORTED, "collidable geom type " + std::to_string(t) + " (mesh/ellipsoid/hfield) is not supported yet");
+            return fail(MOPA_ERR_UNSUPPORTED, "collidable geom type " + std::to_string(t) + " (ellipsoid/hfield) is not supported");
         }
     }
     std::vector<char> needed(m.nbody, 0), is_static(m.nbody, 0);
@@ -588,6 +597,12 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         int b = m.geom_body[g];
         g_type[g] = m.geom_type[g];
         g_rbound[g] = rbound_of(m.geom_type[g], m.geom_size + 3 * g);
+        if (m.geom_type[g] == G_MESH) {   // bounding radius about the geom origin: max |v| over the hull
+            const double *V = m.mesh_vert + 3 * (size_t)m.mesh_vertadr[m.geom_dataid[g]];
+            double r2 = 0.0;
+            for (int i = 0; i < m.mesh_vertnum[m.geom_dataid[g]]; i++) r2 = dmax(r2, dot3(ld3(V + 3 * i), ld3(V + 3 * i)));
+            g_rbound[g] = sqrt(r2);
+        }
         std::memcpy(&g_lpos[3 * g], m.geom_pos + 3 * g, 24);
         std::memcpy(&g_lquat[4 * g], m.geom_quat + 4 * g, 32);
         double *rec = &g_rec[(size_t)kGeomStride * g];
@@ -718,6 +733,19 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.o_mj_axis = B.add_d(mj_axis); h.o_mj_pos = B.add_d(mj_pos); h.o_mj_ref = B.add_d(mj_ref);
     h.o_g_lpos = B.add_d(g_lpos); h.o_g_lquat = B.add_d(g_lquat); h.o_g_rbound = B.add_d(g_rbound);
     if (B.dbl.size() & 1) B.dbl.push_back(0.0);   // 16-byte align the posed records
+    // mesh hulls live in the double blob; a mesh geom's record carries (blob offset of its vertices, vertex count)
+    // where primitives carry their size (mopa_device.hpp: mesh_support_local / d_plane_mesh)
+    if (m.nmesh > 0) {
+        h.has_mesh = 1;
+        h.o_mesh = B.add_d(std::vector<double>(m.mesh_vert, m.mesh_vert + 3 * (size_t)m.nmeshvert));
+        for (int g = 0; g < m.ngeom; g++)
+            if (m.geom_type[g] == G_MESH) {
+                double *rec = &g_rec[(size_t)kGeomStride * g];
+                rec[GO_SIZE] = (double)(h.o_mesh + 3 * m.mesh_vertadr[m.geom_dataid[g]]);
+                rec[GO_SIZE + 1] = (double)m.mesh_vertnum[m.geom_dataid[g]];
+                rec[GO_SIZE + 2] = 0.0;
+            }
+    }
     h.o_g_rec = B.add_d(g_rec);
     h.o_act_lo = B.add_d(act_lo); h.o_act_hi = B.add_d(act_hi); h.o_act_ext = B.add_d(act_ext);
     if (B.dbl.size() & 1) B.dbl.push_back(0.0);
@@ -778,12 +806,13 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     for (hipError_t e : {e1, e2, e3, e4, e5, e6})
         if (e != hipSuccess) { mopa_scene_destroy(S); return fail(MOPA_ERR_HIP, std::string("device allocation: ") + hipGetErrorString(e)); }
     // allow the dynamic LDS size
-    (void)hipFuncSetAttribute((const void *)k_is_valid<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
-    (void)hipFuncSetAttribute((const void *)k_is_valid<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
-    (void)hipFuncSetAttribute((const void *)k_check_motion, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
-    (void)hipFuncSetAttribute((const void *)k_debug_state, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
-    (void)hipFuncSetAttribute((const void *)k_is_valid_v2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, S->v2_lds_bytes);
-    (void)hipFuncSetAttribute((const void *)k_is_valid_v2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, S->v2_lds_bytes);
+    for (const void *k : {(const void *)k_is_valid<false, false>, (const void *)k_is_valid<true, false>, (const void *)k_is_valid<false, true>,
+                          (const void *)k_is_valid<true, true>, (const void *)k_check_motion, (const void *)k_debug_state<false>,
+                          (const void *)k_debug_state<true>})
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
+    for (const void *k : {(const void *)k_is_valid_v2<false, false>, (const void *)k_is_valid_v2<true, false>,
+                          (const void *)k_is_valid_v2<false, true>, (const void *)k_is_valid_v2<true, true>})
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, S->v2_lds_bytes);
     *out = S;
     return MOPA_OK;
 }
@@ -849,12 +878,10 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
         unsigned long long *d_prof = (unsigned long long *)(S->d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride);
         (void)hipMemsetAsync(d_prof, 0, 6 * 8, st);
 #endif
-        if (min_dist)
-            hipLaunchKernelGGL(k_is_valid_v2<true>, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
-                               (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab);
-        else
-            hipLaunchKernelGGL(k_is_valid_v2<false>, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
-                               (long long)N, (long long)samples_per_env, valid, (double *)nullptr, S->d_slab);
+        auto kern = S->hdr.has_mesh ? (min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>)
+                                    : (min_dist ? k_is_valid_v2<true, false> : k_is_valid_v2<false, false>);
+        hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
+                           (long long)samples_per_env, valid, min_dist, S->d_slab);
         HIP_TRY(hipGetLastError());
 #ifdef MOPA_V2_PROFILE
         {
@@ -868,12 +895,10 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
         return MOPA_OK;
     }
     dim3 grid(grid_for(S, N));
-    if (min_dist)
-        hipLaunchKernelGGL(k_is_valid<true>, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
-                           (long long)N, (long long)samples_per_env, valid, min_dist);
-    else
-        hipLaunchKernelGGL(k_is_valid<false>, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env,
-                           (long long)N, (long long)samples_per_env, valid, (double *)nullptr);
+    auto kern = S->hdr.has_mesh ? (min_dist ? k_is_valid<true, true> : k_is_valid<false, true>)
+                                : (min_dist ? k_is_valid<true, false> : k_is_valid<false, false>);
+    hipLaunchKernelGGL(kern, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
+                       (long long)samples_per_env, valid, min_dist);
     HIP_TRY(hipGetLastError());
     return MOPA_OK;
 }
@@ -916,7 +941,7 @@ extern "C" int mopa_is_valid_state(MopaScene *S, const double *qpos_host, int32_
 static int run_debug(MopaScene *S, const double *qpos_host) {
     int rc = upload_state(S, qpos_host);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_debug_state, dim3(1), dim3(kBlock), S->lds_bytes, nullptr, S->hdr, S->d_dbl, S->d_int, S->d_q + S->nq,
+    hipLaunchKernelGGL(S->hdr.has_mesh ? k_debug_state<true> : k_debug_state<false>, dim3(1), dim3(kBlock), S->lds_bytes, nullptr, S->hdr, S->d_dbl, S->d_int, S->d_q + S->nq,
                        S->d_q, S->d_dbg, S->d_dbg + (size_t)kGeomStride * S->hdr.ng);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());

@@ -67,6 +67,15 @@ def _quat_mul(a, b):
     ])
 
 
+def _quat_rotate(q, v):
+    """rotate v by the unit quaternion q (wxyz)"""
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    return R @ np.asarray(v, dtype=np.float64)
+
+
 def _normalize_quat(q):
     q = np.asarray(q, dtype=np.float64)
     n = math.sqrt(float(q @ q))
@@ -148,6 +157,12 @@ class CompiledModel:
     site_body: np.ndarray
     site_pos: np.ndarray
     site_quat: np.ndarray
+    # convex hulls of the meshes collidable geoms use (MuJoCo collides mesh geoms through their hull):
+    # vertices in the geom frame, already re-centred at the mesh's volume centroid (see _load_mesh)
+    geom_dataid: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))      # [ngeom] mesh id or -1
+    mesh_vertadr: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))     # [nmesh]
+    mesh_vertnum: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))     # [nmesh]
+    mesh_vert: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), dtype=np.float64)) # [nmeshvert,3]
     meta: Dict[str, object] = field(default_factory=dict)
 
     # ---- name lookups mirroring the mujoco-py calls the reference makes ----
@@ -179,13 +194,14 @@ class CompiledModel:
         "geom_size geom_pos geom_quat geom_contype geom_conaffinity geom_margin pair_geom site_body site_pos "
         "site_quat"
     ).split()
+    _OPTIONAL = "geom_dataid mesh_vertadr mesh_vertnum mesh_vert".split()   # absent in scenes without collidable meshes
     _LISTS = "body_names jnt_names all_geom_names geom_mesh site_names".split()
 
     def to_json(self) -> str:
         d = {"name": self.name, "nq": self.nq, "meta": self.meta}
         for k in self._LISTS:
             d[k] = getattr(self, k)
-        for k in self._ARRAYS:
+        for k in self._ARRAYS + ([k for k in self._OPTIONAL] if len(self.mesh_vertnum) else []):
             a = getattr(self, k)
             d[k] = {"dtype": str(a.dtype), "shape": list(a.shape),
                     "data": [float(x).hex() if a.dtype.kind == "f" else int(x) for x in a.ravel()]}
@@ -197,14 +213,17 @@ class CompiledModel:
         kw = {"name": d["name"], "nq": d["nq"], "meta": d.get("meta", {})}
         for k in cls._LISTS:
             kw[k] = list(d[k])
-        for k in cls._ARRAYS:
+        for k in cls._ARRAYS + [k for k in cls._OPTIONAL if k in d]:
             e = d[k]
             if e["dtype"].startswith("float"):
                 a = np.array([float.fromhex(x) for x in e["data"]], dtype=np.float64)
             else:
                 a = np.array(e["data"], dtype=np.int32)
             kw[k] = a.reshape(e["shape"])
-        return cls(**kw)
+        m = cls(**kw)
+        if len(m.geom_dataid) == 0:
+            m.geom_dataid = np.full(len(m.geom_type), -1, dtype=np.int32)
+        return m
 
     def save(self, path: str) -> None:
         with open(path, "w") as f:
@@ -272,6 +291,28 @@ class _Defaults:
         return out
 
 
+def _load_mesh(path: str, scale) -> Tuple[np.ndarray, np.ndarray]:
+    """Binary-STL mesh -> (convex-hull vertices re-centred at the volume centroid, centroid), both in the mesh frame.
+    MuJoCo's compiler does the same two things to a mesh asset that matter for collision: geoms collide through the
+    convex hull of the vertices, and the mesh is re-centred at its centre of mass (the geom frame moves with it), which
+    is the interior point MPR starts from.  (It also re-orients to the principal axes -- irrelevant to the shape.)"""
+    from scipy.spatial import ConvexHull
+    raw = open(path, "rb").read()
+    ntri = int(np.frombuffer(raw[80:84], dtype="<u4")[0])
+    if len(raw) != 84 + 50 * ntri:
+        raise MjcfError(f"{path}: only binary STL meshes are supported")
+    rec = np.frombuffer(raw[84:], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+    tri = rec["v"].astype(np.float64) * np.asarray(scale, dtype=np.float64)
+    # volume centroid from signed tetrahedra (closed surface)
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    vol = np.einsum("ij,ij->i", a, np.cross(b, c)) / 6.0
+    centroid = ((a + b + c) / 4.0 * vol[:, None]).sum(0) / vol.sum()
+    verts = np.unique(tri.reshape(-1, 3), axis=0)
+    hull = ConvexHull(verts)
+    hv = verts[np.sort(hull.vertices)] - centroid
+    return hv, centroid
+
+
 class _Builder:
     def __init__(self, xml_path: str):
         self.xml_path = xml_path
@@ -289,6 +330,14 @@ class _Builder:
         self.defaults = _Defaults()
         for d in root.findall("default"):
             self.defaults.add_section(d)
+        # mesh assets: name -> (file path, scale); MuJoCo resolves files against meshdir, itself relative to the model file
+        self.mesh_assets: Dict[str, Tuple[str, List[float]]] = {}
+        mdir = os.path.join(os.path.dirname(os.path.abspath(xml_path)), comp.get("meshdir", ""))
+        for a in root.findall("asset"):
+            for me in a.findall("mesh"):
+                f = me.attrib.get("file", "")
+                name = me.attrib.get("name", os.path.splitext(os.path.basename(f))[0])
+                self.mesh_assets[name] = (os.path.join(mdir, f), _floats(me.attrib.get("scale", "1 1 1")))
         # accumulators
         self.bodies: List[dict] = []
         self.joints: List[dict] = []
@@ -477,7 +526,26 @@ class _Builder:
                 a = a.reshape(shape)
             return a
 
-        cg = [geoms[i] for i in coll]
+        cg = [dict(geoms[i]) for i in coll]
+        mesh_ids: Dict[str, int] = {}
+        mesh_vertadr, mesh_vertnum, mesh_vert = [], [], []
+        geom_dataid = np.full(len(cg), -1, dtype=np.int32)
+        for gi, g in enumerate(cg):
+            if g["type"] != GEOM_MESH:
+                continue
+            if g["mesh"] not in self.mesh_assets:
+                raise MjcfError(f"geom {g['name']!r}: unknown mesh asset {g['mesh']!r}")
+            path, scale = self.mesh_assets[g["mesh"]]
+            hv, centroid = _load_mesh(path, scale)
+            if g["mesh"] not in mesh_ids:
+                mesh_ids[g["mesh"]] = len(mesh_vertadr)
+                mesh_vertadr.append(sum(mesh_vertnum))
+                mesh_vertnum.append(len(hv))
+                mesh_vert.append(hv)
+            geom_dataid[gi] = mesh_ids[g["mesh"]]
+            # the geom frame follows the re-centred mesh; size = half extents of the hull's AABB (as MuJoCo reports it)
+            g["pos"] = g["pos"] + _quat_rotate(g["quat"], centroid)
+            g["size"] = 0.5 * (hv.max(0) - hv.min(0))
         nj = len(self.joints)
         jr = np.zeros((nj, 2))
         for i, j in enumerate(self.joints):
@@ -506,6 +574,9 @@ class _Builder:
             geom_contype=arr(cg, "contype", np.int32), geom_conaffinity=arr(cg, "conaffinity", np.int32),
             geom_margin=arr(cg, "margin", np.float64),
             geom_mesh=[g["mesh"] for g in cg],
+            geom_dataid=geom_dataid, mesh_vertadr=np.array(mesh_vertadr, dtype=np.int32),
+            mesh_vertnum=np.array(mesh_vertnum, dtype=np.int32),
+            mesh_vert=(np.concatenate(mesh_vert) if mesh_vert else np.zeros((0, 3))),
             pair_geom=np.array(pairs, dtype=np.int32).reshape(-1, 2),
             site_names=[s["name"] for s in self.sites],
             site_body=arr(self.sites, "body", np.int32),

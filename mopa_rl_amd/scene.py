@@ -59,7 +59,7 @@ ENV_SPECS: Dict[str, EnvSpec] = {
         env="SawyerPushObstacle-v0", scene="sawyer_push_obstacle", robot_joints=tuple(_SAWYER_JOINTS),
         static_bodies=("table", "bin1"), manipulation_geoms=("cube",),
         init_qpos=(4.57e-4, -0.114, 3.21e-2, -7.12e-3, 3.03e-2, -3.02e-2, -9.94e-3)),
-    # env/sawyer/sawyer_lift_obstacle.py:13-14,163-189 (collidable convex mesh: not yet supported)
+    # env/sawyer/sawyer_lift_obstacle.py:13-14,163-189 (the can is a collidable mesh: collides through its convex hull)
     "SawyerLiftObstacle-v0": EnvSpec(
         env="SawyerLiftObstacle-v0", scene="sawyer_lift_obstacle", robot_joints=tuple(_SAWYER_JOINTS),
         static_bodies=("table", "bin1"), manipulation_geoms=("cube",),

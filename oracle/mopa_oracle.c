@@ -77,6 +77,9 @@ struct OrcScene {
     double *act_lo, *act_hi, *act_ext;
     uint8_t *act_so2;  /* unlimited hinge -> OMPL SO2StateSpace (mujoco_ompl_interface.cpp:234-239) */
     uint8_t *body_needed;  /* body has a collidable geom below it */
+    int nmesh, nmeshvert;
+    int32_t *mesh_vertadr, *mesh_vertnum, *geom_dataid;   /* convex hulls of mesh geoms; geom_dataid NULL = no meshes */
+    double *mesh_vert;
     double thr;
 };
 
@@ -307,12 +310,31 @@ OrcScene *orc_scene_create(
     return s;
 }
 
+/* convex hulls of the mesh geoms (mopa_rl_amd.mjcf: geom_dataid / mesh_vertadr / mesh_vertnum / mesh_vert) */
+void orc_scene_set_meshes(OrcScene *s, int nmesh, const int32_t *mesh_vertadr, const int32_t *mesh_vertnum, int nmeshvert,
+                          const double *mesh_vert, const int32_t *geom_dataid) {
+    s->nmesh = nmesh; s->nmeshvert = nmeshvert;
+    s->mesh_vertadr = dupmem(mesh_vertadr, sizeof(int32_t) * nmesh);
+    s->mesh_vertnum = dupmem(mesh_vertnum, sizeof(int32_t) * nmesh);
+    s->mesh_vert = dupmem(mesh_vert, sizeof(double) * 3 * nmeshvert);
+    s->geom_dataid = dupmem(geom_dataid, sizeof(int32_t) * s->ngeom);
+    for (int g = 0; g < s->ngeom; g++) {
+        if (s->geom_type[g] != G_MESH || geom_dataid[g] < 0) continue;
+        /* bounding radius about the geom origin: max |v| over the hull */
+        double r2 = 0.0;
+        const double *V = s->mesh_vert + 3 * mesh_vertadr[geom_dataid[g]];
+        for (int i = 0; i < mesh_vertnum[geom_dataid[g]]; i++) r2 = dmax(r2, dot3(V + 3 * i, V + 3 * i));
+        s->geom_rbound[g] = sqrt(r2);
+    }
+}
+
 void orc_scene_destroy(OrcScene *s) {
     if (!s) return;
     free(s->body_parent); free(s->body_pos); free(s->body_quat); free(s->body_jntadr); free(s->body_jntnum);
     free(s->jnt_type); free(s->jnt_qposadr); free(s->jnt_limited); free(s->jnt_axis); free(s->jnt_pos);
     free(s->jnt_ref); free(s->jnt_range); free(s->geom_type); free(s->geom_body); free(s->geom_mjid);
     free(s->geom_size); free(s->geom_pos); free(s->geom_quat); free(s->geom_rbound); free(s->pair_geom);
+    free(s->mesh_vertadr); free(s->mesh_vertnum); free(s->mesh_vert); free(s->geom_dataid);
     free(s->pair_ignored); free(s->active_idx); free(s->act_lo); free(s->act_hi); free(s->act_ext); free(s->act_so2);
     free(s->body_needed);
     free(s);
@@ -398,7 +420,7 @@ void orc_fk(const OrcScene *s, const double *qpos, double *gpos, double *gmat) {
 /* ------------------------------------------------------------------ */
 /* narrow phase                                                        */
 /* ------------------------------------------------------------------ */
-typedef struct { int type; const double *size, *pos, *mat; } Geom;
+typedef struct { int type; const double *size, *pos, *mat; const double *verts; int nvert; } Geom;   /* verts: convex-hull vertices of a mesh geom (geom frame) */
 
 /* [3P] mjc_PlaneSphere */
 static double d_plane_sphere(const Geom *P, const Geom *S) {
@@ -431,6 +453,22 @@ static double d_plane_cylinder(const Geom *P, const Geom *C) {
     double s2 = fma(-na, na, 1.0);
     double sr = (s2 > 0.0) ? sqrt(s2) : 0.0;
     return (d0 - C->size[1] * fabs(na)) - C->size[0] * sr;
+}
+/* [3P] mjc_PlaneConvex for a mesh: the hull vertex that is deepest along -n (first one on ties) */
+static double d_plane_mesh(const Geom *P, const Geom *M) {
+    double n[3], ln[3], w[3], diff[3];
+    col3(n, P->mat, 2);
+    matT_vec(ln, M->mat, n);
+    int best = 0;
+    double bd = dot3(ln, M->verts);
+    for (int i = 1; i < M->nvert; i++) {
+        double d = dot3(ln, M->verts + 3 * i);
+        if (d < bd) { bd = d; best = i; }
+    }
+    mat_vec(w, M->mat, M->verts + 3 * best);
+    add3(w, w, M->pos);
+    sub3(diff, w, P->pos);
+    return dot3(diff, n);
 }
 /* [3P] mjc_PlaneBox: deepest vertex */
 static double d_plane_box(const Geom *P, const Geom *B) {
@@ -667,6 +705,15 @@ static void support_geom(const Geom *g, const double *dir, double *out) {
         case G_BOX:
             lr[0] = signd(ld[0]) * g->size[0]; lr[1] = signd(ld[1]) * g->size[1]; lr[2] = signd(ld[2]) * g->size[2];
             break;
+        case G_MESH: { /* [3P] mjccd_support, mesh: exhaustive search over the hull vertices, first maximum wins */
+            int best = 0;
+            double bd = dot3(ld, g->verts);
+            for (int i = 1; i < g->nvert; i++) {
+                double d = dot3(ld, g->verts + 3 * i);
+                if (d > bd) { bd = d; best = i; }
+            }
+            lr[0] = g->verts[3 * best]; lr[1] = g->verts[3 * best + 1]; lr[2] = g->verts[3 * best + 2];
+        } break;
         default: /* sphere */
             lr[0] = ld[0] * g->size[0]; lr[1] = ld[1] * g->size[0]; lr[2] = ld[2] * g->size[0];
             break;
@@ -838,6 +885,7 @@ static double geom_dist(const Geom *A, const Geom *B) {
                 case G_CAPSULE: return d_plane_capsule(A, B);
                 case G_CYLINDER: return d_plane_cylinder(A, B);
                 case G_BOX: return d_plane_box(A, B);
+                case G_MESH: return d_plane_mesh(A, B);
                 default: return ORC_FAR;
             }
         case G_SPHERE:
@@ -846,6 +894,7 @@ static double geom_dist(const Geom *A, const Geom *B) {
                 case G_CAPSULE: return d_sphere_capsule(A, B);
                 case G_CYLINDER: return d_sphere_cylinder(A, B);
                 case G_BOX: return d_sphere_box(A, B);
+                case G_MESH: return d_convex(A, B);   /* [3P] mjc_Convex for every primitive-mesh pair */
                 default: return ORC_FAR;
             }
         case G_CAPSULE:
@@ -853,24 +902,43 @@ static double geom_dist(const Geom *A, const Geom *B) {
                 case G_CAPSULE: return d_capsule_capsule(A, B);
                 case G_CYLINDER: return d_convex(A, B);
                 case G_BOX: return d_capsule_box(A, B);
+                case G_MESH: return d_convex(A, B);
                 default: return ORC_FAR;
             }
         case G_CYLINDER:
             switch (B->type) {
                 case G_CYLINDER: return d_convex(A, B);
                 case G_BOX: return d_convex(A, B);
+                case G_MESH: return d_convex(A, B);
                 default: return ORC_FAR;
             }
         case G_BOX:
             if (B->type == G_BOX) return d_box_box(A, B);
+            if (B->type == G_MESH) return d_convex(A, B);
             return ORC_FAR;
         default: return ORC_FAR;
     }
 }
 
+double orc_geom_dist_mesh(int t1, const double *size1, const double *pos1, const double *mat1,
+                          const double *verts, int nvert, const double *pos2, const double *mat2) {
+    static const double zero3[3] = { 0.0, 0.0, 0.0 };
+    Geom A = { t1, size1, pos1, mat1, NULL, 0 }, B = { G_MESH, zero3, pos2, mat2, verts, nvert };
+    return geom_dist(&A, &B);
+}
+
+static inline Geom scene_geom(const OrcScene *s, int g, const double *gpos, const double *gmat) {
+    Geom G = { s->geom_type[g], s->geom_size + 3 * g, gpos + 3 * g, gmat + 9 * g, NULL, 0 };
+    if (s->geom_dataid && s->geom_dataid[g] >= 0) {
+        G.verts = s->mesh_vert + 3 * s->mesh_vertadr[s->geom_dataid[g]];
+        G.nvert = s->mesh_vertnum[s->geom_dataid[g]];
+    }
+    return G;
+}
+
 double orc_geom_dist(int t1, const double *size1, const double *pos1, const double *mat1,
                      int t2, const double *size2, const double *pos2, const double *mat2) {
-    Geom A = { t1, size1, pos1, mat1 }, B = { t2, size2, pos2, mat2 };
+    Geom A = { t1, size1, pos1, mat1, NULL, 0 }, B = { t2, size2, pos2, mat2, NULL, 0 };
     return geom_dist(&A, &B);
 }
 
@@ -892,8 +960,7 @@ static void pair_dists(const OrcScene *s, const double *gpos, const double *gmat
     for (int p = 0; p < s->npair; p++) {
         int g1 = s->pair_geom[2 * p], g2 = s->pair_geom[2 * p + 1];
         if (bp_cull(s, g1, g2, gpos, gmat)) { dist[p] = ORC_FAR; continue; }
-        Geom A = { s->geom_type[g1], s->geom_size + 3 * g1, gpos + 3 * g1, gmat + 9 * g1 };
-        Geom B = { s->geom_type[g2], s->geom_size + 3 * g2, gpos + 3 * g2, gmat + 9 * g2 };
+        Geom A = scene_geom(s, g1, gpos, gmat), B = scene_geom(s, g2, gpos, gmat);
         dist[p] = geom_dist(&A, &B);
     }
 }
@@ -919,8 +986,7 @@ static int is_valid_ws(const OrcScene *s, const double *qpos, double *min_dist, 
         if (s->pair_ignored[p]) continue;
         int g1 = s->pair_geom[2 * p], g2 = s->pair_geom[2 * p + 1];
         if (bp_cull(s, g1, g2, gpos, gmat)) continue;
-        Geom A = { s->geom_type[g1], s->geom_size + 3 * g1, gpos + 3 * g1, gmat + 9 * g1 };
-        Geom B = { s->geom_type[g2], s->geom_size + 3 * g2, gpos + 3 * g2, gmat + 9 * g2 };
+        Geom A = scene_geom(s, g1, gpos, gmat), B = scene_geom(s, g2, gpos, gmat);
         double d = geom_dist(&A, &B);
         if (d < md) md = d;
         if (d <= s->thr) valid = 0; /* the reference keeps scanning (its break is commented out) */

@@ -41,6 +41,9 @@ OrcScene *orc_scene_create(
     int n_passive, const int32_t *passive_qpos_idx,
     int n_ignored, const int32_t *ignored_pairs /* [n,2] MuJoCo geom ids, ordered */,
     double contact_threshold);
+/* optional: convex hulls of mesh geoms (type 7); without it mesh pairs report ORC_FAR */
+void orc_scene_set_meshes(OrcScene *s, int nmesh, const int32_t *mesh_vertadr, const int32_t *mesh_vertnum, int nmeshvert,
+                          const double *mesh_vert /*[nmeshvert,3]*/, const int32_t *geom_dataid /*[ngeom]*/);
 void orc_scene_destroy(OrcScene *s);
 int orc_num_active(const OrcScene *s);
 void orc_active_idx(const OrcScene *s, int32_t *out);
@@ -56,6 +59,10 @@ void orc_fk_bodies(const OrcScene *s, const double *qpos, double *xpos, double *
 /* signed distance of two posed primitives (types ordered t1<=t2) */
 double orc_geom_dist(int t1, const double *size1, const double *pos1, const double *mat1,
                      int t2, const double *size2, const double *pos2, const double *mat2);
+
+/* primitive (t1) vs a convex mesh given by its hull vertices in the mesh frame */
+double orc_geom_dist_mesh(int t1, const double *size1, const double *pos1, const double *mat1,
+                          const double *verts, int nvert, const double *pos2, const double *mat2);
 
 /* per-pair distances for one state; culled pairs get ORC_FAR */
 void orc_pair_dist(const OrcScene *s, const double *qpos, double *dist /*[npair]*/);

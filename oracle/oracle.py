@@ -66,6 +66,10 @@ def lib():
         L.orc_plan.restype = C.c_int
         L.orc_plan.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                _dp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+        L.orc_scene_set_meshes.restype = None
+        L.orc_scene_set_meshes.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int, _dp, _ip]
+        L.orc_geom_dist_mesh.restype = C.c_double
+        L.orc_geom_dist_mesh.argtypes = [C.c_int, _dp, _dp, _dp, _dp, C.c_int, _dp, _dp]
         L.orc_exp.restype = C.c_double
         L.orc_exp.argtypes = [C.c_double]
         L.orc_tanh_pos.restype = C.c_double
@@ -187,6 +191,14 @@ def geom_dist(t1, size1, pos1, mat1, t2, size2, pos2, mat2) -> float:
     return lib().orc_geom_dist(int(t1), k1[0][1], k1[1][1], k1[2][1], int(t2), k2[0][1], k2[1][1], k2[2][1])
 
 
+def geom_dist_mesh(t1, size1, pos1, mat1, verts, pos2, mat2) -> float:
+    """primitive (type t1) vs the convex hull of `verts` ([n,3], mesh frame) posed at (pos2, mat2)"""
+    k1 = [_d(np.asarray(x, dtype=np.float64).ravel()) for x in (size1, pos1, mat1)]
+    v = _d(np.asarray(verts, dtype=np.float64).reshape(-1, 3))
+    k2 = [_d(np.asarray(x, dtype=np.float64).ravel()) for x in (pos2, mat2)]
+    return lib().orc_geom_dist_mesh(int(t1), k1[0][1], k1[1][1], k1[2][1], v[1], len(v[0]), k2[0][1], k2[1][1])
+
+
 def rng_uniform(seed: int, stream: int, counter: int) -> float:
     return lib().orc_rng_uniform(seed, stream, counter)
 
@@ -214,6 +226,9 @@ class OracleScene:
             i(m.jnt_limited), d(m.jnt_range),
             len(m.geom_type), i(m.geom_type), i(m.geom_body), i(m.geom_mjid), d(m.geom_size), d(m.geom_pos), d(m.geom_quat),
             len(m.pair_geom), i(m.pair_geom), len(pas), i(pas), len(ign), i(ign), float(contact_threshold))
+        if len(getattr(m, "mesh_vertnum", ())):
+            lib().orc_scene_set_meshes(self._h, len(m.mesh_vertnum), i(m.mesh_vertadr), i(m.mesh_vertnum), len(m.mesh_vert),
+                                       d(m.mesh_vert), i(m.geom_dataid))
         self.nq = m.nq
         self.na = lib().orc_num_active(self._h)
         ai = np.zeros(self.na, dtype=np.int32)

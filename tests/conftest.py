@@ -13,7 +13,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-SUPPORTED_ENVS = ["SawyerPushObstacle-v0", "SawyerAssemblyObstacle-v0", "PusherObstacle-v0"]
+SUPPORTED_ENVS = ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0", "PusherObstacle-v0"]
 
 
 def sample_states(pi, n, seed, mode="uniform"):

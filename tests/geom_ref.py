@@ -8,7 +8,7 @@ sampling + local refinement; accuracy ~1e-7.  Nothing here shares code with orac
 import numpy as np
 from scipy.optimize import minimize
 
-PLANE, SPHERE, CAPSULE, CYLINDER, BOX = 0, 2, 3, 5, 6
+PLANE, SPHERE, CAPSULE, CYLINDER, BOX, MESH = 0, 2, 3, 5, 6, 7
 
 
 def support(t, size, mat, n):
@@ -23,6 +23,8 @@ def support(t, size, mat, n):
         return size[1] * np.abs(c) + size[0] * np.sqrt(np.maximum(0.0, 1.0 - c * c))
     if t == BOX:
         return np.abs(n @ ax[0]) * size[0] + np.abs(n @ ax[1]) * size[1] + np.abs(n @ ax[2]) * size[2]
+    if t == MESH:      # `size` holds the hull vertices [k,3] in the mesh frame
+        return ((n @ mat) @ np.asarray(size, float).reshape(-1, 3).T).max(axis=1)
     raise ValueError(t)
 
 
@@ -37,7 +39,7 @@ _DIRS = _fib(40000)
 
 
 def signed_dist(t1, s1, p1, m1, t2, s2, p2, m2, refine=40):
-    s1, p1, m1, s2, p2, m2 = (np.asarray(x, float) for x in (s1, p1, m1, s2, p2, m2))
+    s1, p1, m1, s2, p2, m2 = (np.asarray(x, float) for x in (s1, p1, m1, s2, p2, m2))   # MESH: s2 = vertices
     m1, m2 = m1.reshape(3, 3), m2.reshape(3, 3)
     if t1 == PLANE:
         n = m1[:, 2]

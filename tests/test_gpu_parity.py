@@ -151,6 +151,56 @@ def test_plane_pairs_and_per_env_objects(kernel, oracle_mod):
         assert sc.is_valid_state(qf, want_min_dist=True) == (bool(ov[e * S + 3]), omd[e * S + 3])
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_lift_can_mesh_pairs_decide(kernel, oracle_mod):
+    """SawyerLiftObstacle: the can is a convex mesh.  Park it (random orientation) around the gripper / in the arm's
+    workspace / half-way into the table so that primitive-vs-mesh (MPR on the hull) and plane/table-vs-mesh pairs
+    decide verdicts and depths; per-pair distances of mesh pairs must be bit-identical as well."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.mjcf import GEOM_MESH
+    env = "SawyerLiftObstacle-v0"
+    pi, sc, orc = _mk(env, oracle_mod, kernel)
+    m = pi.model
+    bp = BatchPlanner(sc)
+    E, S = 24, 128
+    qa, row = sample_states(pi, E * S, 31, "near")
+    rows = np.repeat(row, E, axis=0)
+    ca = m.get_joint_qpos_addr("cube")
+    rng = np.random.default_rng(12)
+    names = [m.all_geom_names[i] for i in m.geom_mjid]
+    claw = [i for i, n in enumerate(names) if "claw" in n or "finger" in n][0]
+    for e in range(16):   # the can floats next to THIS env's gripper; the env's states jitter around one arm pose
+        base = qa[e * S].copy()
+        qa[e * S:(e + 1) * S] = np.clip(base + rng.normal(0, 0.04, (S, len(base))), pi.jnt_minimum, pi.jnt_maximum)
+        gpos, _ = orc.fk(_full(pi, base, row[0]))
+        rows[e, ca:ca + 3] = gpos[claw] + rng.normal(0, 0.035, 3)
+    rows[16:20, ca + 2] -= rng.uniform(0.0, 0.03, 4)                  # sunk into the table top
+    quat = rng.normal(size=(20, 4))
+    rows[:20, ca + 3:ca + 7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    ov, omd = orc.is_valid_batch(qa, rows, samples_per_env=S, nthreads=0)
+    tq, tr = torch.from_numpy(qa).cuda(), torch.from_numpy(rows).cuda()
+    v, md = bp.is_valid(tq, tr, samples_per_env=S, want_min_dist=True)
+    v2 = bp.is_valid(tq, tr, samples_per_env=S)
+    torch.cuda.synchronize()
+    assert np.array_equal(v.cpu().numpy(), ov) and np.array_equal(v2.cpu().numpy(), ov)
+    assert np.array_equal(_bits(md.cpu().numpy()), _bits(omd))
+    # mesh pairs really were decisive somewhere, and their distances agree bit for bit
+    g = int(np.where(m.geom_type == GEOM_MESH)[0][0])
+    ignored = set(pi.ignored_contacts)
+    ign_mask = np.array([(min(m.geom_mjid[a], m.geom_mjid[b]), max(m.geom_mjid[a], m.geom_mjid[b])) in ignored
+                         for a, b in m.pair_geom])
+    mesh_pairs = np.where((m.pair_geom == g).any(axis=1) & ~ign_mask)[0]
+    n_hit = 0
+    for i in list(range(0, 20 * S, 97)):
+        qf = _full(pi, qa[i], rows[i // S])
+        od, dd = orc.pair_dist(qf), sc.debug_pair_dist(qf)
+        od[ign_mask] = 1.0e10   # the HIP scene drops ignored pairs altogether
+        assert np.array_equal(_bits(od), _bits(dd))
+        n_hit += int((od[mesh_pairs] < 0).any())
+    assert n_hit >= 3 and 0 < ov[:20 * S].sum() < 20 * S
+
+
 def test_kernel_auto_selection_is_result_invariant(oracle_mod):
     """Default scene: small batches take the wave-per-state kernel, large ones the lane-per-state kernel; the verdicts
     and depths of the same states must not depend on which one ran."""

@@ -42,7 +42,7 @@ def independent_fk(m, qpos):
     return P, Rw
 
 
-@pytest.mark.parametrize("env", SUPPORTED_ENVS + ["SawyerLiftObstacle-v0"])
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
 def test_fk_matches_independent_composition(env, oracle_mod):
     pi = planner_inputs(env)
     m = pi.model

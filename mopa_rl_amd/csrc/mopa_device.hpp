@@ -138,6 +138,31 @@ MOPA_HD void mopa_sincos(double x, double &sout, double &cout) {
     else { sout = -cs; cout = sn; }
 }
 
+// One hinge / slide joint applied to a body pose (the joint loop of [3P] mj_kinematics).  The off-centre correction
+// of a hinge (anchor = pos + R jnt_pos before the rotation, pos = anchor - R' jnt_pos after it) is skipped when
+// jnt_pos is exactly zero -- every joint of the reference's robots: it is then the identity (up to the sign of a
+// zero) and costs two quat->matrix conversions per body.  The CPU checker makes the same choice, so results stay
+// bit-identical.  `anchor_zero` must be `jp == (0,0,0)`.
+MOPA_HD void apply_joint(int jt, V3 ax, V3 jp, bool anchor_zero, double dq, V3 &pos, Q4 &quat) {
+    if (jt == J_SLIDE) {
+        const V3 xaxis = rot_vec_quat(ax, quat);
+        pos = addscl3(pos, xaxis, dq);
+    } else if (jt == J_HINGE) {
+        double sn, cs;
+        mopa_sincos(0.5 * dq, sn, cs);
+        const Q4 ql{cs, ax.x * sn, ax.y * sn, ax.z * sn};
+        if (anchor_zero) {
+            quat = quat_mul(quat, ql);
+        } else {
+            const V3 xanchor = add3(rot_vec_quat(jp, quat), pos);
+            quat = quat_mul(quat, ql);
+            const V3 vec = rot_vec_quat(jp, quat);
+            pos = sub3(xanchor, vec);
+        }
+    }
+}
+MOPA_HD bool is_zero3(V3 v) { return v.x == 0.0 && v.y == 0.0 && v.z == 0.0; }
+
 // Deterministic exp / tanh for the env reward (never libm / OCML, so CPU oracle and GPU agree bit for bit):
 // k = rint(x*log2(e)); two-term Cody-Waite reduction (fdlibm's ln2 split); degree-13 Taylor kernel in Horner
 // form on |r| <= ln2/2 (truncation error 4e-18); scaling by 2^k through the exponent bits (|x| < 700).
@@ -635,6 +660,28 @@ MOPA_HD bool bp_cull(const double *A, int ta, double rba, const double *B, doubl
     if (ta == G_PLANE) return dot3(diff, col3(A + GO_MAT, 2)) > rbb;
     double rs = rba + rbb;
     return dot3(diff, diff) > rs * rs;
+}
+
+// Second-stage cull for a pair of one STATIC and one moving geom: the static geom's world AABB (centre = its pos,
+// half extents H, computed once per scene by static_aabb_half) against the moving geom's bounding sphere.  Tables,
+// bin walls and obstacle posts are long thin boxes whose bounding spheres cover half the workspace; this removes
+// ~40-50 % of the narrow-phase work the sphere test lets through (and the expensive box pairs first).
+MOPA_HD bool aabb_cull(V3 cS, const double *H, V3 cM, double rM) {
+    return fabs(cM.x - cS.x) > H[0] + rM || fabs(cM.y - cS.y) > H[1] + rM || fabs(cM.z - cS.z) > H[2] + rM;
+}
+// world-AABB half extents of a posed primitive (conservative; + 1e-9 so that rounding can never cut into the shape)
+MOPA_HD void static_aabb_half(int type, const double *rec, double rbound, double *H) {
+    const double *M = rec + GO_MAT, *sz = rec + GO_SIZE;
+    for (int i = 0; i < 3; i++) {
+        const double a0 = fabs(M[3 * i]), a1 = fabs(M[3 * i + 1]), a2 = fabs(M[3 * i + 2]);
+        double hv;
+        if (type == G_BOX) hv = fma(a2, sz[2], fma(a1, sz[1], a0 * sz[0]));
+        else if (type == G_SPHERE) hv = sz[0];
+        else if (type == G_CAPSULE) hv = fma(a2, sz[1], sz[0]);
+        else if (type == G_CYLINDER) { const double s2 = fma(-a2, a2, 1.0); hv = fma(a2, sz[1], sz[0] * ((s2 > 0.0) ? sqrt(s2) : 0.0)); }
+        else hv = rbound;   // mesh / anything else: the bounding sphere
+        H[i] = hv + 1e-9;
+    }
 }
 
 // counter-based RNG: splitmix64 finaliser over (seed, stream, counter)

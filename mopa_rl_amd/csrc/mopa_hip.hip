@@ -59,6 +59,7 @@ struct SceneHdr {
     // double-blob offsets
     int o_mb_pos, o_mb_quat, o_sf_pos, o_sf_quat, o_sf_mat, o_mj_axis, o_mj_pos, o_mj_ref;
     int o_g_lpos, o_g_lquat, o_g_rbound, o_g_rec, o_act_lo, o_act_hi, o_act_ext;
+    int o_g_aabb;   // [ng][3] world-AABB half extents of static geoms (second-stage cull), zeros for moving geoms
     // int-blob offsets
     int o_mb_parent, o_mb_jntadr, o_mb_jntnum, o_mj_type, o_mj_qsrc, o_g_type, o_g_slot, o_g_mb;
     int o_mg_geom, o_chain_adr, o_chain_len, o_chain_items, o_pairs, o_pq_adr, o_act_adr, o_act_so2;
@@ -157,6 +158,20 @@ MOPA_D const double *geom_rec(const SceneHdr &h, const LdsView &v, int g) {
     return (slot >= 0) ? (v.grec + slot * kGeomStride) : (v.dbl + h.o_g_rec + g * kGeomStride);
 }
 
+// broad phase of one candidate pair: bounding spheres (plane: signed distance), then -- exactly one geom static --
+// the static geom's world AABB against the moving geom's bounding sphere
+MOPA_D bool pair_culled(const SceneHdr &h, const LdsView &v, int g1, int g2, const double *A, const double *B) {
+    const int *I = v.ints;
+    const double *D = v.dbl;
+    const int t1 = I[h.o_g_type + g1];
+    if (bp_cull(A, t1, D[h.o_g_rbound + g1], B, D[h.o_g_rbound + g2])) return true;
+    if (t1 == G_PLANE) return false;
+    const bool s1 = I[h.o_g_slot + g1] < 0, s2 = I[h.o_g_slot + g2] < 0;
+    if (s1 == s2) return false;
+    const int gs = s1 ? g1 : g2, gm = s1 ? g2 : g1;
+    return aabb_cull(ld3((s1 ? A : B) + GO_POS), D + h.o_g_aabb + 3 * gs, ld3((s1 ? B : A) + GO_POS), D[h.o_g_rbound + gm]);
+}
+
 // Forward kinematics for the state whose joint values are in v.qbuf.
 // Lane l < nmg walks the ancestor chain of moving geom l (same operation order
 // as a parent-first sweep over the body tree) and writes the posed geom.
@@ -198,19 +213,8 @@ MOPA_D void wave_fk(const SceneHdr &h, const LdsView &v, int lane) {
                 quat = quat_mul(pquat, Q4{bq[0], bq[1], bq[2], bq[3]});
                 for (int j = ja; j < ja + jn; j++) {
                     V3 ax = ld3(D + h.o_mj_axis + 3 * j), jp = ld3(D + h.o_mj_pos + 3 * j);
-                    V3 xaxis = rot_vec_quat(ax, quat);
-                    V3 xanchor = add3(rot_vec_quat(jp, quat), pos);
                     double dq = v.qbuf[I[h.o_mj_qsrc + j]] - D[h.o_mj_ref + j];
-                    int jt = I[h.o_mj_type + j];
-                    if (jt == J_SLIDE) {
-                        pos = addscl3(pos, xaxis, dq);
-                    } else if (jt == J_HINGE) {
-                        double sn, cs;
-                        mopa_sincos(0.5 * dq, sn, cs);
-                        quat = quat_mul(quat, Q4{cs, ax.x * sn, ax.y * sn, ax.z * sn});
-                        V3 vec = rot_vec_quat(jp, quat);
-                        pos = sub3(xanchor, vec);
-                    }
+                    apply_joint(I[h.o_mj_type + j], ax, jp, is_zero3(jp), dq, pos, quat);
                 }
                 quat = quat_normalize(quat);
             }
@@ -238,7 +242,6 @@ MOPA_D void wave_fk(const SceneHdr &h, const LdsView &v, int lane) {
 template <bool WANT_MD, bool MESH = false>
 MOPA_D bool wave_collide(const SceneHdr &h, const LdsView &v, int lane, double &min_dist) {
     const int *I = v.ints;
-    const double *D = v.dbl;
     // 1. broad phase + ballot compaction (order-preserving => worklist stays sorted by pair type)
     int wl_count = 0;
     for (int base = 0; base < h.npair; base += 64) {
@@ -248,7 +251,7 @@ MOPA_D bool wave_collide(const SceneHdr &h, const LdsView &v, int lane, double &
             int pk = I[h.o_pairs + p];
             int g1 = pk & 0xff, g2 = (pk >> 8) & 0xff;
             const double *A = geom_rec(h, v, g1), *B = geom_rec(h, v, g2);
-            surv = !bp_cull(A, I[h.o_g_type + g1], D[h.o_g_rbound + g1], B, D[h.o_g_rbound + g2]);
+            surv = !pair_culled(h, v, g1, g2, A, B);
         }
         unsigned long long mask = __ballot(surv);
         if (surv) {
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_state(SceneHdr h, const double
         int g1 = pk & 0xff, g2 = (pk >> 8) & 0xff, code = (pk >> 16) & 0xff;
         const double *A = geom_rec(h, v, g1), *B = geom_rec(h, v, g2);
         double d = kFar;
-        if (!bp_cull(A, v.ints[h.o_g_type + g1], v.dbl[h.o_g_rbound + g1], B, v.dbl[h.o_g_rbound + g2]))
+        if (!pair_culled(h, v, g1, g2, A, B))
             d = geom_dist<MESH>(code, A, v.ints[h.o_g_type + g1], B, v.ints[h.o_g_type + g2], v.dbl);
         out_dist[p] = d;
     }
@@ -703,7 +706,9 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         int32_t *r = &mbr[8 * (size_t)k];
         r[0] = jn; r[1] = ja; r[2] = mb_load[k]; r[3] = (mb_parent[k] < 0) ? -(mb_parent[k] + 1) : 0;
         r[4] = mb_save[k]; r[5] = mb_mgadr[k]; r[6] = mb_mgnum[k];
-        r[7] = (jn > 0) ? ((mj_type[ja] & 0xff) | (mj_qsrc[ja] << 8)) : 0xff;
+        // joint 0: type (7 bits) | bit 7 = anchor at the body origin (mopa_device.hpp: apply_joint) | value slot << 8
+        const bool jp_zero = jn > 0 && mj_pos[3 * (size_t)ja] == 0.0 && mj_pos[3 * (size_t)ja + 1] == 0.0 && mj_pos[3 * (size_t)ja + 2] == 0.0;
+        r[7] = (jn > 0) ? ((mj_type[ja] & 0x7f) | (jp_zero ? 0x80 : 0) | (mj_qsrc[ja] << 8)) : 0x7f;
         double *d = &mbd[16 * (size_t)k];
         std::memcpy(d, &mb_pos[3 * (size_t)k], 24);
         std::memcpy(d + 3, &mb_quat[4 * (size_t)k], 32);
@@ -732,6 +737,13 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.o_sf_pos = B.add_d(sf_pos); h.o_sf_quat = B.add_d(sf_quat); h.o_sf_mat = B.add_d(sf_mat);
     h.o_mj_axis = B.add_d(mj_axis); h.o_mj_pos = B.add_d(mj_pos); h.o_mj_ref = B.add_d(mj_ref);
     h.o_g_lpos = B.add_d(g_lpos); h.o_g_lquat = B.add_d(g_lquat); h.o_g_rbound = B.add_d(g_rbound);
+    {
+        std::vector<double> g_aabb(3 * (size_t)m.ngeom, 0.0);
+        for (int g = 0; g < m.ngeom; g++)
+            if (g_slot[g] < 0 && m.geom_type[g] != G_PLANE)
+                static_aabb_half(m.geom_type[g], &g_rec[(size_t)kGeomStride * g], g_rbound[g], &g_aabb[3 * (size_t)g]);
+        h.o_g_aabb = B.add_d(g_aabb);
+    }
     if (B.dbl.size() & 1) B.dbl.push_back(0.0);   // 16-byte align the posed records
     // mesh hulls live in the double blob; a mesh geom's record carries (blob offset of its vertices, vertex count)
     // where primitives carry their size (mopa_device.hpp: mesh_support_local / d_plane_mesh)

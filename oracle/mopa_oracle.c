@@ -77,6 +77,8 @@ struct OrcScene {
     double *act_lo, *act_hi, *act_ext;
     uint8_t *act_so2;  /* unlimited hinge -> OMPL SO2StateSpace (mujoco_ompl_interface.cpp:234-239) */
     uint8_t *body_needed;  /* body has a collidable geom below it */
+    uint8_t *geom_static;  /* no joint between the geom's body and the world */
+    double *geom_aabb;     /* [ngeom,3] world-AABB half extents of static geoms (second-stage cull) */
     int nmesh, nmeshvert;
     int32_t *mesh_vertadr, *mesh_vertnum, *geom_dataid;   /* convex hulls of mesh geoms; geom_dataid NULL = no meshes */
     double *mesh_vert;
@@ -225,6 +227,8 @@ static void *dupmem(const void *p, size_t n) {
     return r;
 }
 
+static void scene_static_aabbs(OrcScene *s);
+
 OrcScene *orc_scene_create(
     int nq, int nbody, const int32_t *body_parent, const double *body_pos, const double *body_quat,
     const int32_t *body_jntadr, const int32_t *body_jntnum,
@@ -307,6 +311,9 @@ OrcScene *orc_scene_create(
         int b = geom_body[g];
         while (b > 0 && !s->body_needed[b]) { s->body_needed[b] = 1; b = body_parent[b]; }
     }
+    s->geom_static = (uint8_t *)calloc(ngeom ? ngeom : 1, 1);
+    s->geom_aabb = (double *)calloc(ngeom ? 3 * ngeom : 1, sizeof(double));
+    scene_static_aabbs(s);
     return s;
 }
 
@@ -326,6 +333,7 @@ void orc_scene_set_meshes(OrcScene *s, int nmesh, const int32_t *mesh_vertadr, c
         for (int i = 0; i < mesh_vertnum[geom_dataid[g]]; i++) r2 = dmax(r2, dot3(V + 3 * i, V + 3 * i));
         s->geom_rbound[g] = sqrt(r2);
     }
+    scene_static_aabbs(s);
 }
 
 void orc_scene_destroy(OrcScene *s) {
@@ -335,6 +343,7 @@ void orc_scene_destroy(OrcScene *s) {
     free(s->jnt_ref); free(s->jnt_range); free(s->geom_type); free(s->geom_body); free(s->geom_mjid);
     free(s->geom_size); free(s->geom_pos); free(s->geom_quat); free(s->geom_rbound); free(s->pair_geom);
     free(s->mesh_vertadr); free(s->mesh_vertnum); free(s->mesh_vert); free(s->geom_dataid);
+    free(s->geom_static); free(s->geom_aabb);
     free(s->pair_ignored); free(s->active_idx); free(s->act_lo); free(s->act_hi); free(s->act_ext); free(s->act_so2);
     free(s->body_needed);
     free(s);
@@ -366,22 +375,30 @@ static void fk_bodies(const OrcScene *s, const double *qpos, double *xpos, doubl
             quat_mul(q, xquat + 4 * pid, s->body_quat + 4 * b);
             for (int j = ja; j < ja + jn; j++) {
                 const double *ax = s->jnt_axis + 3 * j, *jp = s->jnt_pos + 3 * j;
-                double xaxis[3], xanchor[3];
-                rot_vec_quat(xaxis, ax, q);
-                rot_vec_quat(xanchor, jp, q);
-                add3(xanchor, xanchor, p);
                 double dq = qpos[s->jnt_qposadr[j]] - s->jnt_ref[j];
                 if (s->jnt_type[j] == J_SLIDE) {
+                    double xaxis[3];
+                    rot_vec_quat(xaxis, ax, q);
                     addscl3(p, p, xaxis, dq);
                 } else if (s->jnt_type[j] == J_HINGE) {
-                    double sn, cs, ql[4], qt[4], vec[3];
+                    double sn, cs, ql[4], qt[4];
                     orc_sincos(0.5 * dq, &sn, &cs);
                     ql[0] = cs; ql[1] = ax[0] * sn; ql[2] = ax[1] * sn; ql[3] = ax[2] * sn;
-                    quat_mul(qt, q, ql);
-                    q[0] = qt[0]; q[1] = qt[1]; q[2] = qt[2]; q[3] = qt[3];
-                    /* correct for off-center rotation */
-                    rot_vec_quat(vec, jp, q);
-                    sub3(p, xanchor, vec);
+                    if (jp[0] == 0.0 && jp[1] == 0.0 && jp[2] == 0.0) {
+                        /* anchor at the body origin (every joint of the reference's robots): the off-centre
+                         * correction below is the identity up to the sign of a zero -- skipped, as in the kernels */
+                        quat_mul(qt, q, ql);
+                        q[0] = qt[0]; q[1] = qt[1]; q[2] = qt[2]; q[3] = qt[3];
+                    } else {
+                        double xanchor[3], vec[3];
+                        rot_vec_quat(xanchor, jp, q);
+                        add3(xanchor, xanchor, p);
+                        quat_mul(qt, q, ql);
+                        q[0] = qt[0]; q[1] = qt[1]; q[2] = qt[2]; q[3] = qt[3];
+                        /* correct for off-center rotation */
+                        rot_vec_quat(vec, jp, q);
+                        sub3(p, xanchor, vec);
+                    }
                 }
                 /* ball / extra free joints: not present in the supported scenes */
             }
@@ -415,6 +432,39 @@ void orc_fk(const OrcScene *s, const double *qpos, double *gpos, double *gmat) {
     fk_bodies(s, qpos, xpos, xquat, xmat, 1);
     fk_geoms(s, xpos, xquat, xmat, gpos, gmat);
     free(buf);
+}
+
+/* world-AABB half extents of every static geom (no joint on the way to the world), for the second broad-phase
+ * stage; conservative, + 1e-9 so that rounding can never cut into the shape.  Same expressions as
+ * static_aabb_half() in the kernels' header. */
+static void scene_static_aabbs(OrcScene *s) {
+    double *q0 = (double *)calloc(s->nq ? s->nq : 1, sizeof(double));
+    double *buf = (double *)malloc(sizeof(double) * (16 * (size_t)s->nbody + 12 * (size_t)s->ngeom));
+    double *xpos = buf, *xquat = buf + 3 * s->nbody, *xmat = buf + 7 * s->nbody;
+    double *gpos = buf + 16 * s->nbody, *gmat = gpos + 3 * s->ngeom;
+    fk_bodies(s, q0, xpos, xquat, xmat, 1);      /* static bodies do not read qpos */
+    fk_geoms(s, xpos, xquat, xmat, gpos, gmat);
+    for (int g = 0; g < s->ngeom; g++) {
+        int b = s->geom_body[g], st = 1;
+        for (; b > 0; b = s->body_parent[b]) if (s->body_jntnum[b] > 0) st = 0;
+        s->geom_static[g] = (uint8_t)st;
+        double *H = s->geom_aabb + 3 * g;
+        H[0] = H[1] = H[2] = 0.0;
+        if (!st || s->geom_type[g] == G_PLANE) continue;
+        const double *M = gmat + 9 * g, *sz = s->geom_size + 3 * g;
+        for (int i = 0; i < 3; i++) {
+            double a0 = fabs(M[3 * i]), a1 = fabs(M[3 * i + 1]), a2 = fabs(M[3 * i + 2]), hv;
+            switch (s->geom_type[g]) {
+                case G_BOX: hv = fma(a2, sz[2], fma(a1, sz[1], a0 * sz[0])); break;
+                case G_SPHERE: hv = sz[0]; break;
+                case G_CAPSULE: hv = fma(a2, sz[1], sz[0]); break;
+                case G_CYLINDER: { double s2 = fma(-a2, a2, 1.0); hv = fma(a2, sz[1], sz[0] * ((s2 > 0.0) ? sqrt(s2) : 0.0)); } break;
+                default: hv = s->geom_rbound[g]; break;
+            }
+            H[i] = hv + 1e-9;
+        }
+    }
+    free(buf); free(q0);
 }
 
 /* ------------------------------------------------------------------ */
@@ -953,7 +1003,14 @@ static inline int bp_cull(const OrcScene *s, int g1, int g2, const double *gpos,
     double diff[3];
     sub3(diff, gpos + 3 * g2, gpos + 3 * g1);
     double rs = s->geom_rbound[g1] + s->geom_rbound[g2];
-    return dot3(diff, diff) > rs * rs;
+    if (dot3(diff, diff) > rs * rs) return 1;
+    /* second stage, exactly one geom static: its world AABB vs the moving geom's bounding sphere */
+    if (s->geom_static[g1] == s->geom_static[g2]) return 0;
+    {
+        const int gs = s->geom_static[g1] ? g1 : g2, gm = s->geom_static[g1] ? g2 : g1;
+        const double *cS = gpos + 3 * gs, *cM = gpos + 3 * gm, *H = s->geom_aabb + 3 * gs, rM = s->geom_rbound[gm];
+        return fabs(cM[0] - cS[0]) > H[0] + rM || fabs(cM[1] - cS[1]) > H[1] + rM || fabs(cM[2] - cS[2]) > H[2] + rM;
+    }
 }
 
 static void pair_dists(const OrcScene *s, const double *gpos, const double *gmat, double *dist) {

@@ -201,6 +201,33 @@ def test_lift_can_mesh_pairs_decide(kernel, oracle_mod):
     assert n_hit >= 3 and 0 < ov[:20 * S].sum() < 20 * S
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_offcentre_joint_anchors(kernel, oracle_mod):
+    """No reference scene has a joint anchor away from the body origin, and the FK takes a shortcut for that case:
+    exercise the general branch on a model with random anchors (FK poses, verdicts and depths, both K1 kernels)."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import planner_inputs
+    from test_oracle_fk import _with_offcentre_anchors
+    env = "SawyerPushObstacle-v0"
+    pi = planner_inputs(env)
+    m = _with_offcentre_anchors(pi.model)
+    sc = _scene_with_kernel(kernel, m, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+    orc = oracle_mod.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    qa, row = sample_states(pi, 4096, 77, "near")
+    for i in range(0, 4096, 517):
+        q = _full(pi, qa[i], row[0])
+        gp, gm = sc.debug_fk(q)
+        op, om = orc.fk(q)
+        assert np.array_equal(_bits(gp), _bits(op)) and np.array_equal(_bits(gm.reshape(-1, 9)), _bits(om.reshape(-1, 9)))
+    ov, omd = orc.is_valid_batch(qa, row, samples_per_env=len(qa), nthreads=0)
+    v, md = BatchPlanner(sc).is_valid(torch.from_numpy(qa).cuda(), torch.from_numpy(row).cuda(), samples_per_env=len(qa),
+                                      want_min_dist=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(v.cpu().numpy(), ov) and np.array_equal(_bits(md.cpu().numpy()), _bits(omd))
+    assert 0 < ov.sum() < len(ov)
+
+
 def test_kernel_auto_selection_is_result_invariant(oracle_mod):
     """Default scene: small batches take the wave-per-state kernel, large ones the lane-per-state kernel; the verdicts
     and depths of the same states must not depend on which one ran."""

@@ -105,3 +105,36 @@ def test_sincos_accuracy(oracle_mod):
         err = max(err, abs(s - math.sin(x)), abs(c - math.cos(x)))
     assert err < 2.3e-16
     assert oracle_mod.sincos(0.0) == (0.0, 1.0)
+
+
+def _with_offcentre_anchors(m, seed=0):
+    """copy of a compiled model whose hinge/slide joints get random non-zero anchors (jnt_pos): none of the reference
+    scenes has any, and the FK code takes a shortcut when the anchor is at the body origin"""
+    import copy
+    m2 = copy.copy(m)
+    rng = np.random.default_rng(seed)
+    jp = m.jnt_pos.copy()
+    for j in range(len(m.jnt_names)):
+        if m.jnt_type[j] in (JNT_HINGE, JNT_SLIDE) and j % 3 != 2:      # leave every third joint centred
+            jp[j] = rng.uniform(-0.05, 0.05, 3)
+    m2.jnt_pos = jp
+    return m2
+
+
+@pytest.mark.parametrize("env", ["SawyerPushObstacle-v0", "PusherObstacle-v0"])
+def test_fk_with_offcentre_joint_anchors(env, oracle_mod):
+    pi = planner_inputs(env)
+    m = _with_offcentre_anchors(pi.model)
+    orc = oracle_mod.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    rng = np.random.default_rng(4)
+    q0 = default_qpos(env, m)
+    moved = 0.0
+    for _ in range(10):
+        q = q0.copy()
+        q[pi.ref_joint_pos_indexes] = rng.uniform(pi.jnt_minimum, pi.jnt_maximum)
+        P, Rw = independent_fk(m, q)
+        xpos, xquat = orc.fk_bodies(q)
+        np.testing.assert_allclose(xpos, P, rtol=0, atol=2e-12)
+        P0, _ = independent_fk(pi.model, q)
+        moved = max(moved, np.abs(P - P0).max())
+    assert moved > 0.01      # the anchors really changed the kinematics

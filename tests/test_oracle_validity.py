@@ -200,3 +200,41 @@ def test_rng_is_uniform_and_counter_based(oracle_mod):
     assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.003
     assert oracle_mod.rng_uniform(1, 2, 77) == u[77]
     assert oracle_mod.rng_uniform(1, 3, 77) != u[77] and oracle_mod.rng_uniform(2, 2, 77) != u[77]
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_broad_phase_is_conservative(env, oracle_mod):
+    """Every pair the broad phase culls (bounding spheres, then static world-AABB vs bounding sphere) must be truly
+    separated: its narrow-phase distance, computed here without any cull, is positive (or "no intersection")."""
+    from mopa_rl_amd.mjcf import GEOM_MESH
+    pi = planner_inputs(env)
+    m = pi.model
+    orc = oracle_mod.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    n_culled = n_second_stage = 0
+    for mode in ("uniform", "near"):
+        qa, rows = sample_states(pi, 60, 11, mode)
+        for i in range(len(qa)):
+            q = rows[0].copy()
+            q[pi.ref_joint_pos_indexes] = qa[i]
+            gp, gm = orc.fk(q)
+            d = orc.pair_dist(q)
+            for p in np.where(d == 1.0e10)[0]:
+                a, b = m.pair_geom[p]
+                if m.geom_type[b] == GEOM_MESH:
+                    verts = m.mesh_vert[m.mesh_vertadr[0]:m.mesh_vertadr[0] + m.mesh_vertnum[0]]
+                    true = oracle_mod.geom_dist_mesh(m.geom_type[a], m.geom_size[a], gp[a], gm[a], verts, gp[b], gm[b])
+                else:
+                    true = oracle_mod.geom_dist(m.geom_type[a], m.geom_size[a], gp[a], gm[a], m.geom_type[b], m.geom_size[b], gp[b], gm[b])
+                assert true > 0.0, (env, p, true)
+                n_culled += 1
+                if m.geom_type[a] != 0:
+                    rs = _rbound(m, a) + _rbound(m, b)
+                    n_second_stage += float(np.sum((gp[b] - gp[a]) ** 2)) <= rs * rs
+    assert n_culled > 1000 and n_second_stage > 50      # the AABB stage really culled pairs the spheres let through
+
+
+def _rbound(m, g):
+    t, s = int(m.geom_type[g]), m.geom_size[g]
+    if t == 7:
+        return float(np.linalg.norm(m.mesh_vert, axis=1).max())
+    return {2: s[0], 3: s[0] + s[1], 5: float(np.hypot(s[0], s[1])), 6: float(np.linalg.norm(s))}[t]

@@ -158,6 +158,36 @@ def env_step_section(torch, pi, E, device, steps, with_cpu):
     return out
 
 
+def rollout_section(torch, pi, E, device, agent_steps):
+    """End-to-end MoPA rollout step (mopa_rl_amd/rollout.py): random policy actions -> per env either a direct env step or
+    target / pull-back / straight-line pre-check / RRT-Connect / densification / waypoint execution on the kinematic
+    env.  Host-orchestrated (torch + numpy for the ragged planner paths), every check / plan / env step a batched launch."""
+    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    env = BatchKinematicPushEnv(E, device=device, seed=21, max_episode_steps=250)
+    env.reset()
+    ro = BatchMoPARollout(env, RolloutConfig())
+    g = torch.Generator(device=device)
+    g.manual_seed(8)
+    acts = torch.rand(agent_steps + 1, E, 7, generator=g, dtype=torch.float64, device=device) * 2 - 1
+    out = ro.agent_step(acts[0])
+    env.reset(out["done"].bool())
+    torch.cuda.synchronize()
+    n_env_steps = 0
+    t0 = time.perf_counter()
+    for t in range(agent_steps):
+        out = ro.agent_step(acts[1 + t])
+        n_env_steps += int((out["intra_steps"] + 1).sum().item())
+        if bool(out["done"].any().item()):
+            env.reset(out["done"].bool())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = {k: int(v.sum().item()) for k, v in ro.counters.items()}
+    return {"config": f"{ENV}, {E} envs, {agent_steps} agent steps of uniform random actions in [-1,1]^7 (omega 0.7), kinematic env",
+            "agent_steps_per_s": E * agent_steps / dt, "env_steps_per_s": n_env_steps / dt, "s_per_agent_step_batch": dt / agent_steps,
+            "counters": c}
+
+
 def cpu_baseline(pi, qa_host, rows_host, S, budget_states):
     """Oracle (oracle/mopa_oracle.c, kind="port") on the host cores, on the first `budget_states` states."""
     from oracle import oracle as O
@@ -189,6 +219,7 @@ def main():
     ap.add_argument("--no-plan", action="store_true", help="skip the RRT-Connect section (config 3)")
     ap.add_argument("--plan-envs", type=int, default=4096)
     ap.add_argument("--no-env", action="store_true", help="skip the kinematic env.step section")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the end-to-end rollout section")
     args = ap.parse_args()
 
     import torch
@@ -288,6 +319,8 @@ def main():
             out["planner"] = plan_section(torch, bp, pi, args.plan_envs, device)
         if not args.no_env and world == 1:
             out["env_step"] = env_step_section(torch, pi, args.envs, device, 50, not args.no_cpu)
+        if not args.no_rollout and world == 1:
+            out["rollout"] = rollout_section(torch, pi, args.envs, device, 3)
         if not args.no_cpu and world == 1:
             cb = cpu_baseline(pi, qa.cpu().numpy(), rows.cpu().numpy(), S, args.cpu_states)
             mism = int((cb["verdicts"] != valid[: cb["n"]].cpu().numpy()).sum())

@@ -114,6 +114,8 @@ typedef struct MopaPlanParams {
     int32_t max_path;      /* rows available per env in `path` */
     uint64_t seed;         /* sample-stream seed; stream id = env_id_base + env index */
     uint64_t env_id_base;
+    const uint64_t *env_ids_dev;   /* mopa_plan_batch only, nullable: explicit stream id per query (device pointer, [E]) --
+                                      lets a caller plan for a compacted subset of its envs with the streams of the full set */
 } MopaPlanParams;
 
 const char *mopa_last_error(void);
@@ -207,7 +209,8 @@ void mopa_env_destroy(MopaEnv *env);
 /* One step of E envs (all pointers device, f64 unless noted).  Per env e:
  *   prev = (is_planner && has_prev[e]) ? prev_state[e] : qpos[e, arm]
  *   desired = prev + clip(is_planner ? action[e] : action[e]*ac_scale, -ac_scale, +ac_scale)
- *   if (move_mask == NULL || move_mask[e]) qpos[e, arm] = desired       -- kinematic servo
+ *   move_mask[e] (NULL = 1): bit 1 set -> env e sits this call out entirely (nothing read or written);
+ *   bit 0 set -> qpos[e, arm] = desired (kinematic servo); bit 0 clear -> the command is recorded but the arm stays
  *   prev_state[e] = desired, has_prev[e] = 1; limited qpos entries clipped to their range
  *   FK -> reward, success, obs; ep_len[e] += 1; done[e] = success || ep_len[e] == max_episode_steps
  * action == NULL: no step, only FK -> obs (reward/done/success untouched; used after a reset). */

@@ -141,6 +141,16 @@ def clip_target_to_limits(target_qpos, jnt_minimum, jnt_maximum, is_jnt_limited)
     return out
 
 
+def norm_seq(d):
+    """Euclidean norm with the squares summed left to right.  The reference calls np.linalg.norm (BLAS dot: the
+    summation order, hence the last bit, depends on the BLAS build); this fixed order is what the scalar and the
+    batched back-off share so that they agree bit for bit."""
+    acc = 0.0
+    for x in np.asarray(d, dtype=np.float64).ravel():
+        acc = acc + x * x
+    return float(np.sqrt(acc))
+
+
 def handle_invalid_target(pi, curr_qpos, target_qpos, step_size: float, num_trials: int):
     """rl/mopa_rollouts.py:133-143: walk an invalid target back toward the current state in steps of
     `step_size` (Euclidean, over the full qpos vector) until it is valid or `num_trials` is exhausted.
@@ -150,7 +160,7 @@ def handle_invalid_target(pi, curr_qpos, target_qpos, step_size: float, num_tria
     if not pi.isValidState(target_qpos):
         while not pi.isValidState(target_qpos) and trial < num_trials:
             d = curr_qpos - target_qpos
-            target_qpos += step_size * d / np.linalg.norm(d)
+            target_qpos += step_size * d / norm_seq(d)
             trial += 1
     return target_qpos, trial
 
@@ -230,7 +240,11 @@ def handle_invalid_target_batch(bp, curr_qpos, target_qpos, step_size: float, nu
         if not bool(todo.any().item()):
             break
         d = curr_qpos - target
-        step = step_size * d / torch.linalg.norm(d, dim=1, keepdim=True)
+        sq = d * d
+        acc = torch.zeros_like(sq[:, 0])
+        for c in range(nq):      # same left-to-right order as norm_seq
+            acc = acc + sq[:, c]
+        step = step_size * d / torch.sqrt(acc)[:, None]
         target = torch.where(todo[:, None], target + step, target)
         trials += todo.to(torch.int64)
         valid = torch.where(todo, check(target), valid)

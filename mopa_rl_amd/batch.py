@@ -71,8 +71,9 @@ class BatchPlanner:
         return valid
 
     def plan(self, start, goal, max_iters: int = 2000, max_nodes: int = 1024, max_path: int = 256, seed: int = 0,
-             env_id_base: int = 0, stream=None) -> Tuple["object", "object", "object", "object"]:
-        """E independent RRT-Connect queries.  Returns (path[E,max_path,nq], path_len[E], status[E], n_checks[E])."""
+             env_id_base: int = 0, stream=None, env_ids=None) -> Tuple["object", "object", "object", "object"]:
+        """E independent RRT-Connect queries.  Returns (path[E,max_path,nq], path_len[E], status[E], n_checks[E]).
+        env_ids (int64 [E] GPU tensor, optional): the sample-stream id of every query (default env_id_base + index)."""
         torch = _torch()
         _check_f64(start, "start", self.nq)
         _check_f64(goal, "goal", self.nq)
@@ -82,8 +83,11 @@ class BatchPlanner:
         plen = torch.zeros(E, dtype=torch.int32, device=dev)
         status = torch.zeros(E, dtype=torch.int32, device=dev)
         nchk = torch.zeros(E, dtype=torch.int64, device=dev)
+        if env_ids is not None and (env_ids.dtype != torch.int64 or not env_ids.is_cuda or not env_ids.is_contiguous()
+                                    or tuple(env_ids.shape) != (E,)):
+            raise _lib.MopaError("env_ids must be a contiguous int64 GPU tensor of shape [E]")
         prm = _lib.MopaPlanParams(int(max_iters), int(max_nodes), int(max_path), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                  int(env_id_base))
+                                  int(env_id_base), _ptr(env_ids) if env_ids is not None else None)
         _lib.check(_lib.lib().mopa_plan_batch(self.scene.handle, _ptr(start), _ptr(goal), E, C.byref(prm), _ptr(path),
                                               _ptr(plen), _ptr(status), _ptr(nchk), _stream_handle(stream)))
         return path, plen, status, nchk

@@ -1,0 +1,308 @@
+"""Batched rollout step of MoPA-RL: the body of `MoPARolloutRunner.run`'s inner loop
+(reference rl/mopa_rollouts.py:70-375) for E envs at once, on the batched pieces of this package.
+
+One call of :meth:`BatchMoPARollout.agent_step` is one iteration of the reference's `while not done` loop for every
+env: the policy action either is executed directly (`env.step(ac / omega)`, :336-356) or -- some |ac_j| > omega
+(`is_planner_ac`, rl/sac_agent.py:148-153) -- is turned into a joint-space target (:116-131), pulled back while
+invalid (:133-143), planned to (`SACAgent.plan`, rl/sac_agent.py:198-235: straight-line pre-check, then RRT-Connect,
+then densification of the planner path) and executed waypoint by waypoint with `env.step(.., is_planner=True)` while
+the SMDP reward `sum_i gamma^i r_i` and `intra_steps` are accumulated (:152-199); a failed plan costs one env step with
+the current reward (:303-334).  Counters `mp / rl / interpolation / mp_fail / approximate / invalid` are kept per env.
+
+Restrictions (each raises): joint-space MoPA-SAC only (`use_ik_target=False`, `discrete_action=False`), Sawyer push
+(no unlimited joints, 7-dof actions).  `reuse_data` relabelling (:204-300) is host-side replay-buffer work on the
+returned waypoint rewards and is not part of this step.  The env is the KINEMATIC one (kinematic_env.py) -- not
+dynamics parity.
+
+Where the work runs: every validity check (targets, pull-back, interpolated states, densification) and every
+RRT-Connect query is one batched GPU launch over all envs that need it; env steps are one K4 launch per waypoint index.
+The ragged bookkeeping of planner paths (a minority of envs per step) is done on the host in numpy with the same
+arithmetic as the scalar code, so that results equal the per-env reference loop bit for bit (tests/test_gpu_rollout.py).
+RNG streams: the RRT-Connect query of env e at agent step t uses (seed + t, stream e); the fallback planners inside the
+densification use streams E + e (simple planner) and 2E + e (main planner).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _lib
+from .agent_planning import handle_invalid_target_batch, simple_interpolate_batch
+from .batch import BatchPlanner, _torch
+from .planner import ITERS_PER_SECOND
+from .scene import ENV_SPECS, planner_inputs
+
+COUNTERS = ("mp", "rl", "interpolation", "mp_fail", "approximate", "invalid")
+
+
+@dataclass
+class RolloutConfig:
+    """Defaults restated from the reference: config/__init__.py:24-110 (mopa section), config/sawyer.py:76-112,
+    config/motion_planner.py:4-70."""
+    omega: float = 0.7
+    ac_space_type: str = "piecewise"
+    action_range: float = 0.5
+    ac_scale: float = 0.05
+    invalid_target_handling: bool = True
+    num_trials: int = 100
+    step_size: float = 0.02
+    interpolation: bool = True
+    discount_factor: float = 0.99
+    timelimit: float = 1.0
+    simple_planner_timelimit: float = 0.05
+    range: float = 0.1
+    simple_planner_range: float = 0.05
+    joint_margin: float = 0.001
+    contact_threshold: float = -0.002
+    max_nodes: int = 1024
+    max_path: int = 256
+    seed: int = 1234
+
+
+def convert2planner_displacement(ac, ac_scale, cfg):
+    """rl/sac_agent.py:158-175 on tensors (divisions by tensors: `tensor / python_float` is a reciprocal multiply)."""
+    torch = _torch()
+    if cfg.ac_space_type == "normal":
+        return ac * cfg.action_range
+    if cfg.ac_space_type != "piecewise":
+        raise NotImplementedError(cfg.ac_space_type)
+    om = cfg.omega
+    inner = ac / torch.full_like(ac, om / ac_scale)
+    frac = (ac.abs() - om) / torch.full_like(ac, 1 - om)
+    outer = torch.sign(ac) * (ac_scale + (cfg.action_range - ac_scale) * frac)
+    return torch.where(ac.abs() < om, inner, outer)
+
+
+class BatchMoPARollout:
+    def __init__(self, env, cfg: Optional[RolloutConfig] = None):
+        torch = _torch()
+        self.env = env
+        self.cfg = cfg if cfg is not None else RolloutConfig()
+        if abs(env.ac_scale - self.cfg.ac_scale) > 0:
+            raise _lib.MopaError("env.ac_scale and RolloutConfig.ac_scale differ")
+        spec = ENV_SPECS[env.env_name]
+        pi = planner_inputs(env.env_name, env.model)
+        if len(pi.non_limited_idx):
+            raise NotImplementedError("unlimited joints (3.14 wrap of SamplingBasedPlanner) are not handled by the batched rollout")
+        self.pi = pi
+        dev_index = env.device.index if env.device.index is not None else -1
+        mk = lambda r: _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, self.cfg.contact_threshold, range_=r,
+                                  seed=self.cfg.seed, device=dev_index)
+        self.scene, self.simple_scene = mk(self.cfg.range), mk(self.cfg.simple_planner_range)
+        self.bp = BatchPlanner(self.scene)
+        self.E, self.nq, self.n = env.E, env.nq, env.n_arm
+        self.arm = list(int(i) for i in env.facts.arm_qpos_idx)
+        assert self.arm == list(range(self.n)), "the reference slices qpos[:n] (rl/sac_agent.py:275-278)"
+        f = env.facts
+        dev, f64 = env.device, torch.float64
+        lim = f.qpos_limited.astype(bool)
+        self._lo = torch.tensor(np.where(lim, f.qpos_min, -np.inf), dtype=f64, device=dev)
+        self._hi = torch.tensor(np.where(lim, f.qpos_max, np.inf), dtype=f64, device=dev)
+        self._lim = torch.tensor(lim, device=dev)
+        self._lo_m = torch.tensor(np.where(lim, f.qpos_min + self.cfg.joint_margin, -np.inf), dtype=f64, device=dev)
+        self._hi_m = torch.tensor(np.where(lim, f.qpos_max - self.cfg.joint_margin, np.inf), dtype=f64, device=dev)
+        self.counters: Dict[str, "object"] = {k: torch.zeros(self.E, dtype=torch.int64, device=dev) for k in COUNTERS}
+        self.t = 0     # agent steps taken (part of the RNG stream of the planner queries)
+        self.main_iters = max(1, int(round(self.cfg.timelimit * ITERS_PER_SECOND)))
+        self.simple_iters = max(1, int(round(self.cfg.simple_planner_timelimit * ITERS_PER_SECOND)))
+        del spec
+
+    # ------------------------------------------------------------------
+    def close(self):
+        self.scene.close()
+        self.simple_scene.close()
+
+    def clip_qpos(self, q):
+        """`SACAgent.clip_qpos` (rl/sac_agent.py:237-260) per row: rows with a limited joint out of range are clipped to
+        [min + joint_margin, max - joint_margin]; other rows are untouched."""
+        torch = _torch()
+        out = ((q < self._lo) | (q > self._hi)).any(dim=1)
+        clipped = torch.minimum(torch.maximum(q, self._lo_m), self._hi_m)
+        return torch.where(out[:, None], clipped, q)
+
+    def _valid(self, q):
+        return self.bp.is_valid(q[:, self.arm].contiguous(), q.contiguous(), samples_per_env=1).bool()
+
+    # ------------------------------------------------------------------
+    def plan(self, cur, target, env_ids):
+        """`SACAgent.plan` (rl/sac_agent.py:198-235) for M envs: returns host lists (traj_m [L_m, nq] numpy) and boolean
+        numpy arrays success, interpolation, valid, exact."""
+        torch = _torch()
+        cfg, n = self.cfg, self.n
+        M = cur.shape[0]
+        cur = self.clip_qpos(cur)
+        traj_t, tlen, succ, _ = simple_interpolate_batch(self.bp, cur, target, cfg.ac_scale, self.arm)
+        traj_h, tlen_h, succ_h = traj_t.cpu().numpy(), tlen.cpu().numpy(), succ.cpu().numpy()
+        trajs = [traj_h[m, :tlen_h[m]].copy() for m in range(M)]
+        success, interpolation = succ_h.copy(), np.ones(M, dtype=bool)
+        valid, exact = succ_h.copy(), succ_h.copy()
+        fail = np.where(~succ_h)[0]
+        if len(fail) == 0:
+            return trajs, success, interpolation, valid, exact
+        # ---- main planner for the envs whose straight line is blocked (:205-209)
+        fi = torch.as_tensor(fail, device=cur.device)
+        ids = env_ids[fi].contiguous()
+        path, plen, status, _ = self.bp.plan(cur[fi].contiguous(), target[fi].contiguous(), max_iters=self.main_iters,
+                                             max_nodes=cfg.max_nodes, max_path=cfg.max_path, seed=cfg.seed + self.t, env_ids=ids)
+        path_h, plen_h, st_h = path.cpu().numpy(), plen.cpu().numpy(), status.cpu().numpy()
+        cur_h, tgt_h, ids_h = cur.cpu().numpy(), target.cpu().numpy(), env_ids.cpu().numpy()
+        interpolation[fail] = False
+        seg_jobs = []          # (m, i, start, end) of planner-path segments that need densification
+        for j, m in enumerate(fail):
+            if st_h[j] != 0:   # sentinel rows (sampling_based_planner.py:64-69): -5 goal invalid, -4 no exact solution
+                valid[m], exact[m], success[m] = st_h[j] != _lib.PLAN_INVALID_GOAL, st_h[j] != _lib.PLAN_NO_EXACT, False
+                trajs[m] = np.full((1, self.nq), float(st_h[j]))
+                continue
+            states = path_h[j, :plen_h[j]]
+            # SamplingBasedPlanner.plan: trajectory rebuilt from successive differences (:71-99), PlannerAgent drops row 0
+            tr = [cur_h[m]]
+            for s in range(1, len(states)):
+                tr.append(tr[-1] + (states[s] - states[s - 1]))
+            trajs[m] = np.array(tr[1:])
+            success[m] = valid[m] = exact[m] = True
+            if cfg.interpolation:
+                start = cur_h[m]
+                for i in range(len(trajs[m])):
+                    diff = trajs[m][i] - start
+                    if np.any(diff[:n] < -cfg.ac_scale) or np.any(diff[:n] > cfg.ac_scale):
+                        seg_jobs.append((m, i, start, trajs[m][i]))
+                    start = trajs[m][i]
+        if seg_jobs:
+            self._densify(trajs, seg_jobs, cur_h, ids_h)
+        return trajs, success, interpolation, valid, exact
+
+    def _densify(self, trajs, seg_jobs, cur_h, ids_h):
+        """:210-233 -- every planner-path segment longer than ac_scale in some joint is replaced by
+        `simple_interpolate(start, end, ac_scale, use_planner=True)`; all interpolated states of all segments are
+        validated in ONE launch, the (rare) segments with an invalid interpolated state fall back to the single-query
+        planners exactly as the scalar code does."""
+        torch = _torch()
+        cfg, n = self.cfg, self.n
+        max_action, min_action = 1.0 * cfg.ac_scale * 0.8, -1.0 * cfg.ac_scale * 0.8
+        pieces, states_all, owner = [], [], []
+        for (m, i, start, end) in seg_jobs:
+            diff = end[:n] - start[:n]
+            out = np.where((diff > max_action) | (diff < min_action))[0]
+            od = diff[out]
+            scales = np.where(od > max_action, od / max_action, od / min_action)
+            sf = 1.0 if len(scales) == 0 else max(max(scales), 1.0)
+            scaled = diff / sf
+            interp, rows = start.copy(), []
+            for _ in range(int(sf)):
+                interp = interp.copy()
+                interp[:n] += scaled
+                rows.append(interp)
+            pieces.append(rows)
+            states_all.extend(rows)
+            owner.extend([len(pieces) - 1] * len(rows))
+        ok = np.ones(len(states_all), dtype=bool)
+        if states_all:
+            q = torch.tensor(np.array(states_all), device=self.env.device)
+            ok = self._valid(q).cpu().numpy()
+        owner = np.array(owner, dtype=np.int64)
+        replacement = {}
+        for k, (m, i, start, end) in enumerate(seg_jobs):
+            v = ok[owner == k]
+            if v.all():
+                replacement[(m, i)] = pieces[k] + [end]
+                continue
+            # simple planner, then main planner, then give up with [target] (rl/sac_agent.py:303-313)
+            e = int(ids_h[m])
+            res = None
+            for scene, iters, base in ((self.simple_scene, self.simple_iters, 1), (self.scene, self.main_iters, 2)):
+                st, p, _ = scene.plan(start, end, max_iters=iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path,
+                                      seed=cfg.seed + self.t, env_id=self.E * base + e)
+                if st == 0:
+                    tr = [start]
+                    for s in range(1, len(p)):
+                        tr.append(tr[-1] + (p[s] - p[s - 1]))
+                    res = tr[1:]
+                    break
+            replacement[(m, i)] = res if res is not None else [end]
+        for m in sorted({mm for (mm, _, _, _) in seg_jobs}):
+            new = []
+            for i in range(len(trajs[m])):
+                new.extend(replacement.get((m, i), [trajs[m][i]]))
+            trajs[m] = np.array(new)
+
+    # ------------------------------------------------------------------
+    def agent_step(self, ac):
+        """One agent step for all E envs.  ac: float64 [E, >=7] GPU tensor (policy output in [-1, 1]).
+        Returns a dict of GPU tensors: ob [E,40] (before), ob_next [E,40], rew [E] (SMDP return of the step), done [E]
+        uint8, intra_steps [E] int64, is_planner [E] bool, success [E] bool (env success flag), plus `path_len`."""
+        torch = _torch()
+        env, cfg, E, n = self.env, self.cfg, self.E, self.n
+        dev = env.device
+        a = ac[:, :n].contiguous()
+        prev_ob = env.obs.clone()
+        cur = env.qpos.clone()
+        ar = torch.arange(E, device=dev)
+        is_pl = ((a < -cfg.omega) | (a > cfg.omega)).any(dim=1)
+        plan_ok = torch.zeros(E, dtype=torch.bool, device=dev)
+        path_len = torch.zeros(E, dtype=torch.int64, device=dev)
+        traj_pad = None
+        pl_idx = torch.nonzero(is_pl).flatten()
+        if len(pl_idx):
+            disp = convert2planner_displacement(a[pl_idx], cfg.ac_scale, cfg)
+            target = cur[pl_idx].clone()
+            target[:, :n] += disp
+            # np.clip to the joint limits, unlimited entries restored (:121-131)
+            target = torch.where(self._lim, torch.minimum(torch.maximum(target, self._lo), self._hi), target)
+            if cfg.invalid_target_handling:
+                target, _, tv = handle_invalid_target_batch(self.bp, cur[pl_idx], target, cfg.step_size, cfg.num_trials)
+            else:
+                tv = self._valid(target)
+            v_idx = torch.nonzero(tv).flatten()
+            self.counters["mp_fail"][pl_idx[~tv]] += 1          # invalid target: success, valid, exact = False, False, True
+            self.counters["invalid"][pl_idx[~tv]] += 1
+            if len(v_idx):
+                ids = pl_idx[v_idx].contiguous()
+                trajs, success, interpolation, valid, exact = self.plan(cur[ids].contiguous(), target[v_idx].contiguous(), ids)
+                t = lambda x: torch.as_tensor(x, device=dev)
+                s_t = t(success)
+                plan_ok[ids] = s_t
+                self.counters["interpolation"][ids[s_t & t(interpolation)]] += 1
+                self.counters["mp"][ids[s_t & ~t(interpolation)]] += 1
+                self.counters["mp_fail"][ids[~s_t]] += 1
+                self.counters["approximate"][ids[~s_t & ~t(exact)]] += 1
+                self.counters["invalid"][ids[~s_t & ~t(valid)]] += 1
+                L = max((len(tr) for tr, s in zip(trajs, success) if s), default=0)
+                if L:
+                    pad = np.zeros((len(ids), L, self.nq))
+                    lens = np.zeros(len(ids), dtype=np.int64)
+                    for m, (tr, s) in enumerate(zip(trajs, success)):
+                        if s:
+                            pad[m, :len(tr)] = tr
+                            lens[m] = len(tr)
+                    traj_pad = torch.zeros(E, L, self.nq, dtype=torch.float64, device=dev)
+                    traj_pad[ids] = t(pad)
+                    path_len[ids] = t(lens)
+        direct = ~is_pl
+        self.counters["rl"][direct] += 1
+        # ---- direct execution (:336-356) and failed plans (:303-334: reward of the current state, one env step) in one launch
+        act0 = torch.where(direct[:, None], a / torch.full_like(a, cfg.omega), torch.zeros_like(a)).contiguous()
+        flags = torch.where(direct, 1, torch.where(plan_ok, 2, 0)).to(torch.uint8).contiguous()
+        env._launch(act0, False, flags)
+        rew = torch.where(plan_ok, torch.zeros_like(env.reward), env.reward)
+        done = torch.where(plan_ok, torch.zeros_like(env.done), env.done)
+        intra = torch.zeros(E, dtype=torch.int64, device=dev)
+        # ---- waypoint execution (:152-199)
+        if traj_pad is not None:
+            alive = plan_ok.clone()
+            for k in range(traj_pad.shape[1]):
+                active = alive & (k < path_len)
+                if not bool(active.any().item()):
+                    break
+                act_k = (traj_pad[:, k, :n] - env.qpos[:, :n]).contiguous()          # env.form_action(next_qpos)
+                env._launch(act_k, True, torch.where(active, 1, 2).to(torch.uint8).contiguous())
+                rew = torch.where(active, rew + (cfg.discount_factor ** k) * env.reward, rew)
+                done = torch.where(active, env.done, done)
+                intra = torch.where(active, torch.full_like(intra, k), intra)
+                alive = alive & ~(active & env.done.bool())      # `if done or ep_len >= max_step: break`
+        env.has_prev.zero_()                                     # env._reset_prev_state()
+        self.t += 1
+        del ar
+        return {"ob": prev_ob, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra, "is_planner": is_pl,
+                "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok}

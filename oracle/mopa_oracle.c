@@ -1360,6 +1360,8 @@ void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *
                   int32_t *ep_len, const double *action, int is_planner, int move, double *obs, double *reward,
                   uint8_t *done, uint8_t *success) {
     const int na = d->n_arm;
+    if (action && (move & 2)) return;   /* flags: bit 0 = arm moves, bit 1 = env sits this step out */
+    move &= 1;
     if (action) {
         for (int j = 0; j < na; j++) {
             const int adr = d->arm_qpos_idx[j];

@@ -1,0 +1,166 @@
+"""Batched rollout step (mopa_rl_amd/rollout.py) against a per-env scalar restatement of the
+reference loop (rl/mopa_rollouts.py:70-375 + rl/sac_agent.py:148-318) that runs entirely on the CPU oracle
+(validity, RRT-Connect, kinematic env).  Same actions, same RNG streams => every env must end every agent step in the
+same state with the same SMDP reward / done / intra_steps / counters, bit for bit."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ENV = "SawyerPushObstacle-v0"
+
+
+class _Cfg:
+    pass
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+class OrcAgent:
+    """PlannerAgent-like (rl/planner_agent.py:42-58 over sampling_based_planner.py:57-100) on the CPU oracle."""
+
+    def __init__(self, orc, range_, max_nodes, max_path, ids):
+        self.orc, self.range, self.max_nodes, self.max_path, self.ids = orc, range_, max_nodes, max_path, ids
+        self.seed, self.calls = 0, 0
+
+    def isValidState(self, q):
+        return bool(self.orc.is_valid(np.asarray(q, dtype=np.float64))[0])
+
+    def plan(self, start, goal, timelimit):
+        iters = max(1, int(round(timelimit * 2000)))
+        env_id = self.ids[min(self.calls, len(self.ids) - 1)]
+        self.calls += 1
+        st, path, _, _ = self.orc.plan(start, goal, self.range, max_iters=iters, max_nodes=self.max_nodes, seed=self.seed,
+                                       env_id=env_id, max_path=self.max_path)
+        if st != 0:
+            return np.full((1, len(start)), float(st)), False, st != -5, st != -4
+        tr = [np.asarray(start, dtype=np.float64)]
+        for s in range(1, len(path)):
+            tr.append(tr[-1] + (path[s] - path[s - 1]))
+        return np.array(tr[1:]), True, True, True
+
+
+def _scalar_agent(pi, facts, cfg, main, simple):
+    from mopa_rl_amd.agent_planning import PlanningMixin
+    from mopa_rl_amd.scene import qpos_joint_arrays
+
+    class Agent(PlanningMixin):
+        pass
+
+    a = Agent()
+    c = _Cfg()
+    for k in ("omega", "ac_space_type", "action_range", "timelimit", "simple_planner_timelimit", "interpolation", "joint_margin"):
+        setattr(c, k, getattr(cfg, k))
+    a._config, a._planner, a._simple_planner = c, main, simple
+    a._ref_joint_pos_indexes = list(facts.arm_qpos_idx)
+    a._jnt_indices, a._jnt_minimum, a._jnt_maximum, a._is_jnt_limited = qpos_joint_arrays(pi.model)
+    a._ac_low, a._ac_high = -1.0, 1.0
+    return a
+
+
+def _scalar_agent_step(e, E, t, ac, ref, agent, main, simple, cfg, counters):
+    """one iteration of the reference's `while not done` loop for env e (mopa_rollouts.py:70-375)"""
+    from mopa_rl_amd.agent_planning import clip_target_to_limits, handle_invalid_target
+    n = 7
+    main.seed = simple.seed = cfg.seed + t
+    main.calls = simple.calls = 0
+    main.ids, simple.ids = [e, 2 * E + e], [E + e]
+
+    def env_step(a, is_planner, flag):
+        acts = np.zeros((ref.E, n))
+        acts[e] = a
+        ref._call(e, acts, is_planner, flag)
+        return float(ref.reward[e]), int(ref.done[e])
+
+    curr = ref.qpos[e].copy()
+    if agent.is_planner_ac(ac):
+        disp = agent.convert2planner_displacement(ac[:n], cfg.ac_scale)
+        target = curr.copy()
+        target[:n] += disp
+        target = clip_target_to_limits(target, agent._jnt_minimum[agent._jnt_indices], agent._jnt_maximum[agent._jnt_indices],
+                                       agent._is_jnt_limited[agent._jnt_indices])
+        if cfg.invalid_target_handling and not agent.isValidState(target):
+            target, _ = handle_invalid_target(agent, curr, target, cfg.step_size, cfg.num_trials)[:2]
+        if agent.isValidState(target):
+            traj, success, interpolation, valid, exact = agent.plan(curr, target, ac_scale=cfg.ac_scale)
+        else:
+            success, valid, exact = False, False, True
+        if success:
+            counters["interpolation" if interpolation else "mp"][e] += 1
+            meta, done, intra = 0.0, 0, 0
+            for i, nxt in enumerate(traj):
+                r, done = env_step(nxt[:n] - ref.qpos[e, :n], True, 1)
+                meta += (cfg.discount_factor ** i) * r
+                intra = i
+                if done:
+                    break
+            out = (meta, done, intra)
+        else:
+            counters["mp_fail"][e] += 1
+            counters["approximate"][e] += int(not exact)
+            counters["invalid"][e] += int(not valid)
+            r, done = env_step(np.zeros(n), False, 0)
+            out = (r, done, 0)
+    else:
+        counters["rl"][e] += 1
+        r, done = env_step(ac[:n] / cfg.omega, False, 1)
+        out = (r, done, 0)
+    ref.has_prev[e] = 0
+    return out
+
+
+def test_batched_rollout_equals_scalar_oracle_rollout(oracle_mod):
+    import torch
+    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv, push_env_facts
+    from mopa_rl_amd.rollout import COUNTERS, BatchMoPARollout, RolloutConfig
+    from mopa_rl_amd.scene import planner_inputs
+    E, T = 96, 5
+    cfg = RolloutConfig(max_nodes=512, max_path=128, timelimit=0.15)       # 300 RRT iterations keep the CPU side quick
+    env = BatchKinematicPushEnv(E, seed=5, max_episode_steps=12)
+    env.reset()
+    ro = BatchMoPARollout(env, cfg)
+
+    pi = planner_inputs(ENV)
+    facts = push_env_facts(pi.model)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, cfg.contact_threshold)
+    ref = oracle_mod.OraclePushEnv(orc, facts, E, ac_scale=cfg.ac_scale, max_episode_steps=12)
+    ref.set_state(env.qpos.cpu().numpy())
+    main = OrcAgent(orc, cfg.range, cfg.max_nodes, cfg.max_path, [0])
+    simple = OrcAgent(orc, cfg.simple_planner_range, cfg.max_nodes, cfg.max_path, [0])
+    agent = _scalar_agent(pi, facts, cfg, main, simple)
+    counters = {k: np.zeros(E, dtype=np.int64) for k in COUNTERS}
+
+    rng = np.random.default_rng(0)
+    seen = {k: 0 for k in COUNTERS}
+    for t in range(T):
+        ac = rng.uniform(-1, 1, size=(E, 7)) * rng.choice([0.6, 0.9, 1.0], size=(E, 1))
+        if t == 2:      # far targets towards the table / bin: blocked straight lines and invalid targets
+            ac[: E // 2, 1] = 1.0
+            ac[: E // 2, 3] = -1.0
+        out = ro.agent_step(torch.tensor(ac, device=env.device))
+        want = [_scalar_agent_step(e, E, t, ac[e], ref, agent, main, simple, cfg, counters) for e in range(E)]
+        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(ref.qpos)), f"step {t}: qpos"
+        assert np.array_equal(_bits(out["rew"].cpu().numpy()), _bits(np.array([w[0] for w in want]))), f"step {t}: reward"
+        assert np.array_equal(out["done"].cpu().numpy(), np.array([w[1] for w in want])), f"step {t}: done"
+        assert np.array_equal(out["intra_steps"].cpu().numpy(), np.array([w[2] for w in want])), f"step {t}: intra_steps"
+        assert np.array_equal(env.ep_len.cpu().numpy(), ref.ep_len), f"step {t}: ep_len"
+        assert np.array_equal(_bits(out["ob_next"].cpu().numpy()), _bits(ref.obs)), f"step {t}: ob_next"
+        for k in COUNTERS:
+            assert np.array_equal(ro.counters[k].cpu().numpy(), counters[k]), f"step {t}: counter {k}"
+        # episodes that ended are reset on both sides to the same fresh state
+        d = out["done"].bool()
+        if bool(d.any()):
+            env.reset(d)
+            dm = d.cpu().numpy()
+            q = env.qpos.cpu().numpy()
+            ref.qpos[dm] = q[dm]
+            ref.ep_len[dm] = 0
+            ref.has_prev[dm] = 0
+            for e in np.where(dm)[0]:
+                ref._call(e, None, 0, 1)
+    for k in COUNTERS:
+        seen[k] = int(counters[k].sum())
+    # every branch of the loop was exercised
+    assert seen["rl"] > 0 and seen["interpolation"] > 0 and seen["mp"] > 0 and seen["mp_fail"] > 0 and seen["invalid"] > 0, seen

@@ -7,7 +7,7 @@ OUT=$R/gpurun_out/prof_$TAG
 WORK=/tmp/prof_$TAG
 rm -rf $WORK; mkdir -p $OUT $WORK
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu --no-plan --no-env --steps 5 --warmup 2"
+BENCH="python $R/bench.py --no-cpu --no-plan --no-env --no-rollout --steps 5 --warmup 2"
 run() {  # name, rocprof args...
   name=$1; shift
   rocprofv3 "$@" --output-format csv -d $WORK/$name -o $name -- $BENCH > $OUT/${name}_bench.log 2>&1

@@ -188,6 +188,35 @@ def rollout_section(torch, pi, E, device, agent_steps):
             "counters": c}
 
 
+def ik_section(torch, device, E=8192):
+    """BASELINE.json configs[4]'s IK piece: E damped-LS IK problems (env/inverse_kinematics.py:18-135 restated, K5) on
+    SawyerAssemblyObstacle: grip-site targets N(nominal, 0.15 m), max_steps 100, tol 1e-2 as the rollouts call it."""
+    from mopa_rl_amd.ik import BatchIK
+    from mopa_rl_amd.scene import ENV_SPECS, default_qpos, load_scene
+    env = "SawyerAssemblyObstacle-v0"
+    m = load_scene(ENV_SPECS[env].scene)
+    ik = BatchIK(m, "grip_site", ENV_SPECS[env].robot_joints, device=device.index if device.index is not None else -1)
+    g = torch.Generator(device=device)
+    g.manual_seed(0)
+    q0 = torch.tensor(default_qpos(env, m), device=device).repeat(E, 1)
+    q0[:, :7] += 0.2 * torch.randn(E, 7, generator=g, dtype=torch.float64, device=device)
+    tg = (torch.tensor([0.6, 0.0, 1.1], dtype=torch.float64, device=device)
+          + 0.15 * torch.randn(E, 3, generator=g, dtype=torch.float64, device=device)).contiguous()
+    for _ in range(2):
+        r = ik.solve(q0.clone(), tg, max_steps=100, tol=1e-2)
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = ik.solve(q0.clone(), tg, max_steps=100, tol=1e-2)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"config": f"{env}, {E} IK problems (7 joints, grip_site position target), max_steps 100, tol 1e-2",
+            "solves_per_s": E / dt, "ms_per_batch": dt * 1e3, "success_rate": float(r.success.float().mean().item()),
+            "mean_iterations": float((r.steps.float() + 1).mean().item()),
+            "iterations_per_s": float((r.steps.float() + 1).sum().item()) / dt}
+
+
 def cpu_baseline(pi, qa_host, rows_host, S, budget_states):
     """Oracle (oracle/mopa_oracle.c, kind="port") on the host cores, on the first `budget_states` states."""
     from oracle import oracle as O
@@ -319,6 +348,8 @@ def main():
             out["planner"] = plan_section(torch, bp, pi, args.plan_envs, device)
         if not args.no_env and world == 1:
             out["env_step"] = env_step_section(torch, pi, args.envs, device, 50, not args.no_cpu)
+        if not args.no_env and world == 1:
+            out["ik"] = ik_section(torch, device)
         if not args.no_rollout and world == 1:
             out["rollout"] = rollout_section(torch, pi, args.envs, device, 3)
         if not args.no_cpu and world == 1:

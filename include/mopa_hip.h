@@ -227,6 +227,35 @@ int mopa_env_desired_batch(MopaEnv *env, int64_t E, const double *qpos_dev /*[E,
                            const uint8_t *has_prev_dev /*[E]*/, const double *action_dev /*[E,n_arm]*/, int32_t is_planner,
                            double *desired_dev /*[E,n_arm]*/, void *stream);
 
+/* ======================================================================================================
+ *  batched damped-least-squares IK of a site position: replaces
+ * qpos_from_site_pose(env, site, target_pos, joint_names=..., max_steps, tol, ...)   env/inverse_kinematics.py:18-135
+ * with nullspace_method :274-281.  Per env and iteration:
+ *   err = target - site_xpos; success if |err| < tol;
+ *   J = d site_xpos / d q over the movable joints (hinge: axis x (p_site - anchor), slide: axis);
+ *   dq = (J^T J + regularization_strength I)^-1 J^T err   (always regularised, as the reference calls it, :113-115);
+ *   give up if |err| / |dq| > progress_thresh; |dq| capped at max_update_norm; qpos[movable] += dq.
+ * Position targets only (the reference's optional target_quat branch is not served).  The linear solve is an
+ * unpivoted Cholesky factorisation (the reference uses LAPACK LU through np.linalg.solve): equal to round-off.
+ * ====================================================================================================== */
+typedef struct MopaIkDesc {
+    MopaModel model;              /* body / joint arrays */
+    int32_t n_joints;             /* movable joints, 1..8 */
+    const int32_t *joint_ids;     /* [n_joints] model joint ids (hinge / slide, one per body) */
+    int32_t site_body;            /* body carrying the site */
+    double site_off[3];           /* site position in that body's frame */
+    int32_t device;               /* HIP device ordinal, -1 = current */
+} MopaIkDesc;
+
+typedef struct MopaIk MopaIk;
+
+int mopa_ik_create(const MopaIkDesc *desc, MopaIk **out);
+void mopa_ik_destroy(MopaIk *ik);
+/* E independent IK problems; qpos rows are updated in place (IKResult.qpos); err_norm / steps / success as IKResult. */
+int mopa_ik_solve_batch(MopaIk *ik, int64_t E, double *qpos_dev /*[E,nq] in/out*/, const double *target_pos_dev /*[E,3]*/,
+                        int32_t max_steps, double tol, double max_update_norm, double progress_thresh, double regularization_strength,
+                        double *err_norm_dev /*[E]*/, int32_t *steps_dev /*[E]*/, uint8_t *success_dev /*[E]*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

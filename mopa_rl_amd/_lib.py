@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_step_batch", "mopa_env_desired_batch",
+    "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch",
 ]
 
 
@@ -65,6 +66,11 @@ class MopaEnvDesc(C.Structure):
         ("ac_scale", C.c_double), ("distance_threshold", C.c_double), ("success_reward", C.c_double),
         ("max_episode_steps", C.c_int32), ("device", C.c_int32),
     ]
+
+
+class MopaIkDesc(C.Structure):
+    _fields_ = [("model", MopaModel), ("n_joints", C.c_int32), ("joint_ids", _ip), ("site_body", C.c_int32),
+                ("site_off", C.c_double * 3), ("device", C.c_int32)]
 
 
 class MopaPlanParams(C.Structure):
@@ -117,6 +123,10 @@ def lib() -> C.CDLL:
     L.mopa_env_destroy.restype = None
     L.mopa_env_step_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     L.mopa_env_desired_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp, vp]
+    L.mopa_ik_create.argtypes = [C.POINTER(MopaIkDesc), C.POINTER(vp)]
+    L.mopa_ik_destroy.argtypes = [vp]
+    L.mopa_ik_destroy.restype = None
+    L.mopa_ik_solve_batch.argtypes = [vp, C.c_int64, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp, vp]
     _lib = L
     return L
 

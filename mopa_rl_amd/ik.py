@@ -1,0 +1,91 @@
+"""Batched damped-least-squares IK -- mirrors reference env/inverse_kinematics.py:18-135
+(`qpos_from_site_pose`, position targets) on libmopa_hip.so (kernel K5 `k_ik_solve`, one lane per env).
+
+    ik = BatchIK(model, site="grip_site", joint_names=[...])
+    res = ik.solve(qpos, target_pos, max_steps=100, tol=1e-2)      # IKResult of GPU tensors; qpos updated in place
+
+`qpos_from_site_pose(model, qpos, site, target_pos, joint_names, ...)` is the single-problem form with the reference's
+argument names and return type (`IKResult(qpos, err_norm, steps, success)`); the reference passes a live env, here the
+compiled model and a qpos vector stand in for it.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import collections
+import ctypes as C
+from typing import Sequence
+
+import numpy as np
+
+from . import _lib
+from .batch import _ptr, _stream_handle, _torch
+
+IKResult = collections.namedtuple("IKResult", ["qpos", "err_norm", "steps", "success"])
+
+
+class BatchIK:
+    def __init__(self, model, site: str, joint_names: Sequence[str], device: int = -1):
+        L = _lib.lib()
+        self.model = model
+        si = model.site_name2id(site)
+        self.site_body = int(model.site_body[si])
+        self.site_off = np.asarray(model.site_pos[si], dtype=np.float64)
+        self.joint_ids = np.array([model.joint_name2id(j) for j in joint_names], dtype=np.int32)
+        keep = []
+        d = _lib.MopaIkDesc()
+        d.model = _lib.model_struct(model, keep)
+        ji, jp = _lib._i(self.joint_ids)
+        keep.append(ji)
+        d.n_joints, d.joint_ids = len(ji), jp
+        d.site_body, d.site_off, d.device = self.site_body, (C.c_double * 3)(*self.site_off), int(device)
+        h = C.c_void_p()
+        _lib.check(L.mopa_ik_create(C.byref(d), C.byref(h)))
+        self._h = h
+        self.nq = model.nq
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().mopa_ik_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def solve(self, qpos, target_pos, max_steps: int = 100, tol: float = 1e-14, max_update_norm: float = 2.0,
+              progress_thresh: float = 20.0, regularization_strength: float = 3e-2, stream=None) -> IKResult:
+        """qpos [E, nq] (updated in place), target_pos [E, 3]: contiguous float64 GPU tensors.  Defaults are the
+        reference's (inverse_kinematics.py:24-30); the rollouts call it with max_steps=100, tol=1e-2."""
+        torch = _torch()
+        for t, name, cols in ((qpos, "qpos", self.nq), (target_pos, "target_pos", 3)):
+            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.dim() != 2 or t.shape[1] != cols:
+                raise _lib.MopaError(f"{name} must be a contiguous float64 GPU tensor of shape [E, {cols}]")
+        E = qpos.shape[0]
+        if target_pos.shape[0] != E:
+            raise _lib.MopaError("qpos and target_pos disagree on E")
+        err = torch.zeros(E, dtype=torch.float64, device=qpos.device)
+        steps = torch.zeros(E, dtype=torch.int32, device=qpos.device)
+        succ = torch.zeros(E, dtype=torch.uint8, device=qpos.device)
+        _lib.check(_lib.lib().mopa_ik_solve_batch(self._h, E, _ptr(qpos), _ptr(target_pos), int(max_steps), float(tol),
+                                                  float(max_update_norm), float(progress_thresh), float(regularization_strength),
+                                                  _ptr(err), _ptr(steps), _ptr(succ), _stream_handle(stream)))
+        return IKResult(qpos=qpos, err_norm=err, steps=steps, success=succ)
+
+
+def qpos_from_site_pose(model, qpos, site, target_pos=None, target_quat=None, joint_names=None, max_steps=100, rot_weight=1.0,
+                        tol=1e-14, max_update_norm=2.0, progress_thresh=20.0, regularization_threshold=0.1,
+                        regularization_strength=3e-2) -> IKResult:
+    """Single problem, reference argument names (inverse_kinematics.py:18-31)."""
+    torch = _torch()
+    if target_quat is not None:
+        raise NotImplementedError("orientation targets (target_quat) are not served")
+    if target_pos is None:
+        raise ValueError("At least one of `target_pos` or `target_quat` must be specified")
+    if joint_names is None:
+        raise NotImplementedError("joint_names=None (all dofs) is not served: pass the movable joints")
+    ik = BatchIK(model, site, list(joint_names))
+    q = torch.tensor(np.asarray(qpos, dtype=np.float64)[None], device="cuda")
+    t = torch.tensor(np.asarray(target_pos, dtype=np.float64)[None], device="cuda")
+    r = ik.solve(q, t, max_steps, tol, max_update_norm, progress_thresh, regularization_strength)
+    return IKResult(qpos=r.qpos[0].cpu().numpy(), err_norm=float(r.err_norm[0]), steps=int(r.steps[0]), success=bool(r.success[0]))

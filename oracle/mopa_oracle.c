@@ -1429,3 +1429,98 @@ void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, doubl
                      action ? action + e * d->n_arm : NULL, is_planner, move_mask ? move_mask[e] : 1, obs + e * 40,
                      reward + e, done + e, success + e);
 }
+
+/* ------------------------------------------------------------------ */
+/*  damped-least-squares IK of a site position        */
+/* ------------------------------------------------------------------ */
+/* Restates reference env/inverse_kinematics.py:18-135 (`qpos_from_site_pose`, position target only) with
+ * `nullspace_method` :274-281: per iteration  err = target - site_xpos;  stop (success) if |err| < tol;
+ * J = site position Jacobian w.r.t. the movable joints ([3P] mj_jacSite: hinge column = axis x (p_site - anchor),
+ * slide column = axis);  dq = (J^T J + lambda I)^-1 J^T err  (the reference passes `regularization_strength`
+ * unconditionally, :113-115, so lambda is always on);  stop (failure) if |err| / |dq| > progress_thresh;
+ * |dq| capped at max_update_norm;  qpos[movable] += dq;  forward kinematics.
+ * The reference solves with np.linalg.solve (LAPACK LU); J^T J + lambda I is symmetric positive definite and this
+ * restatement uses an unpivoted Cholesky factorisation in a fixed operation order (shared with the HIP kernel). */
+#define ORC_IK_MAXJ 8
+
+static void ik_chol_solve(double H[ORC_IK_MAXJ][ORC_IK_MAXJ], const double *g, double *x) {
+    double L[ORC_IK_MAXJ][ORC_IK_MAXJ], y[ORC_IK_MAXJ];
+    for (int j = 0; j < ORC_IK_MAXJ; j++) {
+        double d = H[j][j];
+        for (int k = 0; k < j; k++) d = fma(-L[j][k], L[j][k], d);
+        L[j][j] = sqrt(d);
+        for (int i = j + 1; i < ORC_IK_MAXJ; i++) {
+            double s = H[i][j];
+            for (int k = 0; k < j; k++) s = fma(-L[i][k], L[j][k], s);
+            L[i][j] = s / L[j][j];
+        }
+    }
+    for (int i = 0; i < ORC_IK_MAXJ; i++) {
+        double s = g[i];
+        for (int k = 0; k < i; k++) s = fma(-L[i][k], y[k], s);
+        y[i] = s / L[i][i];
+    }
+    for (int i = ORC_IK_MAXJ - 1; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < ORC_IK_MAXJ; k++) s = fma(-L[k][i], x[k], s);
+        x[i] = s / L[i][i];
+    }
+}
+
+void orc_ik_solve(const OrcScene *s, int n_joints, const int32_t *joint_ids, int site_body, const double *site_off,
+                  double *qpos, const double *target_pos, int max_steps, double tol, double max_update_norm,
+                  double progress_thresh, double reg_strength, double *err_norm_out, int32_t *steps_out, uint8_t *success_out) {
+    double *buf = (double *)malloc(sizeof(double) * 16 * s->nbody);
+    double *xpos = buf, *xquat = buf + 3 * s->nbody, *xmat = buf + 7 * s->nbody;
+    double err_norm = 0.0;
+    int steps = 0, success = 0;
+    for (steps = 0; steps < max_steps; steps++) {
+        fk_bodies(s, qpos, xpos, xquat, xmat, 0);
+        double psite[3], err[3];
+        frame_pos(psite, xpos, xmat, site_body, site_off);
+        sub3(err, target_pos, psite);
+        err_norm = norm3(err);
+        if (err_norm < tol) { success = 1; break; }
+        double J[3][ORC_IK_MAXJ];
+        for (int k = 0; k < ORC_IK_MAXJ; k++) J[0][k] = J[1][k] = J[2][k] = 0.0;
+        for (int k = 0; k < n_joints; k++) {
+            const int j = joint_ids[k];
+            /* owning body and whether it is an ancestor (or the body) of the site's body */
+            int jb = -1;
+            for (int b = 0; b < s->nbody; b++)
+                if (j >= s->body_jntadr[b] && j < s->body_jntadr[b] + s->body_jntnum[b]) jb = b;
+            int on_chain = 0;
+            for (int b = site_body; b > 0; b = s->body_parent[b]) if (b == jb) on_chain = 1;
+            if (!on_chain) continue;
+            /* world axis / anchor of the joint.  For the joints of one body MuJoCo applies them in order; the
+             * supported robots carry one joint per body, for which axis and anchor follow from the body pose */
+            double axis[3], anchor[3], r[3], c[3];
+            mat_vec(axis, xmat + 9 * jb, s->jnt_axis + 3 * j);
+            frame_pos(anchor, xpos, xmat, jb, s->jnt_pos + 3 * j);
+            if (s->jnt_type[j] == J_SLIDE) { c[0] = axis[0]; c[1] = axis[1]; c[2] = axis[2]; }
+            else { sub3(r, psite, anchor); cross3(c, axis, r); }
+            J[0][k] = c[0]; J[1][k] = c[1]; J[2][k] = c[2];
+        }
+        double H[ORC_IK_MAXJ][ORC_IK_MAXJ], g[ORC_IK_MAXJ], x[ORC_IK_MAXJ];
+        for (int i = 0; i < ORC_IK_MAXJ; i++) {
+            for (int j2 = 0; j2 < ORC_IK_MAXJ; j2++)
+                H[i][j2] = fma(J[2][i], J[2][j2], fma(J[1][i], J[1][j2], J[0][i] * J[0][j2]));
+            H[i][i] = (i < n_joints) ? H[i][i] + reg_strength : 1.0;   /* padding rows: identity */
+            g[i] = fma(J[2][i], err[2], fma(J[1][i], err[1], J[0][i] * err[0]));
+        }
+        ik_chol_solve(H, g, x);
+        double un2 = 0.0;
+        for (int i = 0; i < n_joints; i++) un2 = fma(x[i], x[i], un2);
+        const double update_norm = sqrt(un2);
+        if (err_norm / update_norm > progress_thresh) break;
+        double sc = 1.0;
+        if (update_norm > max_update_norm) sc = max_update_norm / update_norm;
+        for (int k = 0; k < n_joints; k++) {
+            const int adr = s->jnt_qposadr[joint_ids[k]];
+            qpos[adr] = qpos[adr] + ((update_norm > max_update_norm) ? x[k] * sc : x[k]);
+        }
+    }
+    if (steps == max_steps) steps = max_steps - 1;   /* python: `for steps in range(max_steps)` leaves the last index */
+    *err_norm_out = err_norm; *steps_out = steps; *success_out = (uint8_t)success;
+    free(buf);
+}

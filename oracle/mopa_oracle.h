@@ -118,6 +118,12 @@ void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, doubl
                         int32_t *ep_len, const double *action, int is_planner, const uint8_t *move_mask, double *obs,
                         double *reward, uint8_t *done, uint8_t *success, int nthreads);
 
+/*  damped-LS IK of a site position, one env, in place on qpos -- see mopa_oracle.c */
+void orc_ik_solve(const OrcScene *s, int n_joints, const int32_t *joint_ids /*model joint ids, <= 8*/, int site_body,
+                  const double *site_off /*[3]*/, double *qpos /*[nq] in/out*/, const double *target_pos /*[3]*/, int max_steps,
+                  double tol, double max_update_norm, double progress_thresh, double reg_strength, double *err_norm_out,
+                  int32_t *steps_out, uint8_t *success_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,6 +77,9 @@ def lib():
         L.orc_env_step.restype = None
         L.orc_env_step.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), _dp, _dp, _u8p, _ip, _dp, C.c_int, C.c_int, _dp, _dp,
                                    _u8p, _u8p]
+        L.orc_ik_solve.restype = None
+        L.orc_ik_solve.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, _dp, _ip, _u8p]
         L.orc_env_step_batch.restype = None
         L.orc_env_step_batch.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), C.c_int64, _dp, _dp, _u8p, _ip, _dp, C.c_int, _u8p,
                                          _dp, _dp, _u8p, _u8p, C.c_int]
@@ -299,6 +302,17 @@ class OracleScene:
         valid = np.zeros(N, dtype=np.uint8)
         lib().orc_check_motion_batch(self._h, ap, bp, qep, N, spe, resolution, valid.ctypes.data_as(_u8p), nthreads)
         return valid
+
+    def ik_solve(self, qpos, target_pos, joint_ids, site_body, site_off, max_steps=100, tol=1e-2, max_update_norm=2.0,
+                 progress_thresh=20.0, reg_strength=3e-2):
+        """damped-LS IK (env/inverse_kinematics.py:18-135 restated); returns (qpos, err_norm, steps, success)"""
+        q = np.ascontiguousarray(qpos, dtype=np.float64).copy()
+        t, tp = _d(target_pos); ji, jp = _i(joint_ids); so, sp = _d(site_off)
+        en, st, su = C.c_double(0), C.c_int32(0), C.c_uint8(0)
+        lib().orc_ik_solve(self._h, len(ji), jp, int(site_body), sp, q.ctypes.data_as(_dp), tp, int(max_steps), float(tol),
+                           float(max_update_norm), float(progress_thresh), float(reg_strength), C.byref(en),
+                           C.byref(st), C.byref(su))
+        return q, en.value, st.value, bool(su.value)
 
     def plan(self, start, goal, range_: float, resolution: float = 0.005, max_iters: int = 2000,
              max_nodes: int = 4096, seed: int = 0, env_id: int = 0, max_path: int = 512):

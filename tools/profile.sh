@@ -17,6 +17,10 @@ run() {  # name, rocprof args...
   done
 }
 run trace --kernel-trace --stats
+# all kernels of the default bench (planner K3, env step K4, IK K5, rollout) in one kernel-trace pass
+BENCH_SAVE=$BENCH; BENCH="python $R/bench.py --no-cpu --steps 5 --warmup 2"
+run full --kernel-trace --stats
+BENCH=$BENCH_SAVE
 run pmc_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY
 run pmc_sq2 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE

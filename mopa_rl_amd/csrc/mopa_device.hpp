@@ -647,7 +647,15 @@ MOPA_HD double geom_dist(int code, const double *A, int ta, const double *B, int
         case PC_CAPSULE_CAPSULE: return d_capsule_capsule(A, B);
         case PC_CAPSULE_BOX: return d_capsule_box(A, B);
         case PC_BOX_BOX: return d_box_box(A, B);
-        case PC_CONVEX: return d_convex<false>(A, ta, B, tb);
+        case PC_CONVEX: {
+            // Pre-test before the portal refinement (by far the most expensive narrow-phase routine, and ~90 % of
+            // the cylinder pairs the broad phase lets through are in fact disjoint): a cylinder lies inside the capsule
+            // of the same axis, radius and half length, and capsule-capsule / capsule-box distances are closed form.
+            // Enclosures apart by more than 1e-9  =>  the shapes are disjoint  =>  what MPR would report.
+            const double pre = (tb == G_BOX) ? d_capsule_box(A, B) : d_capsule_capsule(A, B);
+            if (pre > 1e-9) return kFar;
+            return d_convex<false>(A, ta, B, tb);
+        }
         case PC_PLANE_MESH: return MESH ? d_plane_mesh(A, B, aux) : kFar;
         case PC_CONVEX_MESH: return MESH ? d_convex<MESH>(A, ta, B, tb, aux) : kFar;
         default: return kFar;

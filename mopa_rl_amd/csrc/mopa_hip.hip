@@ -175,8 +175,9 @@ MOPA_D bool pair_culled(const SceneHdr &h, const LdsView &v, int g1, int g2, con
 // Forward kinematics for the state whose joint values are in v.qbuf.
 // Lane l < nmg walks the ancestor chain of moving geom l (same operation order
 // as a parent-first sweep over the body tree) and writes the posed geom.
-MOPA_D void wave_fk(const SceneHdr &h, const LdsView &v, int lane) {
-    if (lane < h.nmg) {
+// fk_one_geom: the per-lane work for moving geom `lane` of the state in v.qbuf -> v.grec.
+MOPA_D void fk_one_geom(const SceneHdr &h, const LdsView &v, int lane) {
+    {
         const double *D = v.dbl;
         const int *I = v.ints;
         int g = I[h.o_mg_geom + lane];
@@ -233,6 +234,9 @@ MOPA_D void wave_fk(const SceneHdr &h, const LdsView &v, int lane) {
         const double *srec = D + h.o_g_rec + g * kGeomStride;
         rec[GO_SIZE] = srec[GO_SIZE]; rec[GO_SIZE + 1] = srec[GO_SIZE + 1]; rec[GO_SIZE + 2] = srec[GO_SIZE + 2];
     }
+}
+MOPA_D void wave_fk(const SceneHdr &h, const LdsView &v, int lane) {
+    if (lane < h.nmg) fk_one_geom(h, v, lane);
     wave_sync();
 }
 

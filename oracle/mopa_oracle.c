@@ -927,6 +927,15 @@ static double d_convex(const Geom *A, const Geom *B) {
     return ORC_FAR;
 }
 
+/* {capsule,cylinder}-cylinder and cylinder-box: closed-form pre-test on the enclosing capsules (a cylinder lies inside
+ * the capsule of the same axis, radius and half length) before the portal refinement; enclosures apart by more
+ * than 1e-9 => disjoint => what MPR reports for disjoint shapes.  Same rule in the kernels. */
+static double d_convex_cyl(const Geom *A, const Geom *B) {
+    const double pre = (B->type == G_BOX) ? d_capsule_box(A, B) : d_capsule_capsule(A, B);
+    if (pre > 1e-9) return ORC_FAR;
+    return d_convex(A, B);
+}
+
 static double geom_dist(const Geom *A, const Geom *B) {
     switch (A->type) {
         case G_PLANE:
@@ -950,15 +959,15 @@ static double geom_dist(const Geom *A, const Geom *B) {
         case G_CAPSULE:
             switch (B->type) {
                 case G_CAPSULE: return d_capsule_capsule(A, B);
-                case G_CYLINDER: return d_convex(A, B);
+                case G_CYLINDER: return d_convex_cyl(A, B);
                 case G_BOX: return d_capsule_box(A, B);
                 case G_MESH: return d_convex(A, B);
                 default: return ORC_FAR;
             }
         case G_CYLINDER:
             switch (B->type) {
-                case G_CYLINDER: return d_convex(A, B);
-                case G_BOX: return d_convex(A, B);
+                case G_CYLINDER: return d_convex_cyl(A, B);
+                case G_BOX: return d_convex_cyl(A, B);
                 case G_MESH: return d_convex(A, B);
                 default: return ORC_FAR;
             }

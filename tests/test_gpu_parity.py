@@ -380,3 +380,59 @@ def test_reference_api_end_to_end():
     if not agent.isValidState(bad):
         traj, success, valid, exact = agent.plan(q, bad)
         assert not success and not valid and traj.shape == (1, pi.model.nq) and np.all(traj == -5)
+
+
+def test_full_size_batch_properties(oracle_mod):
+    """BASELINE.json's full single-GPU size (4096 envs x 256 states = 1 048 576 checks, the bench workload) through
+    size-independent properties: (i) both K1 generations agree on every state, (ii) verdicts and depths are equivariant
+    under a permutation of the states within each env (no dependence on tile / lane / queue position),
+    (iii) a state checked as a zero-length motion gets the same verdict, (iv) a random 16k-state subset equals the
+    CPU oracle bit for bit."""
+    import torch
+    from bench import ENV, make_inputs
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(ENV)
+    E, S = 4096, 256
+    dev = torch.device("cuda:0")
+    qa, rows = make_inputs(torch, pi, E, S, 1234, dev)
+    sc2 = _scene_with_kernel("v2", pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+    sc1 = _scene_with_kernel("v1", pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+    bp2, bp1 = BatchPlanner(sc2), BatchPlanner(sc1)
+    v2, md2 = bp2.is_valid(qa, rows, samples_per_env=S, want_min_dist=True)
+    v2e = bp2.is_valid(qa, rows, samples_per_env=S)                      # early-out instantiation
+    v1, md1 = bp1.is_valid(qa, rows, samples_per_env=S, want_min_dist=True)
+    assert torch.equal(v1, v2) and torch.equal(v2, v2e)
+    assert torch.equal(md1.view(torch.int64), md2.view(torch.int64))
+    assert 0.2 < v2.float().mean().item() < 0.8
+    # (ii) permute the states inside every env
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    perm = torch.argsort(torch.rand(E, S, generator=g, device=dev), dim=1)
+    flat = (perm + torch.arange(E, device=dev)[:, None] * S).reshape(-1)
+    vp, mdp = bp2.is_valid(qa[flat].contiguous(), rows, samples_per_env=S, want_min_dist=True)
+    assert torch.equal(vp, v2[flat]) and torch.equal(mdp.view(torch.int64), md2[flat].view(torch.int64))
+    # (iii) zero-length motions
+    sub = slice(0, 65536)
+    mv = bp2.check_motion(qa[sub].contiguous(), qa[sub].contiguous(), rows, samples_per_env=S)
+    assert torch.equal(mv, v2[sub])
+    # (iv) oracle on a random subset
+    idx = torch.randperm(E * S, generator=g, device=dev)[:16384].sort().values
+    qh, rh = qa[idx].cpu().numpy(), rows.cpu().numpy()
+    ov = np.zeros(len(idx), dtype=np.uint8)
+    omd = np.zeros(len(idx))
+    envs = (idx // S).cpu().numpy()
+    for e in np.unique(envs):
+        m = envs == e
+        ov[m], omd[m] = orc_batch(oracle_mod, pi, qh[m], rh[e:e + 1])
+    assert np.array_equal(ov, v2[idx].cpu().numpy()) and np.array_equal(_bits(omd), _bits(md2[idx].cpu().numpy()))
+
+
+_ORC_CACHE = {}
+
+
+def orc_batch(oracle_mod, pi, qa, row):
+    key = pi.spec.env
+    if key not in _ORC_CACHE:
+        _ORC_CACHE[key] = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    return _ORC_CACHE[key].is_valid_batch(qa, row, samples_per_env=len(qa), nthreads=0)

@@ -327,12 +327,12 @@ def main():
             "valid_fraction": n_valid / N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_is_valid_v2<false>", "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
+                         "kernel": "k_is_valid_v5<false>", "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
                          "note": "path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see DESIGN.md"},
         }
         # HBM-side traffic of the same launch, from the committed rocprofv3 PMC passes (tools/profile.sh ->
-        # profiles/r01/k_is_valid_v2_traffic.json); it cannot be collected from inside this process.
-        tj = os.path.join(ROOT, "profiles", "r01", "k_is_valid_v2_traffic.json")
+        # profiles/r01/k_is_valid_v5_traffic.json); it cannot be collected from inside this process.
+        tj = os.path.join(ROOT, "profiles", "r01", "k_is_valid_v5_traffic.json")
         if os.path.exists(tj) and E * S == 1 << 20:
             t = json.load(open(tj))
             out["roofline"]["traffic"] = t["traffic_bytes_per_launch"]

@@ -81,6 +81,7 @@ struct MopaScene {
     SceneHdr hdr{};
     std::vector<double> h_dbl;
     std::vector<int32_t> h_int;
+    std::vector<int32_t> h_gp_tab;
     double *d_dbl = nullptr;
     int32_t *d_int = nullptr;
     int lds_bytes = 0;
@@ -103,6 +104,9 @@ struct MopaScene {
     size_t slab_waves = 0;
     int v2_lds_bytes = 0;
     int use_v2 = 1;
+    int32_t *d_gp_tab = nullptr;   // v5: FP32 broad-phase table [n_gp][8]
+    int v5_lds_bytes = 0;
+    int use_v5 = 0;
     bool v2_forced = false;   // MOPA_VALID_KERNEL=v2: lane-per-state kernel for every N >= 64 (tests, A/B runs)
 };
 
@@ -411,6 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_state(SceneHdr h, const double
 }
 
 #include "mopa_valid_v2.inc"
+#include "mopa_valid_v5.inc"
 
 // ---------------------------------------------------------------------------
 // host: scene compilation
@@ -703,6 +708,38 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         }
     }
 
+    // v5: FP32 broad-phase table, one 32-byte entry per (owner geom, partner) pair:
+    //   [0..2] partner centre (static partners) / a point of the plane, [3] partner bounding radius,
+    //   [4..6] world-AABB half extents of a static partner / the plane normal,
+    //   [7] flags: bits 0..13 = low bits of gp_word (partner gid, code, cur_is_g2, pmov), 14..21 partner slot, 30 plane
+    std::vector<int32_t> gp_tab(8 * gp_word.size(), 0);
+    int max_pnum = 0;
+    {
+        auto f2i = [](double x) { float f = (float)x; int32_t i; std::memcpy(&i, &f, 4); return i; };
+        for (int mslot = 0; mslot < nmg; mslot++) max_pnum = std::max(max_pnum, (int)mg_pnum[mslot]);
+        for (size_t p = 0; p < gp_word.size(); p++) {
+            const int w = gp_word[p];
+            const int pg = w & 0xff, pmov = (w >> 13) & 1;
+            int32_t *te = &gp_tab[8 * p];
+            te[3] = f2i(g_rbound[pg]);
+            int flags = w & 0x3fffff;    // gp_word already carries the slot in bits 14..21
+            if (!pmov) {
+                const double *rec = &g_rec[(size_t)kGeomStride * pg];
+                te[0] = f2i(rec[GO_POS]); te[1] = f2i(rec[GO_POS + 1]); te[2] = f2i(rec[GO_POS + 2]);
+                if (m.geom_type[pg] == G_PLANE) {
+                    te[4] = f2i(rec[GO_MAT + 2]); te[5] = f2i(rec[GO_MAT + 5]); te[6] = f2i(rec[GO_MAT + 8]);
+                    flags |= 1 << 30;
+                } else {
+                    double H[3];
+                    static_aabb_half(m.geom_type[pg], rec, g_rbound[pg], H);
+                    te[4] = f2i(H[0]); te[5] = f2i(H[1]); te[6] = f2i(H[2]);
+                }
+            }
+            te[7] = flags;
+        }
+    }
+    S->h_gp_tab = gp_tab;
+
     std::vector<int32_t> mbr(8 * (size_t)nmb, 0), mgr(4 * (size_t)nmg, 0);
     std::vector<double> mbd(16 * (size_t)nmb, 0.0), mgd(8 * (size_t)nmg, 0.0);
     for (int k = 0; k < nmb; k++) {
@@ -795,6 +832,10 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         const char *ev = std::getenv("MOPA_VALID_KERNEL");
         S->use_v2 = !(ev && std::string(ev) == "v1") && S->v2_lds_bytes <= 160 * 1024;
         S->v2_forced = ev && std::string(ev) == "v2";
+        S->v5_lds_bytes = h.n_dbl * 8 + ((h.n_int + 3) & ~3) * 4 + ((8 * (int)gp_word.size() + 3) & ~3) * 4 + kWavesPerBlock * v5_lds_per_wave(nmg);
+        // third generation (FP32 broad phase out of LDS): default wherever it applies; MOPA_VALID_KERNEL=v2 keeps the second
+        S->use_v5 = !(ev && std::string(ev) == "v2") && S->use_v2 && !h.has_mesh && max_pnum <= 64 && S->v5_lds_bytes <= 80 * 1024;
+        if (ev && std::string(ev) == "v5") S->v2_forced = true;   // "v5" also forces the lane-per-state path for every N >= 64
     }
 
     // --- device upload ---
@@ -814,6 +855,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     };
     hipError_t e1 = up((void **)&S->d_dbl, S->h_dbl.data(), S->h_dbl.size() * 8);
     hipError_t e2 = up((void **)&S->d_int, S->h_int.data(), S->h_int.size() * 4);
+    if (e2 == hipSuccess) e2 = up((void **)&S->d_gp_tab, S->h_gp_tab.data(), S->h_gp_tab.size() * 4);
     S->dbg_doubles = (size_t)kGeomStride * m.ngeom + pairs.size() + 8;
     hipError_t e3 = hipMalloc((void **)&S->d_q, sizeof(double) * (size_t)(m.nq + na + 8));
     hipError_t e4 = hipMalloc((void **)&S->d_valid, 8);
@@ -829,6 +871,8 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     for (const void *k : {(const void *)k_is_valid_v2<false, false>, (const void *)k_is_valid_v2<true, false>,
                           (const void *)k_is_valid_v2<false, true>, (const void *)k_is_valid_v2<true, true>})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, S->v2_lds_bytes);
+    for (const void *k : {(const void *)k_is_valid_v5<false>, (const void *)k_is_valid_v5<true>})
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, S->v5_lds_bytes);
     *out = S;
     return MOPA_OK;
 }
@@ -844,6 +888,7 @@ extern "C" void mopa_scene_destroy(MopaScene *S) {
     if (S->d_md) (void)hipFree(S->d_md);
     if (S->d_dbg) (void)hipFree(S->d_dbg);
     if (S->d_slab) (void)hipFree(S->d_slab);
+    if (S->d_gp_tab) (void)hipFree(S->d_gp_tab);
     delete S;
 }
 
@@ -891,11 +936,19 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
         double *d_tail = S->d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride;
         HIP_TRY(hipMemsetAsync(d_tail + 8, 0, 8, st));
 #ifdef MOPA_V2_PROFILE
-        unsigned long long *d_prof = (unsigned long long *)(S->d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride);
+        unsigned long long *d_prof = (unsigned long long *)d_tail;
         (void)hipMemsetAsync(d_prof, 0, 6 * 8, st);
 #endif
         auto kern = S->hdr.has_mesh ? (min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>)
                                     : (min_dist ? k_is_valid_v2<true, false> : k_is_valid_v2<false, false>);
+        if (S->use_v5) {
+            if (min_dist)
+                hipLaunchKernelGGL(k_is_valid_v5<true>, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active,
+                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab);
+            else
+                hipLaunchKernelGGL(k_is_valid_v5<false>, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active,
+                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab);
+        } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
                            (long long)samples_per_env, valid, min_dist, S->d_slab);
         HIP_TRY(hipGetLastError());

@@ -13,7 +13,7 @@ from conftest import SUPPORTED_ENVS, sample_states
 pytestmark = pytest.mark.gpu
 
 
-KERNELS = ["v1", "v2"]   # K1 generations: wave-per-state / lane-per-state (the library picks by batch size)
+KERNELS = ["v1", "v2", "v5"]   # K1 generations: wave-per-state / lane-per-state (the library picks by batch size)
 
 
 def _scene_with_kernel(kernel, *args, **kw):

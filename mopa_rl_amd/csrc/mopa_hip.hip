@@ -65,6 +65,7 @@ struct SceneHdr {
     int o_mg_geom, o_chain_adr, o_chain_len, o_chain_items, o_pairs, o_pq_adr, o_act_adr, o_act_so2;
     // second-generation validity kernel (mopa_valid_v2.inc): DFS program + per-geom pair lists
     int n_save, n_gp;
+    int v5_ent_cap;   // k_is_valid_v5: survivor-entry buffer capacity per wave
     int o_mesh, has_mesh;   // mesh hull vertices (doubles); has_mesh selects the MESH kernel instantiations
     int o_mb_load, o_mb_save, o_mb_mgadr, o_mb_mgnum, o_mg_padr, o_mg_pnum, o_mg_store, o_gp_word;
     int o_mbr, o_mbd, o_mgr, o_mgd;   // packed per-body / per-geom records (ints: 8 / 4, doubles: 16 / 8)
@@ -79,6 +80,8 @@ constexpr int kBlock = 64 * kWavesPerBlock;
 struct MopaScene {
     int device = 0;
     SceneHdr hdr{};
+    SceneHdr hdr_mesh{};      // same scene, per-geom pair lists = the mesh pairs only (second pass of the lane-per-state kernels)
+    int n_mesh_gp = 0;
     std::vector<double> h_dbl;
     std::vector<int32_t> h_int;
     std::vector<int32_t> h_gp_tab;
@@ -686,27 +689,36 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     }
     for (int k = 1; k < nmb; k++)   // slots must follow body order for the "earlier partner" rule
         if (mb_mgnum[k] && mb_mgnum[k - 1] && mb_mgadr[k] < mb_mgadr[k - 1]) { delete S; return fail(MOPA_ERR_UNSUPPORTED, "geom order does not follow body order"); }
-    std::vector<int32_t> mg_padr(nmg, 0), mg_pnum(nmg, 0), mg_store(nmg, 0), gp_word;
-    {
+    // Per-owner-geom pair lists for the lane-per-state kernels.  Pairs whose class involves a mesh are kept in a list
+    // of their own: the main pass (k_is_valid_v5 / v2) then carries no mesh code at all, and a second, light pass of
+    // the MESH instantiation handles the handful of mesh pairs and folds its verdict into the first one's.
+    std::vector<int32_t> mg_store(nmg, 0);
+    auto build_lists = [&](bool want_mesh, std::vector<int32_t> &padr, std::vector<int32_t> &pnum, std::vector<int32_t> &words) {
+        padr.assign(nmg, 0); pnum.assign(nmg, 0); words.clear();
         std::vector<std::vector<PairE>> own(nmg);
         for (const PairE &e : pairs) {   // already sorted by cost class
+            const bool is_mesh = (e.code == PC_PLANE_MESH || e.code == PC_CONVEX_MESH);
+            if (is_mesh != want_mesh) continue;
             int s1 = g_slot[e.g1], s2 = g_slot[e.g2];
             int owner = (s2 > s1) ? s2 : s1;
             own[owner].push_back(e);
         }
         for (int mslot = 0; mslot < nmg; mslot++) {
-            mg_padr[mslot] = (int)gp_word.size();
-            mg_pnum[mslot] = (int)own[mslot].size();
+            padr[mslot] = (int)words.size();
+            pnum[mslot] = (int)own[mslot].size();
             for (const PairE &e : own[mslot]) {
                 int cur = mg_geom[mslot];
                 int cur_is_g2 = (e.g2 == cur) ? 1 : 0;
                 int partner = cur_is_g2 ? e.g1 : e.g2;
                 int pslot = g_slot[partner];
                 if (pslot >= 0) mg_store[pslot] = 1;
-                gp_word.push_back(partner | (e.code << 8) | (cur_is_g2 << 12) | ((pslot >= 0 ? 1 : 0) << 13) | ((pslot >= 0 ? pslot : 0) << 14));
+                words.push_back(partner | (e.code << 8) | (cur_is_g2 << 12) | ((pslot >= 0 ? 1 : 0) << 13) | ((pslot >= 0 ? pslot : 0) << 14));
             }
         }
-    }
+    };
+    std::vector<int32_t> mg_padr, mg_pnum, gp_word, mg_padr_mesh, mg_pnum_mesh, gp_word_mesh;
+    build_lists(false, mg_padr, mg_pnum, gp_word);
+    build_lists(true, mg_padr_mesh, mg_pnum_mesh, gp_word_mesh);
 
     // v5: FP32 broad-phase table, one 32-byte entry per (owner geom, partner) pair:
     //   [0..2] partner centre (static partners) / a point of the plane, [3] partner bounding radius,
@@ -740,7 +752,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     }
     S->h_gp_tab = gp_tab;
 
-    std::vector<int32_t> mbr(8 * (size_t)nmb, 0), mgr(4 * (size_t)nmg, 0);
+    std::vector<int32_t> mbr(8 * (size_t)nmb, 0), mgr(4 * (size_t)nmg, 0), mgr_mesh(4 * (size_t)nmg, 0);
     std::vector<double> mbd(16 * (size_t)nmb, 0.0), mgd(8 * (size_t)nmg, 0.0);
     for (int k = 0; k < nmb; k++) {
         int ja = mb_jntadr[k], jn = mb_jntnum[k];
@@ -763,6 +775,8 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         int g = mg_geom[ms];
         int32_t *r = &mgr[4 * (size_t)ms];
         r[0] = g; r[1] = mg_store[ms] | ((m.geom_type[g] == G_BOX ? 1 : 0) << 1); r[2] = mg_padr[ms]; r[3] = mg_pnum[ms];
+        int32_t *rm = &mgr_mesh[4 * (size_t)ms];
+        rm[0] = r[0]; rm[1] = r[1]; rm[2] = mg_padr_mesh[ms]; rm[3] = mg_pnum_mesh[ms];
         double *d = &mgd[8 * (size_t)ms];
         std::memcpy(d, &g_lpos[3 * (size_t)g], 24);
         std::memcpy(d + 3, &g_lquat[4 * (size_t)g], 32);
@@ -815,6 +829,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.o_mg_padr = B.add_i(mg_padr); h.o_mg_pnum = B.add_i(mg_pnum); h.o_mg_store = B.add_i(mg_store); h.o_gp_word = B.add_i(gp_word);
     while (B.ints.size() & 7) B.ints.push_back(0);   // 32-byte align the packed records (scalar dwordx8 loads)
     h.o_mbr = B.add_i(mbr); h.o_mgr = B.add_i(mgr);
+    const int o_mgr_mesh = B.add_i(mgr_mesh), o_gp_word_mesh = B.add_i(gp_word_mesh);
     h.n_dbl = (int)B.dbl.size();
     h.n_int = (int)B.ints.size();
     h.wave_dbl = nmg * kGeomStride + na + n_pq + na;   // geom records, joint values, one spare state vector
@@ -832,11 +847,30 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         const char *ev = std::getenv("MOPA_VALID_KERNEL");
         S->use_v2 = !(ev && std::string(ev) == "v1") && S->v2_lds_bytes <= 160 * 1024;
         S->v2_forced = ev && std::string(ev) == "v2";
-        S->v5_lds_bytes = h.n_dbl * 8 + ((h.n_int + 3) & ~3) * 4 + ((8 * (int)gp_word.size() + 3) & ~3) * 4 + kWavesPerBlock * v5_lds_per_wave(nmg);
+        {
+            // largest entry buffer (multiple of 64, 256..1024) that still lets two workgroups share a CU's 160 KiB of LDS
+            const int fixed = h.n_dbl * 8 + ((h.n_int + 3) & ~3) * 4 + ((8 * (int)gp_word.size() + 3) & ~3) * 4;
+            int cap = kEntCapV5Max;
+            while (cap > 256 && fixed + kWavesPerBlock * v5_lds_per_wave(nmg, cap) > 80 * 1024) cap -= 64;
+            if (fixed + kWavesPerBlock * v5_lds_per_wave(nmg, cap) > 80 * 1024) cap = 768;   // one workgroup per CU anyway
+            h.v5_ent_cap = cap;
+            S->v5_lds_bytes = fixed + kWavesPerBlock * v5_lds_per_wave(nmg, cap);
+            if (std::getenv("MOPA_DEBUG"))
+                fprintf(stderr, "[mopa] scene: nmg %d nmb %d pairs %d (+%d mesh) lds: wave-per-state %d, v2 %d, v5 %d (entry cap %d, fixed %d)\n", nmg, nmb,
+                        (int)gp_word.size(), (int)gp_word_mesh.size(), S->lds_bytes, S->v2_lds_bytes, S->v5_lds_bytes, cap, fixed);
+        }
         // third generation (FP32 broad phase out of LDS): default wherever it applies; MOPA_VALID_KERNEL=v2 keeps the second
-        S->use_v5 = !(ev && std::string(ev) == "v2") && S->use_v2 && !h.has_mesh && max_pnum <= 64 && S->v5_lds_bytes <= 80 * 1024;
+        // ... unless it would get one workgroup per CU where the second generation still gets two (LDS: the FP32 centre
+        // table grows with the number of moving geoms; SawyerLift: 19 of them)
+        const bool v5_fits2 = S->v5_lds_bytes <= 80 * 1024, v2_fits2 = S->v2_lds_bytes <= 80 * 1024;
+        S->use_v5 = !(ev && std::string(ev) == "v2") && S->use_v2 && max_pnum <= 64 && S->v5_lds_bytes <= 160 * 1024 &&
+                    (v5_fits2 || !v2_fits2 || (ev && std::string(ev) == "v5"));
         if (ev && std::string(ev) == "v5") S->v2_forced = true;   // "v5" also forces the lane-per-state path for every N >= 64
     }
+
+    S->hdr_mesh = h;
+    S->hdr_mesh.o_mgr = o_mgr_mesh; S->hdr_mesh.o_gp_word = o_gp_word_mesh; S->hdr_mesh.n_gp = (int)gp_word_mesh.size();
+    S->n_mesh_gp = (int)gp_word_mesh.size();
 
     // --- device upload ---
     int ndev = mopa_device_count();
@@ -939,8 +973,7 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
         unsigned long long *d_prof = (unsigned long long *)d_tail;
         (void)hipMemsetAsync(d_prof, 0, 6 * 8, st);
 #endif
-        auto kern = S->hdr.has_mesh ? (min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>)
-                                    : (min_dist ? k_is_valid_v2<true, false> : k_is_valid_v2<false, false>);
+        auto kern = min_dist ? k_is_valid_v2<true, false> : k_is_valid_v2<false, false>;   // main lists carry no mesh pair
         if (S->use_v5) {
             if (min_dist)
                 hipLaunchKernelGGL(k_is_valid_v5<true>, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active,
@@ -950,7 +983,14 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
                                    qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab);
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                           (long long)samples_per_env, valid, min_dist, S->d_slab);
+                           (long long)samples_per_env, valid, min_dist, S->d_slab, 0);
+        if (S->n_mesh_gp > 0) {
+            // second pass: the mesh pairs only (MESH instantiation), verdict AND-ed / depth min-ed into the first pass's
+            HIP_TRY(hipMemsetAsync(d_tail + 8, 0, 8, st));
+            auto km = min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>;
+            hipLaunchKernelGGL(km, grid, block, S->v2_lds_bytes, st, S->hdr_mesh, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
+                               (long long)samples_per_env, valid, min_dist, S->d_slab, 1);
+        }
         HIP_TRY(hipGetLastError());
 #ifdef MOPA_V2_PROFILE
         {

@@ -143,13 +143,13 @@ MOPA_HD void mopa_sincos(double x, double &sout, double &cout) {
 // jnt_pos is exactly zero -- every joint of the reference's robots: it is then the identity (up to the sign of a
 // zero) and costs two quat->matrix conversions per body.  The CPU checker makes the same choice, so results stay
 // bit-identical.  `anchor_zero` must be `jp == (0,0,0)`.
-MOPA_HD void apply_joint(int jt, V3 ax, V3 jp, bool anchor_zero, double dq, V3 &pos, Q4 &quat) {
+// (sn, cs) = sin / cos of half the hinge angle, computed by the caller (mopa_sincos(0.5 * dq)): the wave-per-state
+// path evaluates them for all joints of a state in parallel lanes before the serial walk down the kinematic chain
+MOPA_HD void apply_joint_sc(int jt, V3 ax, V3 jp, bool anchor_zero, double dq, double sn, double cs, V3 &pos, Q4 &quat) {
     if (jt == J_SLIDE) {
         const V3 xaxis = rot_vec_quat(ax, quat);
         pos = addscl3(pos, xaxis, dq);
     } else if (jt == J_HINGE) {
-        double sn, cs;
-        mopa_sincos(0.5 * dq, sn, cs);
         const Q4 ql{cs, ax.x * sn, ax.y * sn, ax.z * sn};
         if (anchor_zero) {
             quat = quat_mul(quat, ql);
@@ -160,6 +160,11 @@ MOPA_HD void apply_joint(int jt, V3 ax, V3 jp, bool anchor_zero, double dq, V3 &
             pos = sub3(xanchor, vec);
         }
     }
+}
+MOPA_HD void apply_joint(int jt, V3 ax, V3 jp, bool anchor_zero, double dq, V3 &pos, Q4 &quat) {
+    double sn = 0.0, cs = 1.0;
+    if (jt == J_HINGE) mopa_sincos(0.5 * dq, sn, cs);
+    apply_joint_sc(jt, ax, jp, anchor_zero, dq, sn, cs, pos, quat);
 }
 MOPA_HD bool is_zero3(V3 v) { return v.x == 0.0 && v.y == 0.0 && v.z == 0.0; }
 

@@ -136,6 +136,7 @@ struct LdsView {
     const int *ints;     // shared scene ints
     double *grec;        // per-wave posed records of moving geoms [nmg*kGeomStride]
     double *qbuf;        // per-wave joint values: [na active][n_pq passive]
+    double *sc;          // per-wave [nmj][2]: sin, cos of half the angle of every moving hinge joint of the state in qbuf
     unsigned short *wl;  // per-wave worklist [npair]
 };
 
@@ -155,7 +156,8 @@ MOPA_D LdsView make_view(const SceneHdr &h, unsigned char *smem) {
     v.ints = s_int;
     v.grec = reinterpret_cast<double *>(wave_base);
     v.qbuf = v.grec + h.nmg * kGeomStride;
-    v.wl = reinterpret_cast<unsigned short *>(v.qbuf + h.na + h.n_pq + h.na);
+    v.sc = v.qbuf + h.na + h.n_pq + h.na;
+    v.wl = reinterpret_cast<unsigned short *>(v.sc + 2 * h.nmj);
     return v;
 }
 
@@ -222,7 +224,7 @@ MOPA_D void fk_one_geom(const SceneHdr &h, const LdsView &v, int lane) {
                 for (int j = ja; j < ja + jn; j++) {
                     V3 ax = ld3(D + h.o_mj_axis + 3 * j), jp = ld3(D + h.o_mj_pos + 3 * j);
                     double dq = v.qbuf[I[h.o_mj_qsrc + j]] - D[h.o_mj_ref + j];
-                    apply_joint(I[h.o_mj_type + j], ax, jp, is_zero3(jp), dq, pos, quat);
+                    apply_joint_sc(I[h.o_mj_type + j], ax, jp, is_zero3(jp), dq, v.sc[2 * j], v.sc[2 * j + 1], pos, quat);
                 }
                 quat = quat_normalize(quat);
             }
@@ -293,6 +295,18 @@ MOPA_D bool wave_collide(const SceneHdr &h, const LdsView &v, int lane, double &
     return !any_bad;
 }
 
+// sin/cos of half the joint angle for every moving hinge joint of the state in v.qbuf, one joint per lane: taken out of
+// the serial walk down the kinematic chain (it is ~half of a body's critical path there).  Same arithmetic.
+MOPA_D void wave_sincos_table(const SceneHdr &h, const LdsView &v, int lane) {
+    for (int j = lane; j < h.nmj; j += 64) {
+        double sn = 0.0, cs = 1.0;
+        if (v.ints[h.o_mj_type + j] == J_HINGE) mopa_sincos(0.5 * (v.qbuf[v.ints[h.o_mj_qsrc + j]] - v.dbl[h.o_mj_ref + j]), sn, cs);
+        v.sc[2 * j] = sn;
+        v.sc[2 * j + 1] = cs;
+    }
+    wave_sync();
+}
+
 // fill v.qbuf for (env row, active vector)
 MOPA_D void wave_load_state(const SceneHdr &h, const LdsView &v, int lane, const double *q_active, const double *qpos_row) {
     if (lane < h.na) v.qbuf[lane] = q_active[lane];
@@ -301,6 +315,7 @@ MOPA_D void wave_load_state(const SceneHdr &h, const LdsView &v, int lane, const
     for (int i = lane + 64; i < h.na + h.n_pq; i += 64)
         v.qbuf[i] = (i < h.na) ? q_active[i] : qpos_row[v.ints[h.o_pq_adr + i - h.na]];
     wave_sync();
+    wave_sincos_table(h, v, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -832,7 +847,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     const int o_mgr_mesh = B.add_i(mgr_mesh), o_gp_word_mesh = B.add_i(gp_word_mesh);
     h.n_dbl = (int)B.dbl.size();
     h.n_int = (int)B.ints.size();
-    h.wave_dbl = nmg * kGeomStride + na + n_pq + na;   // geom records, joint values, one spare state vector
+    h.wave_dbl = nmg * kGeomStride + na + n_pq + na + 2 * nmj;   // geom records, joint values, one spare state vector, sin/cos table
     int wl_bytes = (int)((pairs.size() * 2 + 15) & ~size_t(15));
     h.wave_bytes = ((h.wave_dbl * 8 + wl_bytes) + 15) & ~15;
     h.thr = desc->contact_threshold;

@@ -10,9 +10,9 @@ the SMDP reward `sum_i gamma^i r_i` and `intra_steps` are accumulated (:152-199)
 the current reward (:303-334).  Counters `mp / rl / interpolation / mp_fail / approximate / invalid` are kept per env.
 
 Restrictions (each raises): joint-space MoPA-SAC only (`use_ik_target=False`, `discrete_action=False`), Sawyer push
-(no unlimited joints, 7-dof actions).  `reuse_data` relabelling (:204-300) is host-side replay-buffer work on the
-returned waypoint rewards and is not part of this step.  The env is the KINEMATIC one (kinematic_env.py) -- not
-dynamics parity.
+(no unlimited joints, 7-dof actions).  The `reuse_data` relabelling (:204-300) -- extra transitions between random
+pairs of waypoints of an executed path -- is `reuse_transitions()` below, fed by `agent_step(..., record=True)`.
+The env is the KINEMATIC one (kinematic_env.py) -- not dynamics parity.
 
 Where the work runs: every validity check (targets, pull-back, interpolated states, densification) and every
 RRT-Connect query is one batched GPU launch over all envs that need it; env steps are one K4 launch per waypoint index.
@@ -59,6 +59,50 @@ class RolloutConfig:
     max_nodes: int = 1024
     max_path: int = 256
     seed: int = 1234
+
+
+def invert_displacement_np(displacement, ac_scale, cfg):
+    """rl/sac_agent.py:177-196 (numpy, as the host-side relabelling uses it)"""
+    if cfg.ac_space_type == "normal":
+        return displacement / cfg.action_range
+    om = cfg.omega
+    return np.where(np.abs(displacement) < ac_scale, displacement * (om / ac_scale),
+                    np.sign(displacement) * ((np.abs(displacement) - ac_scale) / ((cfg.action_range - ac_scale) / (1.0 - ac_scale))
+                                             / ((1.0 - ac_scale) / (1.0 - om)) + om))
+
+
+def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30):
+    """The `reuse_data` relabelling of rl/mopa_rollouts.py:204-300 on the record of one `agent_step(..., record=True)`:
+    for every env that executed a planner path with more than 3 waypoints, up to min(len, max_reuse_data) random
+    (start, goal) waypoint pairs become extra transitions  ob_list[start] --inverse-displacement action--> ob_list[goal]
+    with reward (meta_rew[goal] - meta_rew[start]) * gamma^-(start+1), done = done_list[goal],
+    intra_steps = goal - start - 1, kept only if the relabelled action is a planner action inside [-1, 1].
+    `rng` is a numpy RandomState-like object (`randint(low, high)`); the reference draws from the global np.random.
+    Returns a list of dicts (env, start, goal, ob, ac, rew, done, intra_steps, ob_next) of numpy values."""
+    rec = out["record"]
+    ob, mr, dn, wp = (rec[k].cpu().numpy() for k in ("ob", "meta_rew", "done", "waypoint"))
+    nexec = rec["n_exec"].cpu().numpy()
+    extra = []
+    for e in np.where(nexec > 3)[0]:
+        L = int(nexec[e])
+        pairs = []
+        for _ in range(min(L, max_reuse_data)):
+            start = rng.randint(low=0, high=L - 1)
+            if start + 1 > L - 1:
+                continue
+            goal = rng.randint(low=start + 1, high=L)
+            if (start, goal) in pairs:
+                continue
+            pairs.append((start, goal))
+            ac = invert_displacement_np(wp[e, goal, :n_arm] - wp[e, start, :n_arm], cfg.ac_scale, cfg)   # env.form_action(traj[goal], traj[start])
+            if not (np.any(ac < -cfg.omega) or np.any(ac > cfg.omega)):      # pi.is_planner_ac
+                continue
+            if not (np.all(ac >= -1.0) and np.all(ac <= 1.0)):               # pi.valid_action
+                continue
+            rew = (mr[e, goal] - mr[e, start]) * cfg.discount_factor ** (-(start + 1))
+            extra.append({"env": int(e), "start": start, "goal": goal, "ob": ob[e, start], "ac": ac, "rew": float(rew),
+                          "done": int(dn[e, goal]), "intra_steps": goal - start - 1, "ob_next": ob[e, goal]})
+    return extra
 
 
 def convert2planner_displacement(ac, ac_scale, cfg):
@@ -228,10 +272,13 @@ class BatchMoPARollout:
             trajs[m] = np.array(new)
 
     # ------------------------------------------------------------------
-    def agent_step(self, ac):
+    def agent_step(self, ac, record: bool = False):
         """One agent step for all E envs.  ac: float64 [E, >=7] GPU tensor (policy output in [-1, 1]).
         Returns a dict of GPU tensors: ob [E,40] (before), ob_next [E,40], rew [E] (SMDP return of the step), done [E]
-        uint8, intra_steps [E] int64, is_planner [E] bool, success [E] bool (env success flag), plus `path_len`."""
+        uint8, intra_steps [E] int64, is_planner [E] bool, success [E] bool (env success flag), plus `path_len`.
+        record=True adds `record`: per executed waypoint k the obs after it, the running SMDP return, the done flag and
+        the waypoint itself ([E, L, ...]; `n_exec` [E] = waypoints actually executed) -- the `ob_list / meta_rew_list /
+        done_list / traj` of the reference, input of `reuse_transitions`."""
         torch = _torch()
         env, cfg, E, n = self.env, self.cfg, self.E, self.n
         dev = env.device
@@ -289,6 +336,14 @@ class BatchMoPARollout:
         done = torch.where(plan_ok, torch.zeros_like(env.done), env.done)
         intra = torch.zeros(E, dtype=torch.int64, device=dev)
         # ---- waypoint execution (:152-199)
+        rec = None
+        if record:
+            Lr = traj_pad.shape[1] if traj_pad is not None else 0
+            rec = {"ob": torch.zeros(E, Lr, env.obs.shape[1], dtype=torch.float64, device=dev),
+                   "meta_rew": torch.zeros(E, Lr, dtype=torch.float64, device=dev),
+                   "done": torch.zeros(E, Lr, dtype=torch.uint8, device=dev),
+                   "waypoint": traj_pad if traj_pad is not None else torch.zeros(E, 0, self.nq, dtype=torch.float64, device=dev),
+                   "n_exec": torch.zeros(E, dtype=torch.int64, device=dev)}
         if traj_pad is not None:
             alive = plan_ok.clone()
             for k in range(traj_pad.shape[1]):
@@ -300,9 +355,17 @@ class BatchMoPARollout:
                 rew = torch.where(active, rew + (cfg.discount_factor ** k) * env.reward, rew)
                 done = torch.where(active, env.done, done)
                 intra = torch.where(active, torch.full_like(intra, k), intra)
+                if rec is not None:
+                    rec["ob"][:, k] = torch.where(active[:, None], env.obs, rec["ob"][:, k])
+                    rec["meta_rew"][:, k] = torch.where(active, rew, rec["meta_rew"][:, k])
+                    rec["done"][:, k] = torch.where(active, env.done, rec["done"][:, k])
+                    rec["n_exec"] += active.to(torch.int64)
                 alive = alive & ~(active & env.done.bool())      # `if done or ep_len >= max_step: break`
         env.has_prev.zero_()                                     # env._reset_prev_state()
         self.t += 1
         del ar
-        return {"ob": prev_ob, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra, "is_planner": is_pl,
-                "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok}
+        res = {"ob": prev_ob, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra, "is_planner": is_pl,
+               "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok}
+        if rec is not None:
+            res["record"] = rec
+        return res

@@ -164,3 +164,50 @@ def test_batched_rollout_equals_scalar_oracle_rollout(oracle_mod):
         seen[k] = int(counters[k].sum())
     # every branch of the loop was exercised
     assert seen["rl"] > 0 and seen["interpolation"] > 0 and seen["mp"] > 0 and seen["mp_fail"] > 0 and seen["invalid"] > 0, seen
+
+
+def test_reuse_data_relabelling(oracle_mod):
+    """`reuse_transitions` (rl/mopa_rollouts.py:204-300) on a recorded step: same random draws => the same relabelled
+    transitions as a direct transcription of the reference loop over the recorded lists; rewards telescope correctly."""
+    import torch
+    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig, invert_displacement_np, reuse_transitions
+    E = 64
+    cfg = RolloutConfig(max_nodes=512, max_path=128, timelimit=0.15)
+    env = BatchKinematicPushEnv(E, seed=9)
+    env.reset()
+    ro = BatchMoPARollout(env, cfg)
+    rng = np.random.default_rng(1)
+    ac = rng.uniform(-1, 1, size=(E, 7))
+    ac[:, 0] = np.sign(ac[:, 0]) * rng.uniform(0.85, 1.0, E)          # far targets: long interpolated paths
+    out = ro.agent_step(torch.tensor(ac, device=env.device), record=True)
+    rec = out["record"]
+    nexec = rec["n_exec"].cpu().numpy()
+    assert np.array_equal(nexec, np.where(out["plan_ok"].cpu().numpy(), out["intra_steps"].cpu().numpy() + 1, 0))
+    assert (nexec > 3).sum() > 10
+    # the last recorded waypoint carries the step's SMDP return and final obs
+    idx = torch.nonzero(out["plan_ok"]).flatten()
+    last = rec["n_exec"][idx] - 1
+    assert torch.equal(rec["meta_rew"][idx, last].view(torch.int64), out["rew"][idx].view(torch.int64))
+    assert torch.equal(rec["ob"][idx, last].view(torch.int64), out["ob_next"][idx].view(torch.int64))
+    got = reuse_transitions(out, cfg, 7, np.random.RandomState(5))
+    # direct transcription of the reference loop
+    ob, mr, dn, wp = (rec[k].cpu().numpy() for k in ("ob", "meta_rew", "done", "waypoint"))
+    rs = np.random.RandomState(5)
+    want = []
+    for e in np.where(nexec > 3)[0]:
+        ob_list, pairs = list(ob[e, :nexec[e]]), []
+        for _ in range(min(len(ob_list), 30)):
+            start = rs.randint(low=0, high=len(ob_list) - 1)
+            if start + 1 > len(ob_list) - 1:
+                continue
+            goal = rs.randint(low=start + 1, high=len(ob_list))
+            if (start, goal) in pairs:
+                continue
+            pairs.append((start, goal))
+            a = invert_displacement_np(wp[e, goal, :7] - wp[e, start, :7], cfg.ac_scale, cfg)
+            if (np.any(a < -cfg.omega) or np.any(a > cfg.omega)) and np.all(a >= -1) and np.all(a <= 1):
+                want.append((int(e), start, goal, (mr[e, goal] - mr[e, start]) * cfg.discount_factor ** (-(start + 1)), goal - start - 1))
+    assert [(t["env"], t["start"], t["goal"], t["rew"], t["intra_steps"]) for t in got] == want and len(got) > 5
+    for t in got[:20]:
+        assert np.array_equal(t["ob"], ob[t["env"], t["start"]]) and np.array_equal(t["ob_next"], ob[t["env"], t["goal"]])

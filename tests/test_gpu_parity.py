@@ -436,3 +436,26 @@ def orc_batch(oracle_mod, pi, qa, row):
     if key not in _ORC_CACHE:
         _ORC_CACHE[key] = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
     return _ORC_CACHE[key].is_valid_batch(qa, row, samples_per_env=len(qa), nthreads=0)
+
+
+@pytest.mark.parametrize("kernel", ["v2", "v5"])
+@pytest.mark.parametrize("N,S", [(64, 64), (65, 13), (1000, 7), (4097, 100)])
+def test_ragged_batch_sizes(kernel, N, S, oracle_mod):
+    """Tile remainders, envs that straddle tiles, samples_per_env that does not divide 64 (lane-per-state kernels)."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    env = "SawyerPushObstacle-v0"
+    pi, sc, orc = _mk(env, oracle_mod, kernel)
+    E = (N + S - 1) // S
+    qa, row = sample_states(pi, N, 5 + N, "near")
+    rows = np.repeat(row, E, axis=0)
+    rng = np.random.default_rng(N)
+    rows[:, 7:9] = rng.uniform(-0.008, 0.015, size=(E, 2))
+    cube = pi.model.get_joint_qpos_addr("cube")
+    rows[:, cube:cube + 2] += rng.uniform(-0.05, 0.05, size=(E, 2))
+    ov, omd = orc.is_valid_batch(qa, rows, samples_per_env=S, nthreads=0)
+    v, md = BatchPlanner(sc).is_valid(torch.from_numpy(qa).cuda(), torch.from_numpy(rows).cuda(), samples_per_env=S, want_min_dist=True)
+    v2 = BatchPlanner(sc).is_valid(torch.from_numpy(qa).cuda(), torch.from_numpy(rows).cuda(), samples_per_env=S)
+    torch.cuda.synchronize()
+    assert np.array_equal(v.cpu().numpy(), ov) and np.array_equal(v2.cpu().numpy(), ov)
+    assert np.array_equal(_bits(md.cpu().numpy()), _bits(omd))

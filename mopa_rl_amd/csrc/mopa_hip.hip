@@ -739,30 +739,43 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     //   [0..2] partner centre (static partners) / a point of the plane, [3] partner bounding radius,
     //   [4..6] world-AABB half extents of a static partner / the plane normal,
     //   [7] flags: bits 0..13 = low bits of gp_word (partner gid, code, cur_is_g2, pmov), 14..21 partner slot, 30 plane
-    std::vector<int32_t> gp_tab(8 * gp_word.size(), 0);
+    // Within a geom's range the entries are ordered [moving partners | static non-plane partners | planes] (the kernel
+    // runs one branch-free loop per group); the group sizes follow the table: tab[8 n_gp + slot] = nmov | nstat<<8 | nplane<<16.
+    std::vector<int32_t> gp_tab(8 * gp_word.size() + nmg, 0);
     int max_pnum = 0;
     {
         auto f2i = [](double x) { float f = (float)x; int32_t i; std::memcpy(&i, &f, 4); return i; };
-        for (int mslot = 0; mslot < nmg; mslot++) max_pnum = std::max(max_pnum, (int)mg_pnum[mslot]);
-        for (size_t p = 0; p < gp_word.size(); p++) {
-            const int w = gp_word[p];
-            const int pg = w & 0xff, pmov = (w >> 13) & 1;
-            int32_t *te = &gp_tab[8 * p];
-            te[3] = f2i(g_rbound[pg]);
-            int flags = w & 0x3fffff;    // gp_word already carries the slot in bits 14..21
-            if (!pmov) {
-                const double *rec = &g_rec[(size_t)kGeomStride * pg];
-                te[0] = f2i(rec[GO_POS]); te[1] = f2i(rec[GO_POS + 1]); te[2] = f2i(rec[GO_POS + 2]);
-                if (m.geom_type[pg] == G_PLANE) {
-                    te[4] = f2i(rec[GO_MAT + 2]); te[5] = f2i(rec[GO_MAT + 5]); te[6] = f2i(rec[GO_MAT + 8]);
-                    flags |= 1 << 30;
-                } else {
-                    double H[3];
-                    static_aabb_half(m.geom_type[pg], rec, g_rbound[pg], H);
-                    te[4] = f2i(H[0]); te[5] = f2i(H[1]); te[6] = f2i(H[2]);
-                }
+        for (int mslot = 0; mslot < nmg; mslot++) {
+            max_pnum = std::max(max_pnum, (int)mg_pnum[mslot]);
+            std::vector<int> order[3];
+            for (int p = mg_padr[mslot]; p < mg_padr[mslot] + mg_pnum[mslot]; p++) {
+                const int w = gp_word[p];
+                const int grp = ((w >> 13) & 1) ? 0 : (m.geom_type[w & 0xff] == G_PLANE ? 2 : 1);
+                order[grp].push_back(p);
             }
-            te[7] = flags;
+            gp_tab[8 * gp_word.size() + mslot] = (int)order[0].size() | ((int)order[1].size() << 8) | ((int)order[2].size() << 16);
+            size_t dst = (size_t)mg_padr[mslot];
+            for (int grp = 0; grp < 3; grp++)
+                for (int p : order[grp]) {
+                    const int w = gp_word[p];
+                    const int pg = w & 0xff, pmov = (w >> 13) & 1;
+                    int32_t *te = &gp_tab[8 * dst++];
+                    te[3] = f2i(g_rbound[pg]);
+                    int flags = w & 0x3fffff;    // gp_word already carries the slot in bits 14..21
+                    if (!pmov) {
+                        const double *rec = &g_rec[(size_t)kGeomStride * pg];
+                        te[0] = f2i(rec[GO_POS]); te[1] = f2i(rec[GO_POS + 1]); te[2] = f2i(rec[GO_POS + 2]);
+                        if (m.geom_type[pg] == G_PLANE) {
+                            te[4] = f2i(rec[GO_MAT + 2]); te[5] = f2i(rec[GO_MAT + 5]); te[6] = f2i(rec[GO_MAT + 8]);
+                            flags |= 1 << 30;
+                        } else {
+                            double H[3];
+                            static_aabb_half(m.geom_type[pg], rec, g_rbound[pg], H);
+                            te[4] = f2i(H[0]); te[5] = f2i(H[1]); te[6] = f2i(H[2]);
+                        }
+                    }
+                    te[7] = flags;
+                }
         }
     }
     S->h_gp_tab = gp_tab;
@@ -864,7 +877,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         S->v2_forced = ev && std::string(ev) == "v2";
         {
             // largest entry buffer (multiple of 64, 256..1024) that still lets two workgroups share a CU's 160 KiB of LDS
-            const int fixed = h.n_dbl * 8 + ((h.n_int + 3) & ~3) * 4 + ((8 * (int)gp_word.size() + 3) & ~3) * 4;
+            const int fixed = h.n_dbl * 8 + ((h.n_int + 3) & ~3) * 4 + ((8 * (int)gp_word.size() + nmg + 3) & ~3) * 4;
             int cap = kEntCapV5Max;
             while (cap > 256 && fixed + kWavesPerBlock * v5_lds_per_wave(nmg, cap) > 80 * 1024) cap -= 64;
             if (fixed + kWavesPerBlock * v5_lds_per_wave(nmg, cap) > 80 * 1024) cap = 768;   // one workgroup per CU anyway

@@ -110,6 +110,34 @@ def plan_section(torch, bp, pi, E, device):
             "mean_checks_per_plan": float(nchk.float().mean().item())}
 
 
+def motion_section(torch, bp, pi, qa, rows, S, device):
+    """A5: OMPL DiscreteMotionValidator (K2) on the first 262 144 states of the step batch as segment starts; segment =
+    a random direction of L1 length `range` (one RRT extension, ~1.5 states) or 5 x range."""
+    n = min(len(qa), 1 << 18)
+    n -= n % S
+    a = qa[:n].contiguous()
+    g = torch.Generator(device=device)
+    g.manual_seed(2)
+    lo = torch.tensor(pi.jnt_minimum, dtype=torch.float64, device=device)
+    hi = torch.tensor(pi.jnt_maximum, dtype=torch.float64, device=device)
+    out = {"config": f"{ENV}, {n} segments per launch, resolution 0.005 (KinematicPlanner.cpp:87)"}
+    for name, step in (("range", pi.spec.range), ("5x_range", 5 * pi.spec.range)):
+        d = torch.randn(n, a.shape[1], generator=g, dtype=torch.float64, device=device)
+        d = d / d.abs().sum(dim=1, keepdim=True) * step
+        b = torch.minimum(torch.maximum(a + d, lo), hi).contiguous()
+        for _ in range(2):
+            bp.check_motion(a, b, rows, samples_per_env=S)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            v = bp.check_motion(a, b, rows, samples_per_env=S)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        out[f"motions_per_s_{name}"] = n / dt
+        out[f"valid_fraction_{name}"] = float(v.float().mean().item())
+    return out
+
+
 def env_step_section(torch, pi, E, device, steps, with_cpu):
     """The "env-steps/sec" half of BASELINE.json's metric: E kinematic SawyerPushObstacle envs (K4 `k_env_step`),
     KINEMATIC -- the physics of the reference env.step is replaced by its kinematic limit (mopa_rl_amd/kinematic_env.py),
@@ -345,6 +373,7 @@ def main():
                                            "insts_per_check": t["valu_insts_per_launch"] / t["states_per_launch"],
                                            "note": "SQ_INSTS_VALU from the committed PMC pass / live kernel time"}
         if not args.no_plan and world == 1:
+            out["motion"] = motion_section(torch, bp, pi, qa, rows, S, device)
             out["planner"] = plan_section(torch, bp, pi, args.plan_envs, device)
         if not args.no_env and world == 1:
             out["env_step"] = env_step_section(torch, pi, args.envs, device, 50, not args.no_cpu)

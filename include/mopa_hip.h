@@ -141,7 +141,10 @@ int mopa_is_valid_batch(MopaScene *scene, const double *q_active_dev /*[N,na]*/,
 
 /* N segments qa[i] -> qb[i] (active coordinates), OMPL DiscreteMotionValidator semantics:
  * valid[i] = 1 iff qb[i] and every interior state interpolate(qa,qb,k/nd), k=1..nd-1, is valid,
- * nd = max_j ceil(|d_j| / (resolution * extent_j)). */
+ * nd = max_j ceil(|d_j| / (resolution * extent_j)).
+ * Large batches are served by expanding every segment into its states (count, scan, expand), validating them with the
+ * lane-per-state kernel and AND-ing per segment; that path reads the total state count back once, i.e. the call
+ * synchronises `stream` before it returns (results are still produced asynchronously on the stream). */
 int mopa_check_motion_batch(MopaScene *scene, const double *qa_dev /*[N,na]*/, const double *qb_dev /*[N,na]*/,
                             const double *qpos_env_dev /*[E,nq]*/, int64_t N, int64_t samples_per_env,
                             uint8_t *valid_dev /*[N]*/, void *stream);

@@ -12,6 +12,7 @@
 //   K4 k_env_step      (mopa_env.inc) one lane per env, kinematic env.step
 //   FP64 VALU bound, no MFMA (there is no dense contraction on this path).
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>
@@ -108,6 +109,12 @@ struct MopaScene {
     int v2_lds_bytes = 0;
     int use_v2 = 1;
     int32_t *d_gp_tab = nullptr;   // v5: FP32 broad-phase table [n_gp][8]
+    // expanded motion validation (mopa_motion.inc): per-segment counts / offsets, expanded states, their env rows, verdicts
+    int32_t *mv_cnt = nullptr, *mv_off = nullptr, *mv_env = nullptr;
+    double *mv_q = nullptr;
+    uint8_t *mv_valid = nullptr;
+    void *mv_scan = nullptr;
+    size_t mv_cap_seg = 0, mv_cap_states = 0, mv_scan_bytes = 0;
     int v5_lds_bytes = 0;
     int use_v5 = 0;
     bool v2_forced = false;   // MOPA_VALID_KERNEL=v2: lane-per-state kernel for every N >= 64 (tests, A/B runs)
@@ -951,6 +958,8 @@ extern "C" void mopa_scene_destroy(MopaScene *S) {
     if (S->d_dbg) (void)hipFree(S->d_dbg);
     if (S->d_slab) (void)hipFree(S->d_slab);
     if (S->d_gp_tab) (void)hipFree(S->d_gp_tab);
+    for (void *q : {(void *)S->mv_cnt, (void *)S->mv_off, (void *)S->mv_env, (void *)S->mv_q, (void *)S->mv_valid, S->mv_scan})
+        if (q) (void)hipFree(q);
     delete S;
 }
 
@@ -969,8 +978,9 @@ static int grid_for(const MopaScene *S, int64_t N) {
     return (int)std::max<int64_t>(1, std::min(blocks, cap));
 }
 
-extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const double *qpos_env, int64_t N,
-                                   int64_t samples_per_env, uint8_t *valid, double *min_dist, void *stream) {
+// state validity of N states; env row of state i = env_idx ? env_idx[i] : i / samples_per_env
+static int launch_is_valid(MopaScene *S, const double *q_active, const double *qpos_env, int64_t N, int64_t samples_per_env,
+                           const int *env_idx, uint8_t *valid, double *min_dist, void *stream) {
     if (!S || !valid || (N > 0 && (!q_active || !qpos_env))) return fail(MOPA_ERR_INVALID_ARG, "null argument");
     if (N < 0 || samples_per_env <= 0) return fail(MOPA_ERR_INVALID_ARG, "N < 0 or samples_per_env <= 0");
     if (N == 0) return MOPA_OK;
@@ -981,7 +991,7 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
     // env, e.g. the collision gate of the kinematic env.step) go to the latter.  Measured crossover on MI355X
     // (tools/crossover.py): 8192 states 155 vs 171 us, 12288 states 202 vs 168 us  =>  ~36 states per CU.
     const int64_t v2_min = S->v2_forced ? 64 : std::max<int64_t>(64, (int64_t)S->n_cu * 36);
-    if (S->use_v2 && N >= v2_min) {
+    if (S->use_v2 && (N >= v2_min || env_idx)) {
         // one lane per state, 64-state tiles; 2 workgroups per CU keep the pose slab small and L2 resident
         int64_t tiles = (N + 63) / 64;
         int64_t blocks = std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)S->n_cu * 2);
@@ -1005,19 +1015,19 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
         if (S->use_v5) {
             if (min_dist)
                 hipLaunchKernelGGL(k_is_valid_v5<true>, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active,
-                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab);
+                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx);
             else
                 hipLaunchKernelGGL(k_is_valid_v5<false>, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active,
-                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab);
+                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx);
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                           (long long)samples_per_env, valid, min_dist, S->d_slab, 0);
+                           (long long)samples_per_env, valid, min_dist, S->d_slab, 0, env_idx);
         if (S->n_mesh_gp > 0) {
             // second pass: the mesh pairs only (MESH instantiation), verdict AND-ed / depth min-ed into the first pass's
             HIP_TRY(hipMemsetAsync(d_tail + 8, 0, 8, st));
             auto km = min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>;
             hipLaunchKernelGGL(km, grid, block, S->v2_lds_bytes, st, S->hdr_mesh, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                               (long long)samples_per_env, valid, min_dist, S->d_slab, 1);
+                               (long long)samples_per_env, valid, min_dist, S->d_slab, 1, env_idx);
         }
         HIP_TRY(hipGetLastError());
 #ifdef MOPA_V2_PROFILE
@@ -1031,6 +1041,7 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
 #endif
         return MOPA_OK;
     }
+    if (env_idx) return fail(MOPA_ERR_UNSUPPORTED, "explicit env indices need the lane-per-state kernels");
     dim3 grid(grid_for(S, N));
     auto kern = S->hdr.has_mesh ? (min_dist ? k_is_valid<true, true> : k_is_valid<false, true>)
                                 : (min_dist ? k_is_valid<true, false> : k_is_valid<false, false>);
@@ -1040,12 +1051,22 @@ extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const d
     return MOPA_OK;
 }
 
+extern "C" int mopa_is_valid_batch(MopaScene *S, const double *q_active, const double *qpos_env, int64_t N,
+                                   int64_t samples_per_env, uint8_t *valid, double *min_dist, void *stream) {
+    return launch_is_valid(S, q_active, qpos_env, N, samples_per_env, nullptr, valid, min_dist, stream);
+}
+
+#include "mopa_motion.inc"
+
 extern "C" int mopa_check_motion_batch(MopaScene *S, const double *qa, const double *qb, const double *qpos_env, int64_t N,
                                        int64_t samples_per_env, uint8_t *valid, void *stream) {
     if (!S || !valid || (N > 0 && (!qa || !qb || !qpos_env))) return fail(MOPA_ERR_INVALID_ARG, "null argument");
     if (N < 0 || samples_per_env <= 0) return fail(MOPA_ERR_INVALID_ARG, "N < 0 or samples_per_env <= 0");
     if (N == 0) return MOPA_OK;
     hipStream_t st = (hipStream_t)stream;
+    // large batches: expand every segment into its states, validate them with the lane-per-state kernel, AND per segment
+    const int64_t big = S->v2_forced ? 64 : std::max<int64_t>(64, (int64_t)S->n_cu * 16);
+    if (S->use_v2 && N >= big) return motion_expanded(S, qa, qb, qpos_env, N, samples_per_env, valid, st);
     dim3 grid(grid_for(S, N)), block(kBlock);
     hipLaunchKernelGGL(k_check_motion, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, qa, qb, qpos_env, (long long)N,
                        (long long)samples_per_env, valid);

@@ -259,15 +259,17 @@ def test_single_state_api(env, oracle_mod):
 
 
 @pytest.mark.parametrize("env", SUPPORTED_ENVS)
-def test_check_motion_matches_oracle(env, oracle_mod):
+@pytest.mark.parametrize("kernel", KERNELS)   # v1: wave per segment; v2 / v5: segments expanded into states (mopa_motion.inc)
+def test_check_motion_matches_oracle(env, kernel, oracle_mod):
     import torch
     from mopa_rl_amd.batch import BatchPlanner
-    pi, sc, orc = _mk(env, oracle_mod)
+    pi, sc, orc = _mk(env, oracle_mod, kernel)
     bp = BatchPlanner(sc)
     n = 2048
     qa, row = sample_states(pi, n, 31, "near")
     rng = np.random.default_rng(9)
     step = rng.normal(0, 0.05, size=qa.shape)
+    step[n // 2:] *= 6.0   # long segments: a dozen interior states
     step[: n // 8] = 0.0   # degenerate zero-length segments
     qb = np.clip(qa + step, pi.jnt_minimum, pi.jnt_maximum)
     ov = orc.check_motion_batch(qa, qb, row, samples_per_env=n, nthreads=0)

@@ -105,6 +105,7 @@ struct MopaScene {
     int n_cu = 256;
     // v2 kernel resources
     double *d_slab = nullptr;
+    double *d_mpr = nullptr;      // v5: per-wave ring of deferred cylinder pairs
     size_t slab_waves = 0;
     int v2_lds_bytes = 0;
     int use_v2 = 1;
@@ -957,6 +958,7 @@ extern "C" void mopa_scene_destroy(MopaScene *S) {
     if (S->d_md) (void)hipFree(S->d_md);
     if (S->d_dbg) (void)hipFree(S->d_dbg);
     if (S->d_slab) (void)hipFree(S->d_slab);
+    if (S->d_mpr) (void)hipFree(S->d_mpr);
     if (S->d_gp_tab) (void)hipFree(S->d_gp_tab);
     for (void *q : {(void *)S->mv_cnt, (void *)S->mv_off, (void *)S->mv_env, (void *)S->mv_q, (void *)S->mv_valid, S->mv_scan})
         if (q) (void)hipFree(q);
@@ -1001,6 +1003,9 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             S->d_slab = nullptr; S->slab_waves = 0;
             size_t want = std::max(waves, (size_t)S->n_cu * 2 * kWavesPerBlock);
             HIP_TRY(hipMalloc((void **)&S->d_slab, (want * (size_t)(S->hdr.nmg + S->hdr.n_save) * kSlabStride + 16) * sizeof(double)));
+            if (S->d_mpr) (void)hipFree(S->d_mpr);
+            S->d_mpr = nullptr;
+            HIP_TRY(hipMalloc((void **)&S->d_mpr, want * (size_t)kMprCapV5 * kMprRow * sizeof(double)));
             S->slab_waves = want;
         }
         dim3 grid((unsigned)blocks);
@@ -1015,10 +1020,10 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
         if (S->use_v5) {
             if (min_dist)
                 hipLaunchKernelGGL(k_is_valid_v5<true>, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active,
-                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx);
+                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx, S->d_mpr);
             else
                 hipLaunchKernelGGL(k_is_valid_v5<false>, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active,
-                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx);
+                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx, S->d_mpr);
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
                            (long long)samples_per_env, valid, min_dist, S->d_slab, 0, env_idx);

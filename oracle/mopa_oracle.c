@@ -1244,6 +1244,9 @@ static int grow_tree(Grow *g, Tree *tree, int is_start, const double *rstate) {
         dstate = g->xstate;
         reach = 0;
     }
+    /* node budget (a deviation: OMPL's trees are unbounded): a full tree cannot take the new state, so its motion is not
+     * validated either -- before this test sat behind the validation, a query that had filled a tree kept paying for it */
+    if (tree->n >= tree->cap) return TRAPPED;
     int ok;
     if (is_start) ok = check_motion_ws(s, g->qpos_env, nstate, dstate, g->resolution, g->n_checks, g->qpos, g->ws);
     else {
@@ -1252,7 +1255,6 @@ static int grow_tree(Grow *g, Tree *tree, int is_start, const double *rstate) {
              check_motion_ws(s, g->qpos_env, dstate, nstate, g->resolution, g->n_checks, g->qpos, g->ws);
     }
     if (!ok) return TRAPPED;
-    if (tree->n >= tree->cap) return TRAPPED; /* node budget exhausted */
     memcpy(tree->q + (size_t)tree->n * s->na, dstate, sizeof(double) * s->na);
     tree->parent[tree->n] = nm;
     g->xmotion = tree->n;

@@ -31,6 +31,8 @@ using namespace mopa;
 // error plumbing
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
+constexpr int kMaxLdsBytes = 160 * 1024;   // LDS per CU on gfx950
+static void plan_register_lds();            // defined with K3 (mopa_planner.inc)
 static int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
@@ -119,6 +121,10 @@ struct MopaScene {
     int v5_lds_bytes = 0;
     int use_v5 = 0;
     bool v2_forced = false;   // MOPA_VALID_KERNEL=v2: lane-per-state kernel for every N >= 64 (tests, A/B runs)
+    // planner workspace (mopa_planner.inc): both trees of every env, grown on demand
+    double *plan_tree_q = nullptr;
+    int32_t *plan_tree_parent = nullptr;
+    size_t plan_q_bytes = 0, plan_p_bytes = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -877,11 +883,11 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     S->h_dbl = B.dbl;
     S->h_int = B.ints;
     S->lds_bytes = h.n_dbl * 8 + ((h.n_int + 1) & ~1) * 4 + kWavesPerBlock * h.wave_bytes;
-    if (S->lds_bytes > 160 * 1024) { delete S; return fail(MOPA_ERR_LIMIT, "scene does not fit the 160 KiB LDS"); }
+    if (S->lds_bytes > kMaxLdsBytes) { delete S; return fail(MOPA_ERR_LIMIT, "scene does not fit the 160 KiB LDS"); }
     {
         S->v2_lds_bytes = h.n_dbl * 8 + ((h.n_int + 1) & ~1) * 4 + kWavesPerBlock * kV2LdsPerWave;
         const char *ev = std::getenv("MOPA_VALID_KERNEL");
-        S->use_v2 = !(ev && std::string(ev) == "v1") && S->v2_lds_bytes <= 160 * 1024;
+        S->use_v2 = !(ev && std::string(ev) == "v1") && S->v2_lds_bytes <= kMaxLdsBytes;
         S->v2_forced = ev && std::string(ev) == "v2";
         {
             // largest entry buffer (multiple of 64, 256..1024) that still lets two workgroups share a CU's 160 KiB of LDS
@@ -899,7 +905,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         // ... unless it would get one workgroup per CU where the second generation still gets two (LDS: the FP32 centre
         // table grows with the number of moving geoms; SawyerLift: 19 of them)
         const bool v5_fits2 = S->v5_lds_bytes <= 80 * 1024, v2_fits2 = S->v2_lds_bytes <= 80 * 1024;
-        S->use_v5 = !(ev && std::string(ev) == "v2") && S->use_v2 && max_pnum <= 64 && S->v5_lds_bytes <= 160 * 1024 &&
+        S->use_v5 = !(ev && std::string(ev) == "v2") && S->use_v2 && max_pnum <= 64 && S->v5_lds_bytes <= kMaxLdsBytes &&
                     (v5_fits2 || !v2_fits2 || (ev && std::string(ev) == "v5"));
         if (ev && std::string(ev) == "v5") S->v2_forced = true;   // "v5" also forces the lane-per-state path for every N >= 64
     }
@@ -934,23 +940,23 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     for (hipError_t e : {e1, e2, e3, e4, e5, e6})
         if (e != hipSuccess) { mopa_scene_destroy(S); return fail(MOPA_ERR_HIP, std::string("device allocation: ") + hipGetErrorString(e)); }
     // allow the dynamic LDS size
+    // the attribute is per function, not per scene: register the device maximum once so scenes of different sizes can
+    // coexist in one process in any creation order (each launch still passes its own, checked, size)
     for (const void *k : {(const void *)k_is_valid<false, false>, (const void *)k_is_valid<true, false>, (const void *)k_is_valid<false, true>,
                           (const void *)k_is_valid<true, true>, (const void *)k_check_motion, (const void *)k_debug_state<false>,
-                          (const void *)k_debug_state<true>})
-        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, S->lds_bytes);
-    for (const void *k : {(const void *)k_is_valid_v2<false, false>, (const void *)k_is_valid_v2<true, false>,
-                          (const void *)k_is_valid_v2<false, true>, (const void *)k_is_valid_v2<true, true>})
-        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, S->v2_lds_bytes);
-    for (const void *k : {(const void *)k_is_valid_v5<false>, (const void *)k_is_valid_v5<true>})
-        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, S->v5_lds_bytes);
+                          (const void *)k_debug_state<true>, (const void *)k_is_valid_v2<false, false>,
+                          (const void *)k_is_valid_v2<true, false>, (const void *)k_is_valid_v2<false, true>,
+                          (const void *)k_is_valid_v2<true, true>, (const void *)k_is_valid_v5<false>, (const void *)k_is_valid_v5<true>})
+        (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
+    plan_register_lds();
     *out = S;
     return MOPA_OK;
 }
 
-static void plan_ws_release(MopaScene *S);
 extern "C" void mopa_scene_destroy(MopaScene *S) {
     if (!S) return;
-    plan_ws_release(S);
+    if (S->plan_tree_q) (void)hipFree(S->plan_tree_q);
+    if (S->plan_tree_parent) (void)hipFree(S->plan_tree_parent);
     if (S->d_dbl) (void)hipFree(S->d_dbl);
     if (S->d_int) (void)hipFree(S->d_int);
     if (S->d_q) (void)hipFree(S->d_q);

@@ -72,11 +72,9 @@ def make_inputs(torch, pi, E, S, seed, device, mode="mixed"):
     return qa.reshape(E * S, na).contiguous(), rows.contiguous()
 
 
-def plan_section(torch, bp, pi, E, device):
-    """BASELINE.json configs[2]: E envs, each one RRT-Connect query (K3, one wave per env).  start = init_qpos +
-    N(0, 0.02) (as `_reset`, env/sawyer/sawyer_push_obstacle.py:36-41), goal = a valid state with |dq|_inf <= 0.5
-    (action_range).  Reported next to, not inside, the headline metric."""
-    import time as _t
+def planner_queries(torch, bp, pi, E, device):
+    """start = init_qpos + N(0, 0.02) (as `_reset`, env/sawyer/sawyer_push_obstacle.py:36-41), goal = a valid state
+    with |dq|_inf <= 0.5 (action_range)."""
     from mopa_rl_amd.scene import default_qpos
     g = torch.Generator(device=device)
     g.manual_seed(99)
@@ -94,6 +92,14 @@ def plan_section(torch, bp, pi, E, device):
     goal = start.clone()
     pick = cand.reshape(E, C, 7)[torch.arange(E, device=device), first]
     goal[:, :7] = torch.where(ok.any(dim=1, keepdim=True), pick, start[:, :7])
+    return start, goal
+
+
+def plan_section(torch, bp, pi, E, device):
+    """BASELINE.json configs[2]: E envs, each one RRT-Connect query (K3, one wave per env).  Reported next to, not
+    inside, the headline metric."""
+    import time as _t
+    start, goal = planner_queries(torch, bp, pi, E, device)
     prm = dict(max_iters=2000, max_nodes=1024, max_path=256, seed=7)
     bp.plan(start, goal, **prm)
     torch.cuda.synchronize()

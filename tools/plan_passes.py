@@ -1,0 +1,34 @@
+"""Debug tool: build the library with -DMOPA_PLAN_STATS first (make -C mopa_rl_amd/csrc EXTRA=-DMOPA_PLAN_STATS).
+Prints, for the bench's planner queries, validity passes / evaluated states / tree sizes per failing and succeeding env."""
+import sys; sys.path.insert(0, ".")
+import torch, numpy as np
+import bench
+from mopa_rl_amd import _lib
+from mopa_rl_amd.batch import BatchPlanner
+from mopa_rl_amd.scene import planner_inputs
+pi = planner_inputs(bench.ENV)
+sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+bp = BatchPlanner(sc)
+start, goal = bench.planner_queries(torch, bp, pi, 4096, torch.device("cuda:0"))
+path, plen, st, nchk = bp.plan(start, goal, max_iters=2000, max_nodes=1024, max_path=256, seed=7)
+n = nchk.cpu().numpy(); st = st.cpu().numpy()
+chk, npass, nst, n0, n1 = n & 0xffff, (n >> 16) & 0x3fff, (n >> 30) & 0x3fff, (n >> 44) & 0x3ff, (n >> 54) & 0x3ff
+for name, m in (("fail", st != 0), ("ok", st == 0)):
+    print(name, int(m.sum()), "checks", chk[m].mean(), "passes", npass[m].mean(), "states", nst[m].mean(), "tree0", n0[m].mean(), "tree1", n1[m].mean())
+f = np.where(st != 0)[0][:12]
+for e in f: print(e, chk[e], npass[e], nst[e], n0[e], n1[e])
+
+import ctypes
+lib = _lib.lib()
+if hasattr(lib, "mopa_debug_plan_times"):
+    buf = (ctypes.c_ulonglong * 40)()
+    lib.mopa_debug_plan_times(buf, 1)
+    fi = torch.nonzero(torch.tensor(st != 0)).flatten().to(start.device)
+    bp.plan(start[fi].contiguous(), goal[fi].contiguous(), max_iters=2000, max_nodes=1024, max_path=256, seed=7, env_ids=fi.contiguous())
+    lib.mopa_debug_plan_times(buf, 1)
+    t = list(buf); n = len(fi)
+    print("failing envs only: per env, 100 MHz ticks -> us: pose+fk %.0f broad %.0f narrow %.0f | survivors/pass %.1f states/pass %.2f passes %d" % (
+        t[0] / n / 100, t[1] / n / 100, t[2] / n / 100, t[3] / max(t[4], 1), t[5] / max(t[4], 1), t[4] / n))
+    names = "PLANE_SPHERE PLANE_CAPSULE PLANE_CYLINDER PLANE_BOX SPHERE_SPHERE SPHERE_CAPSULE SPHERE_CYLINDER SPHERE_BOX CAPSULE_CAPSULE CAPSULE_BOX BOX_BOX CONVEX PLANE_MESH CONVEX_MESH".split()
+    for k, nm in enumerate(names):
+        if t[24 + k]: print("  class %-16s rounds/pass %.2f  us/round %.2f  us/pass %.2f" % (nm, t[24 + k] / t[4], t[8 + k] / t[24 + k] / 100, t[8 + k] / t[4] / 100))

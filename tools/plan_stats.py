@@ -8,17 +8,7 @@ pi = planner_inputs(bench.ENV)
 sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
 bp = BatchPlanner(sc); dev = torch.device("cuda:0")
 E = 4096
-g = torch.Generator(device=dev); g.manual_seed(99)
-q0 = torch.tensor(default_qpos(bench.ENV, pi.model), dtype=torch.float64, device=dev)
-lo = torch.tensor(pi.jnt_minimum, dtype=torch.float64, device=dev); hi = torch.tensor(pi.jnt_maximum, dtype=torch.float64, device=dev)
-start = q0.repeat(E, 1); start[:, :7] += 0.02 * torch.randn(E, 7, generator=g, dtype=torch.float64, device=dev)
-C = 8
-cand = start[:, None, :7] + (torch.rand(E, C, 7, generator=g, dtype=torch.float64, device=dev) - 0.5)
-cand = torch.minimum(torch.maximum(cand, lo), hi).reshape(E * C, 7).contiguous()
-ok = bp.is_valid(cand, start.contiguous(), samples_per_env=C).reshape(E, C).bool()
-first = torch.argmax(ok.int(), dim=1); goal = start.clone()
-pick = cand.reshape(E, C, 7)[torch.arange(E, device=dev), first]
-goal[:, :7] = torch.where(ok.any(dim=1, keepdim=True), pick, start[:, :7])
+start, goal = bench.planner_queries(torch, bp, pi, E, dev)
 for iters in (2000, 500):
     bp.plan(start, goal, max_iters=iters, max_nodes=1024, max_path=256, seed=7); torch.cuda.synchronize()
     t0 = time.perf_counter(); path, plen, st, nchk = bp.plan(start, goal, max_iters=iters, max_nodes=1024, max_path=256, seed=7); torch.cuda.synchronize()

@@ -392,9 +392,14 @@ __device__ __noinline__ bool plan_state_valid_impl(const SceneHdr *hp, const dou
 __global__ __launch_bounds__(kBlock) void k_check_motion(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
                                                          const double *__restrict__ qa_all, const double *__restrict__ qb_all,
                                                          const double *__restrict__ qpos_env, long long N, long long samples_per_env,
-                                                         unsigned char *__restrict__ valid) {
+                                                         unsigned char *__restrict__ valid, int hdr_lds_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsView v = make_view(h, smem);
+    // the non-inlined validity routine reads the header through an LDS pointer (a pointer to the by-value kernel
+    // argument would live in scratch memory)
+    SceneHdr *lh = reinterpret_cast<SceneHdr *>(smem + hdr_lds_off);
+    for (int i = threadIdx.x; i < (int)(sizeof(SceneHdr) / 4); i += blockDim.x)
+        reinterpret_cast<int *>(lh)[i] = reinterpret_cast<const int *>(&h)[i];
     stage_scene(h, g_dbl, g_int, const_cast<double *>(v.dbl), const_cast<int *>(v.ints));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long stride = (long long)gridDim.x * kWavesPerBlock;
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(kBlock) void k_check_motion(SceneHdr h, const doubl
             if (lane < h.na) tst[lane] = (k == nd) ? qb[lane] : interp_dim(h, v, lane, qa[lane], qb[lane], t);
             for (int i = lane + 64; i < h.na; i += 64) tst[i] = (k == nd) ? qb[i] : interp_dim(h, v, i, qa[i], qb[i], t);
             wave_sync();
-            ok = plan_state_valid_impl(&h, v.dbl, v.ints, v.grec, v.qbuf, v.wl, lane, tst, row);
+            ok = plan_state_valid_impl(lh, v.dbl, v.ints, v.grec, v.qbuf, v.wl, lane, tst, row);
         }
         if (lane == 0) valid[s] = ok ? 1 : 0;
     }
@@ -1079,8 +1084,10 @@ extern "C" int mopa_check_motion_batch(MopaScene *S, const double *qa, const dou
     const int64_t big = S->v2_forced ? 64 : std::max<int64_t>(64, (int64_t)S->n_cu * 16);
     if (S->use_v2 && N >= big) return motion_expanded(S, qa, qb, qpos_env, N, samples_per_env, valid, st);
     dim3 grid(grid_for(S, N)), block(kBlock);
-    hipLaunchKernelGGL(k_check_motion, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, qa, qb, qpos_env, (long long)N,
-                       (long long)samples_per_env, valid);
+    const int hdr_off = (S->lds_bytes + 15) & ~15;
+    if (hdr_off + (int)sizeof(SceneHdr) > kMaxLdsBytes) return fail(MOPA_ERR_LIMIT, "motion validation LDS does not fit");
+    hipLaunchKernelGGL(k_check_motion, grid, block, hdr_off + sizeof(SceneHdr), st, S->hdr, S->d_dbl, S->d_int, qa, qb, qpos_env,
+                       (long long)N, (long long)samples_per_env, valid, hdr_off);
     HIP_TRY(hipGetLastError());
     return MOPA_OK;
 }

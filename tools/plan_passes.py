@@ -29,6 +29,8 @@ if hasattr(lib, "mopa_debug_plan_times"):
     t = list(buf); n = len(fi)
     print("failing envs only: per env, 100 MHz ticks -> us: pose+fk %.0f broad %.0f narrow %.0f | survivors/pass %.1f states/pass %.2f passes %d" % (
         t[0] / n / 100, t[1] / n / 100, t[2] / n / 100, t[3] / max(t[4], 1), t[5] / max(t[4], 1), t[4] / n))
+    print("  own nearest-neighbour %.0f us, speculation (memo lookup + fused NN + steering) %.0f us per env" % (t[6] / n / 100, t[7] / n / 100))
+    print("  speculation split: fused NN %.0f us, two steer+push %.0f us, connect-chain %.0f us per env" % (t[22] / n / 100, t[23] / n / 100, t[38] / n / 100))
     names = "PLANE_SPHERE PLANE_CAPSULE PLANE_CYLINDER PLANE_BOX SPHERE_SPHERE SPHERE_CAPSULE SPHERE_CYLINDER SPHERE_BOX CAPSULE_CAPSULE CAPSULE_BOX BOX_BOX CONVEX PLANE_MESH CONVEX_MESH".split()
     for k, nm in enumerate(names):
         if t[24 + k]: print("  class %-16s rounds/pass %.2f  us/round %.2f  us/pass %.2f" % (nm, t[24 + k] / t[4], t[8 + k] / t[24 + k] / 100, t[8 + k] / t[4] / 100))

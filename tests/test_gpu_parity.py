@@ -319,6 +319,42 @@ def test_plan_matches_oracle(env, oracle_mod):
     assert n_ok >= 1
 
 
+def test_plan_with_nine_active_coordinates(oracle_mod):
+    """The gripper slides made active (9 coordinates, two of them with a 23 mm extent => motions of >100 states):
+    the planner's generic nearest-neighbour path (> 8 coordinates) and long bisection queues, against the oracle."""
+    import torch
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs("SawyerPushObstacle-v0")
+    passive = [a for a in pi.passive_joint_idx if a not in (7, 8)]
+    sc = _lib.Scene(pi.model, passive, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range, seed=7)
+    orc = oracle_mod.OracleScene(pi.model, passive, pi.ignored_contacts, pi.spec.contact_threshold)
+    bp = BatchPlanner(sc)
+    rng = np.random.default_rng(3)
+    arm, row = sample_states(pi, 2000, 43, "near")
+    qa = np.concatenate([arm, rng.uniform(-0.008, 0.015, size=(len(arm), 2))], axis=1)
+    ov, _ = orc.is_valid_batch(qa, row, samples_per_env=len(qa))
+    good = qa[ov == 1]
+    E = 8
+    assert len(good) >= 2 * E
+    act = list(range(9))
+    starts, goals = np.repeat(row, E, axis=0), np.repeat(row, E, axis=0)
+    starts[:, act] = good[:E]
+    goals[:, act] = good[E:2 * E]
+    max_iters, max_nodes, max_path = 150, 512, 256
+    path, plen, status, nchk = bp.plan(torch.from_numpy(starts).cuda(), torch.from_numpy(goals).cuda(),
+                                       max_iters=max_iters, max_nodes=max_nodes, max_path=max_path, seed=77, env_id_base=0)
+    torch.cuda.synchronize()
+    path, plen, status, nchk = path.cpu().numpy(), plen.cpu().numpy(), status.cpu().numpy(), nchk.cpu().numpy()
+    for e in range(E):
+        st, opath, ochk, _ = orc.plan(starts[e], goals[e], pi.spec.range, 0.005, max_iters, max_nodes, seed=77, env_id=e,
+                                      max_path=max_path)
+        assert status[e] == st and plen[e] == len(opath) and nchk[e] == ochk, (e, status[e], st, nchk[e], ochk)
+        assert np.array_equal(_bits(path[e, :plen[e]]), _bits(opath)), f"env {e}: path differs"
+    assert (status == 0).sum() >= 1 and nchk.max() > 100
+
+
 @pytest.mark.parametrize("env", SUPPORTED_ENVS)
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_hip_matches_committed_golden(env, kernel):

@@ -235,6 +235,10 @@ def handle_invalid_target_batch(bp, curr_qpos, target_qpos, step_size: float, nu
 
     valid = check(target)
     trials = torch.zeros(E, dtype=torch.int64, device=target.device)
+    # Columns in which no env's target differs from its current state stay that way (their step is 0 / norm = 0), and
+    # their squares are +0.0, which leaves a non-negative running sum bit-for-bit unchanged: the sequential sum below
+    # visits only the other columns (the arm joints), in the same left-to-right order as norm_seq.
+    cols = torch.nonzero(((curr_qpos - target) != 0).any(dim=0)).flatten().tolist()
     for _ in range(num_trials):
         todo = ~valid
         if not bool(todo.any().item()):
@@ -242,7 +246,7 @@ def handle_invalid_target_batch(bp, curr_qpos, target_qpos, step_size: float, nu
         d = curr_qpos - target
         sq = d * d
         acc = torch.zeros_like(sq[:, 0])
-        for c in range(nq):      # same left-to-right order as norm_seq
+        for c in cols:
             acc = acc + sq[:, c]
         step = step_size * d / torch.sqrt(acc)[:, None]
         target = torch.where(todo[:, None], target + step, target)

@@ -171,51 +171,68 @@ class BatchMoPARollout:
 
     # ------------------------------------------------------------------
     def plan(self, cur, target, env_ids):
-        """`SACAgent.plan` (rl/sac_agent.py:198-235) for M envs: returns host lists (traj_m [L_m, nq] numpy) and boolean
-        numpy arrays success, interpolation, valid, exact."""
+        """`SACAgent.plan` (rl/sac_agent.py:198-235) for M envs.  Returns (traj [M, L, nq] device tensor, length [M] device
+        int64 -- 0 where the plan failed --, and the boolean numpy arrays success, interpolation, valid, exact).  Straight
+        lines that validate never leave the GPU; only the envs that needed RRT-Connect are post-processed on the host
+        (ragged paths: successive differences, densification) and uploaded into their rows."""
         torch = _torch()
         cfg, n = self.cfg, self.n
         M = cur.shape[0]
         cur = self.clip_qpos(cur)
         traj_t, tlen, succ, _ = simple_interpolate_batch(self.bp, cur, target, cfg.ac_scale, self.arm)
-        traj_h, tlen_h, succ_h = traj_t.cpu().numpy(), tlen.cpu().numpy(), succ.cpu().numpy()
-        trajs = [traj_h[m, :tlen_h[m]].copy() for m in range(M)]
+        succ_h = succ.cpu().numpy()
         success, interpolation = succ_h.copy(), np.ones(M, dtype=bool)
         valid, exact = succ_h.copy(), succ_h.copy()
+        lens = torch.where(succ, tlen.to(torch.int64), torch.zeros_like(tlen, dtype=torch.int64))
         fail = np.where(~succ_h)[0]
         if len(fail) == 0:
-            return trajs, success, interpolation, valid, exact
+            return traj_t, lens, success, interpolation, valid, exact
         # ---- main planner for the envs whose straight line is blocked (:205-209)
         fi = torch.as_tensor(fail, device=cur.device)
         ids = env_ids[fi].contiguous()
-        path, plen, status, _ = self.bp.plan(cur[fi].contiguous(), target[fi].contiguous(), max_iters=self.main_iters,
+        cur_f = cur[fi].contiguous()
+        path, plen, status, _ = self.bp.plan(cur_f, target[fi].contiguous(), max_iters=self.main_iters,
                                              max_nodes=cfg.max_nodes, max_path=cfg.max_path, seed=cfg.seed + self.t, env_ids=ids)
-        path_h, plen_h, st_h = path.cpu().numpy(), plen.cpu().numpy(), status.cpu().numpy()
-        cur_h, tgt_h, ids_h = cur.cpu().numpy(), target.cpu().numpy(), env_ids.cpu().numpy()
+        plen_h, st_h = plen.cpu().numpy(), status.cpu().numpy()
+        path_h = path[:, :max(1, int(plen_h.max()))].cpu().numpy()      # the [max_path] tail of every row is unused
+        cur_h, ids_h = cur_f.cpu().numpy(), ids.cpu().numpy()
         interpolation[fail] = False
-        seg_jobs = []          # (m, i, start, end) of planner-path segments that need densification
+        trajs = {}             # j (index into `fail`) -> [L_j, nq] numpy
+        seg_jobs = []          # (j, i, start, end) of planner-path segments that need densification
         for j, m in enumerate(fail):
             if st_h[j] != 0:   # sentinel rows (sampling_based_planner.py:64-69): -5 goal invalid, -4 no exact solution
                 valid[m], exact[m], success[m] = st_h[j] != _lib.PLAN_INVALID_GOAL, st_h[j] != _lib.PLAN_NO_EXACT, False
-                trajs[m] = np.full((1, self.nq), float(st_h[j]))
                 continue
             states = path_h[j, :plen_h[j]]
             # SamplingBasedPlanner.plan: trajectory rebuilt from successive differences (:71-99), PlannerAgent drops row 0
-            tr = [cur_h[m]]
+            tr = [cur_h[j]]
             for s in range(1, len(states)):
                 tr.append(tr[-1] + (states[s] - states[s - 1]))
-            trajs[m] = np.array(tr[1:])
+            trajs[j] = np.array(tr[1:])
             success[m] = valid[m] = exact[m] = True
             if cfg.interpolation:
-                start = cur_h[m]
-                for i in range(len(trajs[m])):
-                    diff = trajs[m][i] - start
+                start = cur_h[j]
+                for i in range(len(trajs[j])):
+                    diff = trajs[j][i] - start
                     if np.any(diff[:n] < -cfg.ac_scale) or np.any(diff[:n] > cfg.ac_scale):
-                        seg_jobs.append((m, i, start, trajs[m][i]))
-                    start = trajs[m][i]
+                        seg_jobs.append((j, i, start, trajs[j][i]))
+                    start = trajs[j][i]
         if seg_jobs:
             self._densify(trajs, seg_jobs, cur_h, ids_h)
-        return trajs, success, interpolation, valid, exact
+        if trajs:
+            L = max(traj_t.shape[1], max(len(tr) for tr in trajs.values()))
+            if L > traj_t.shape[1]:
+                traj_t = torch.cat([traj_t, torch.zeros(M, L - traj_t.shape[1], self.nq, dtype=traj_t.dtype, device=traj_t.device)], dim=1)
+            js = sorted(trajs)
+            pad = np.zeros((len(js), L, self.nq))
+            ln = np.zeros(len(js), dtype=np.int64)
+            for r, j in enumerate(js):
+                pad[r, :len(trajs[j])] = trajs[j]
+                ln[r] = len(trajs[j])
+            rows = torch.as_tensor(fail[js], device=cur.device)
+            traj_t[rows] = torch.as_tensor(pad, device=cur.device)
+            lens[rows] = torch.as_tensor(ln, device=cur.device)
+        return traj_t, lens, success, interpolation, valid, exact
 
     def _densify(self, trajs, seg_jobs, cur_h, ids_h):
         """:210-233 -- every planner-path segment longer than ac_scale in some joint is replaced by
@@ -282,6 +299,20 @@ class BatchMoPARollout:
         torch = _torch()
         env, cfg, E, n = self.env, self.cfg, self.E, self.n
         dev = env.device
+        tm = getattr(self, "timing", None)     # optional dict: phase -> seconds (each mark synchronises; profiling only)
+        if tm is not None:
+            import time as _time
+            torch.cuda.synchronize()
+            _t = [_time.perf_counter()]
+
+            def mark(name):
+                torch.cuda.synchronize()
+                now = _time.perf_counter()
+                tm[name] = tm.get(name, 0.0) + now - _t[0]
+                _t[0] = now
+        else:
+            def mark(name):
+                pass
         a = ac[:, :n].contiguous()
         prev_ob = env.obs.clone()
         cur = env.qpos.clone()
@@ -301,12 +332,14 @@ class BatchMoPARollout:
                 target, _, tv = handle_invalid_target_batch(self.bp, cur[pl_idx], target, cfg.step_size, cfg.num_trials)
             else:
                 tv = self._valid(target)
+            mark("target")
             v_idx = torch.nonzero(tv).flatten()
             self.counters["mp_fail"][pl_idx[~tv]] += 1          # invalid target: success, valid, exact = False, False, True
             self.counters["invalid"][pl_idx[~tv]] += 1
             if len(v_idx):
                 ids = pl_idx[v_idx].contiguous()
-                trajs, success, interpolation, valid, exact = self.plan(cur[ids].contiguous(), target[v_idx].contiguous(), ids)
+                traj_dev, lens_dev, success, interpolation, valid, exact = self.plan(cur[ids].contiguous(), target[v_idx].contiguous(), ids)
+                mark("plan")
                 t = lambda x: torch.as_tensor(x, device=dev)
                 s_t = t(success)
                 plan_ok[ids] = s_t
@@ -315,17 +348,12 @@ class BatchMoPARollout:
                 self.counters["mp_fail"][ids[~s_t]] += 1
                 self.counters["approximate"][ids[~s_t & ~t(exact)]] += 1
                 self.counters["invalid"][ids[~s_t & ~t(valid)]] += 1
-                L = max((len(tr) for tr, s in zip(trajs, success) if s), default=0)
+                L = int(lens_dev.max().item())
                 if L:
-                    pad = np.zeros((len(ids), L, self.nq))
-                    lens = np.zeros(len(ids), dtype=np.int64)
-                    for m, (tr, s) in enumerate(zip(trajs, success)):
-                        if s:
-                            pad[m, :len(tr)] = tr
-                            lens[m] = len(tr)
                     traj_pad = torch.zeros(E, L, self.nq, dtype=torch.float64, device=dev)
-                    traj_pad[ids] = t(pad)
-                    path_len[ids] = t(lens)
+                    traj_pad[ids] = traj_dev[:, :L]
+                    path_len[ids] = lens_dev
+        mark("pad")
         direct = ~is_pl
         self.counters["rl"][direct] += 1
         # ---- direct execution (:336-356) and failed plans (:303-334: reward of the current state, one env step) in one launch
@@ -361,6 +389,7 @@ class BatchMoPARollout:
                     rec["done"][:, k] = torch.where(active, env.done, rec["done"][:, k])
                     rec["n_exec"] += active.to(torch.int64)
                 alive = alive & ~(active & env.done.bool())      # `if done or ep_len >= max_step: break`
+        mark("execute")
         env.has_prev.zero_()                                     # env._reset_prev_state()
         self.t += 1
         del ar

@@ -23,6 +23,8 @@
  *     resolution KinematicPlanner.cpp:87)
  *   KinematicPlanner::plan(start, goal, timelimit)   mopa_plan()                (1 query, host ptrs)
  *     KinematicPlanner.cpp:125-251 (RRTConnect)      mopa_plan_batch()          (E queries, device ptrs)
+ *   invalid-target back-off of the rollout runner    mopa_pullback_batch()      (E targets, device ptrs)
+ *     rl/mopa_rollouts.py:133-143
  *   KinematicPlanner::getPlannerStatus()             mopa_planner_status()
  *     KinematicPlanner.cpp:288-291
  *
@@ -154,6 +156,14 @@ int mopa_check_motion_batch(MopaScene *scene, const double *qa_dev /*[N,na]*/, c
 int mopa_plan_batch(MopaScene *scene, const double *start_dev /*[E,nq]*/, const double *goal_dev /*[E,nq]*/, int64_t E,
                     const MopaPlanParams *params, double *path_dev /*[E,max_path,nq]*/, int32_t *path_len_dev /*[E]*/,
                     int32_t *status_dev /*[E]*/, int64_t *n_checks_dev /*[E] or NULL*/, void *stream);
+
+/* The rollout's invalid-target back-off (rl/mopa_rollouts.py:133-143) for E envs in one launch: while target[e] (a full
+ * qpos row, validated with its own passive entries) is invalid and fewer than num_trials steps were taken,
+ *   target[e] += step_size * (cur[e] - target[e]) / ||cur[e] - target[e]||   (Euclidean norm over all nq entries, squares
+ * summed left to right).  target is updated in place; n_trials[e] = steps taken, valid[e] = verdict of the final row. */
+int mopa_pullback_batch(MopaScene *scene, const double *cur_dev /*[E,nq]*/, double *target_dev /*[E,nq] in/out*/, int64_t E,
+                        double step_size, int32_t num_trials, int32_t *n_trials_dev /*[E]*/, uint8_t *valid_dev /*[E]*/,
+                        void *stream);
 
 /* ---- single-query convenience forms: what PyKinematicPlanner binds (host pointers, synchronous) ---- */
 int mopa_is_valid_state(MopaScene *scene, const double *qpos_host /*[nq]*/, int32_t *valid_out, double *min_dist_out /*nullable*/);

@@ -25,7 +25,7 @@ _ip = C.POINTER(C.c_int32)
 EXPORTED_SYMBOLS = [
     "mopa_last_error", "mopa_version", "mopa_device_count", "mopa_scene_create", "mopa_scene_destroy",
     "mopa_scene_num_active", "mopa_scene_active_idx", "mopa_scene_num_pairs", "mopa_scene_lds_bytes",
-    "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_is_valid_state", "mopa_plan",
+    "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_step_batch", "mopa_env_desired_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch",
@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
     L.mopa_is_valid_batch.argtypes = [vp, vp, vp, C.c_int64, C.c_int64, vp, vp, vp]
     L.mopa_check_motion_batch.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, vp, vp]
     L.mopa_plan_batch.argtypes = [vp, vp, vp, C.c_int64, C.POINTER(MopaPlanParams), vp, vp, vp, vp, vp]
+    L.mopa_pullback_batch.argtypes = [vp, vp, vp, C.c_int64, C.c_double, C.c_int32, vp, vp, vp]
     L.mopa_is_valid_state.argtypes = [vp, _dp, C.POINTER(C.c_int32), _dp]
     L.mopa_plan.argtypes = [vp, _dp, _dp, C.POINTER(MopaPlanParams), _dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                             C.POINTER(C.c_int64)]

@@ -91,3 +91,17 @@ class BatchPlanner:
         _lib.check(_lib.lib().mopa_plan_batch(self.scene.handle, _ptr(start), _ptr(goal), E, C.byref(prm), _ptr(path),
                                               _ptr(plen), _ptr(status), _ptr(nchk), _stream_handle(stream)))
         return path, plen, status, nchk
+
+    def pullback(self, cur, target, step_size: float, num_trials: int, stream=None):
+        """The rollout's invalid-target back-off (rl/mopa_rollouts.py:133-143) for E envs in one launch.
+        cur / target: [E, nq] float64 GPU tensors.  Returns (target' [E, nq], n_trials [E] int32, valid [E] uint8)."""
+        torch = _torch()
+        _check_f64(cur, "cur", self.nq)
+        _check_f64(target, "target", self.nq)
+        E = cur.shape[0]
+        out = target.clone()
+        trials = torch.zeros(E, dtype=torch.int32, device=cur.device)
+        valid = torch.zeros(E, dtype=torch.uint8, device=cur.device)
+        _lib.check(_lib.lib().mopa_pullback_batch(self.scene.handle, _ptr(cur), _ptr(out), E, float(step_size), int(num_trials),
+                                                  _ptr(trials), _ptr(valid), _stream_handle(stream)))
+        return out, trials, valid

@@ -1151,5 +1151,6 @@ extern "C" const char *mopa_planner_status(const MopaScene *S) { return S ? S->s
 
 // The planner entry points are defined in mopa_planner.inc (K3).
 #include "mopa_planner.inc"
+#include "mopa_pullback.inc"
 #include "mopa_env.inc"
 #include "mopa_ik.inc"

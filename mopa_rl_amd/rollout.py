@@ -329,7 +329,8 @@ class BatchMoPARollout:
             # np.clip to the joint limits, unlimited entries restored (:121-131)
             target = torch.where(self._lim, torch.minimum(torch.maximum(target, self._lo), self._hi), target)
             if cfg.invalid_target_handling:
-                target, _, tv = handle_invalid_target_batch(self.bp, cur[pl_idx], target, cfg.step_size, cfg.num_trials)
+                target, _, tv = self.bp.pullback(cur[pl_idx].contiguous(), target.contiguous(), cfg.step_size, cfg.num_trials)
+                tv = tv.bool()
             else:
                 tv = self._valid(target)
             mark("target")

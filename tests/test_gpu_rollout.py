@@ -211,3 +211,34 @@ def test_reuse_data_relabelling(oracle_mod):
     assert [(t["env"], t["start"], t["goal"], t["rew"], t["intra_steps"]) for t in got] == want and len(got) > 5
     for t in got[:20]:
         assert np.array_equal(t["ob"], ob[t["env"], t["start"]]) and np.array_equal(t["ob_next"], ob[t["env"], t["goal"]])
+
+
+def test_pullback_kernel_equals_host_form(oracle_mod):
+    """`mopa_pullback_batch` (one launch) against `handle_invalid_target_batch` (torch ops + one validity launch per
+    trial, itself the batched form of rl/mopa_rollouts.py:133-143): same targets, trial counts and verdicts, bit for bit."""
+    import torch
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.agent_planning import handle_invalid_target_batch
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import default_qpos, planner_inputs
+    pi = planner_inputs(ENV)
+    sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+    bp = BatchPlanner(sc)
+    E = 300
+    rng = np.random.default_rng(2)
+    q0 = default_qpos(ENV, pi.model)
+    cur = np.repeat(q0[None], E, axis=0)
+    cur[:, :7] += rng.normal(0, 0.05, size=(E, 7))
+    tgt = cur.copy()
+    tgt[:, :7] += rng.uniform(-1.0, 1.0, size=(E, 7)) * rng.choice([0.3, 1.0, 2.0], size=(E, 1))
+    tgt[:, :7] = np.clip(tgt[:, :7], pi.jnt_minimum, pi.jnt_maximum)
+    tgt[0] = cur[0]                                   # degenerate: target == current state
+    c, t = torch.tensor(cur, device="cuda"), torch.tensor(tgt, device="cuda")
+    for num_trials in (100, 3):
+        want_t, want_n, want_v = handle_invalid_target_batch(bp, c, t, 0.02, num_trials)
+        got_t, got_n, got_v = bp.pullback(c, t, 0.02, num_trials)
+        assert np.array_equal(got_v.cpu().numpy().astype(bool), want_v.cpu().numpy())
+        assert np.array_equal(got_n.cpu().numpy().astype(np.int64), want_n.cpu().numpy())
+        assert np.array_equal(_bits(got_t.cpu().numpy()), _bits(want_t.cpu().numpy()))
+    n = want_n.cpu().numpy()
+    assert (n > 0).sum() > 30 and (~want_v.cpu().numpy()).sum() >= 0 and n.max() == 3

@@ -233,6 +233,23 @@ int mopa_env_step_batch(MopaEnv *env, int64_t E, double *qpos_dev /*[E,nq] in/ou
                         const uint8_t *move_mask_dev /*[E] or NULL*/, double *obs_dev /*[E,40]*/,
                         double *reward_dev /*[E]*/, uint8_t *done_dev /*[E]*/, uint8_t *success_dev /*[E]*/, void *stream);
 
+/* Waypoint execution of the rollout runner (rl/mopa_rollouts.py:152-199) for E envs in ONE launch: env e steps through
+ * traj[e, 0 .. path_len[e]-1] (full qpos rows; the action of step k is env.form_action(waypoint) = waypoint - current arm
+ * state, is_planner semantics of mopa_env_step_batch) until its path ends or a step reports done, with
+ *   smdp_rew[e] += disc_pow[k] * reward_k   (disc_pow[k] = discount_factor^k, supplied by the caller),
+ *   smdp_done[e] = done_k, intra[e] = k for the last step taken.  Envs with path_len[e] == 0 are not touched.
+ * rec_* (all four or none): per executed waypoint the obs after the step, the running return and the done flag, and
+ * n_exec[e] = steps taken -- the reference's ob_list / meta_rew_list / done_list (input of its reuse_data relabelling).
+ * obs / reward / done / success hold the env's last step afterwards, exactly as after that many mopa_env_step_batch calls. */
+int mopa_env_exec_batch(MopaEnv *env, int64_t E, double *qpos_dev /*[E,nq] in/out*/, double *prev_state_dev /*[E,n_arm] in/out*/,
+                        uint8_t *has_prev_dev /*[E] in/out*/, int32_t *ep_len_dev /*[E] in/out*/,
+                        const double *traj_dev /*[E,L,nq]*/, const int64_t *path_len_dev /*[E]*/, int32_t L,
+                        const double *disc_pow_dev /*[L]*/, double *obs_dev /*[E,40]*/, double *reward_dev /*[E]*/,
+                        uint8_t *done_dev /*[E]*/, uint8_t *success_dev /*[E]*/, double *smdp_rew_dev /*[E] in/out*/,
+                        uint8_t *smdp_done_dev /*[E] in/out*/, int64_t *intra_dev /*[E] in/out*/,
+                        double *rec_ob_dev /*[E,L,40] or NULL*/, double *rec_rew_dev /*[E,L] or NULL*/,
+                        uint8_t *rec_done_dev /*[E,L] or NULL*/, int64_t *n_exec_dev /*[E] or NULL*/, void *stream);
+
 /* The limit-clamped arm state the NEXT mopa_env_step_batch call with the same arguments would command
  * (desired_state of sawyer_push_obstacle.py:186), without stepping: input of a collision gate
  * (mopa_is_valid_batch with samples_per_env = 1 -> move_mask). */

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "mopa_scene_num_active", "mopa_scene_active_idx", "mopa_scene_num_pairs", "mopa_scene_lds_bytes",
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
-    "mopa_env_create", "mopa_env_destroy", "mopa_env_step_batch", "mopa_env_desired_batch",
+    "mopa_env_create", "mopa_env_destroy", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch",
 ]
 
@@ -123,6 +123,7 @@ def lib() -> C.CDLL:
     L.mopa_env_destroy.argtypes = [vp]
     L.mopa_env_destroy.restype = None
     L.mopa_env_step_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.mopa_env_exec_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mopa_env_desired_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp, vp]
     L.mopa_ik_create.argtypes = [C.POINTER(MopaIkDesc), C.POINTER(vp)]
     L.mopa_ik_destroy.argtypes = [vp]

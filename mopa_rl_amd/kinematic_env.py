@@ -173,6 +173,19 @@ class BatchKinematicPushEnv:
             _ptr(move_mask) if move_mask is not None else None, _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
             _ptr(self.success), _stream_handle(stream)))
 
+    def exec_trajectories(self, traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec=None, stream=None):
+        """Waypoint execution of the rollout (rl/mopa_rollouts.py:152-199) in one launch: env e steps through
+        traj[e, :path_len[e]] ([E, L, nq] f64, [E] int64) until its path ends or a step reports done; smdp_rew [E] f64,
+        smdp_done [E] uint8 and intra [E] int64 are updated in place (disc_pow [L] f64 = discount^k).  rec: optional dict
+        with 'ob' [E,L,40] f64, 'meta_rew' [E,L] f64, 'done' [E,L] uint8, 'n_exec' [E] int64 filled per executed waypoint."""
+        L = int(traj.shape[1])
+        r = rec or {}
+        p = lambda k: _ptr(r[k]) if k in r else None
+        _lib.check(_lib.lib().mopa_env_exec_batch(
+            self._h, self.E, _ptr(self.qpos), _ptr(self.prev_state), _ptr(self.has_prev), _ptr(self.ep_len), _ptr(traj),
+            _ptr(path_len), L, _ptr(disc_pow), _ptr(self.obs), _ptr(self.reward), _ptr(self.done), _ptr(self.success),
+            _ptr(smdp_rew), _ptr(smdp_done), _ptr(intra), p("ob"), p("meta_rew"), p("done"), p("n_exec"), _stream_handle(stream)))
+
     # ------------------------------------------------------------------
     def reset(self, mask=None):
         """`_reset` of the reference (sawyer_push_obstacle.py:36-52): arm = init_qpos + N(0, 0.02^2), target sliders

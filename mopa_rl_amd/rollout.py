@@ -374,22 +374,12 @@ class BatchMoPARollout:
                    "waypoint": traj_pad if traj_pad is not None else torch.zeros(E, 0, self.nq, dtype=torch.float64, device=dev),
                    "n_exec": torch.zeros(E, dtype=torch.int64, device=dev)}
         if traj_pad is not None:
-            alive = plan_ok.clone()
-            for k in range(traj_pad.shape[1]):
-                active = alive & (k < path_len)
-                if not bool(active.any().item()):
-                    break
-                act_k = (traj_pad[:, k, :n] - env.qpos[:, :n]).contiguous()          # env.form_action(next_qpos)
-                env._launch(act_k, True, torch.where(active, 1, 2).to(torch.uint8).contiguous())
-                rew = torch.where(active, rew + (cfg.discount_factor ** k) * env.reward, rew)
-                done = torch.where(active, env.done, done)
-                intra = torch.where(active, torch.full_like(intra, k), intra)
-                if rec is not None:
-                    rec["ob"][:, k] = torch.where(active[:, None], env.obs, rec["ob"][:, k])
-                    rec["meta_rew"][:, k] = torch.where(active, rew, rec["meta_rew"][:, k])
-                    rec["done"][:, k] = torch.where(active, env.done, rec["done"][:, k])
-                    rec["n_exec"] += active.to(torch.int64)
-                alive = alive & ~(active & env.done.bool())      # `if done or ep_len >= max_step: break`
+            # one launch: every env walks its own waypoints until its path ends or a step reports done
+            L = traj_pad.shape[1]
+            disc = torch.tensor([cfg.discount_factor ** k for k in range(L)], dtype=torch.float64, device=dev)
+            rew, done = rew.contiguous(), done.to(torch.uint8).contiguous()
+            env.exec_trajectories(traj_pad, torch.where(plan_ok, path_len, torch.zeros_like(path_len)).contiguous(), disc,
+                                  rew, done, intra, rec={k: rec[k] for k in ("ob", "meta_rew", "done", "n_exec")} if rec else None)
         mark("execute")
         env.has_prev.zero_()                                     # env._reset_prev_state()
         self.t += 1

@@ -199,24 +199,29 @@ class BatchMoPARollout:
         interpolation[fail] = False
         trajs = {}             # j (index into `fail`) -> [L_j, nq] numpy
         seg_jobs = []          # (j, i, start, end) of planner-path segments that need densification
-        for j, m in enumerate(fail):
-            if st_h[j] != 0:   # sentinel rows (sampling_based_planner.py:64-69): -5 goal invalid, -4 no exact solution
-                valid[m], exact[m], success[m] = st_h[j] != _lib.PLAN_INVALID_GOAL, st_h[j] != _lib.PLAN_NO_EXACT, False
-                continue
-            states = path_h[j, :plen_h[j]]
-            # SamplingBasedPlanner.plan: trajectory rebuilt from successive differences (:71-99), PlannerAgent drops row 0
-            tr = [cur_h[j]]
-            for s in range(1, len(states)):
-                tr.append(tr[-1] + (states[s] - states[s - 1]))
-            trajs[j] = np.array(tr[1:])
-            success[m] = valid[m] = exact[m] = True
+        bad = st_h != 0        # sentinel rows (sampling_based_planner.py:64-69): -5 goal invalid, -4 no exact solution
+        valid[fail[bad]] = st_h[bad] != _lib.PLAN_INVALID_GOAL
+        exact[fail[bad]] = st_h[bad] != _lib.PLAN_NO_EXACT
+        success[fail[bad]] = False
+        good = np.where(~bad)[0]
+        if len(good):
+            success[fail[good]] = valid[fail[good]] = exact[fail[good]] = True
+            # SamplingBasedPlanner.plan rebuilds the trajectory from successive differences (:71-99) and PlannerAgent
+            # drops row 0: tr[k] = tr[k-1] + (states[k] - states[k-1]), tr[0] = cur.  np.add.accumulate is that same
+            # strictly sequential sum, for all paths at once (rows past a path's length hold garbage and are cut off).
+            P = path_h[good]
+            A = np.concatenate([cur_h[good][:, None, :], P[:, 1:] - P[:, :-1]], axis=1)
+            T = np.add.accumulate(A, axis=1)
+            nrow = plen_h[good] - 1
             if cfg.interpolation:
-                start = cur_h[j]
-                for i in range(len(trajs[j])):
-                    diff = trajs[j][i] - start
-                    if np.any(diff[:n] < -cfg.ac_scale) or np.any(diff[:n] > cfg.ac_scale):
-                        seg_jobs.append((j, i, start, trajs[j][i]))
-                    start = trajs[j][i]
+                step = T[:, 1:, :n] - T[:, :-1, :n]                      # waypoint i minus its predecessor (cur for i = 0)
+                far = ((step < -cfg.ac_scale) | (step > cfg.ac_scale)).any(axis=2)
+                far &= np.arange(far.shape[1])[None, :] < nrow[:, None]
+            for r, j in enumerate(good):
+                trajs[j] = T[r, 1:nrow[r] + 1].copy()
+                if cfg.interpolation:
+                    for i in np.nonzero(far[r])[0]:
+                        seg_jobs.append((j, int(i), T[r, i].copy(), trajs[j][i]))
         if seg_jobs:
             self._densify(trajs, seg_jobs, cur_h, ids_h)
         if trajs:

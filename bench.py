@@ -100,7 +100,7 @@ def plan_section(torch, bp, pi, E, device):
     inside, the headline metric."""
     import time as _t
     start, goal = planner_queries(torch, bp, pi, E, device)
-    prm = dict(max_iters=2000, max_nodes=1024, max_path=256, seed=7)
+    prm = dict(max_iters=2000, max_nodes=4096, max_path=256, seed=7)
     bp.plan(start, goal, **prm)
     torch.cuda.synchronize()
     reps = 3

@@ -10,7 +10,7 @@ pi = planner_inputs(bench.ENV)
 sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
 bp = BatchPlanner(sc)
 start, goal = bench.planner_queries(torch, bp, pi, 4096, torch.device("cuda:0"))
-path, plen, st, nchk = bp.plan(start, goal, max_iters=2000, max_nodes=1024, max_path=256, seed=7)
+path, plen, st, nchk = bp.plan(start, goal, max_iters=2000, max_nodes=4096, max_path=256, seed=7)
 n = nchk.cpu().numpy(); st = st.cpu().numpy()
 chk, npass, nst, n0, n1 = n & 0xffff, (n >> 16) & 0x3fff, (n >> 30) & 0x3fff, (n >> 44) & 0x3ff, (n >> 54) & 0x3ff
 for name, m in (("fail", st != 0), ("ok", st == 0)):
@@ -24,7 +24,7 @@ if hasattr(lib, "mopa_debug_plan_times"):
     buf = (ctypes.c_ulonglong * 40)()
     lib.mopa_debug_plan_times(buf, 1)
     fi = torch.nonzero(torch.tensor(st != 0)).flatten().to(start.device)
-    bp.plan(start[fi].contiguous(), goal[fi].contiguous(), max_iters=2000, max_nodes=1024, max_path=256, seed=7, env_ids=fi.contiguous())
+    bp.plan(start[fi].contiguous(), goal[fi].contiguous(), max_iters=2000, max_nodes=4096, max_path=256, seed=7, env_ids=fi.contiguous())
     lib.mopa_debug_plan_times(buf, 1)
     t = list(buf); n = len(fi)
     print("failing envs only: per env, 100 MHz ticks -> us: pose+fk %.0f broad %.0f narrow %.0f | survivors/pass %.1f states/pass %.2f passes %d" % (

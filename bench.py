@@ -193,31 +193,42 @@ def env_step_section(torch, pi, E, device, steps, with_cpu):
 
 
 def rollout_section(torch, pi, E, device, agent_steps):
-    """End-to-end MoPA rollout step (mopa_rl_amd/rollout.py): random policy actions -> per env either a direct env step or
-    target / pull-back / straight-line pre-check / RRT-Connect / densification / waypoint execution on the kinematic
-    env.  Host-orchestrated (torch + numpy for the ragged planner paths), every check / plan / env step a batched launch."""
+    """End-to-end MoPA rollout step (mopa_rl_amd/rollout.py), SURVEY 8d config 3: a SAC actor (stock PyTorch, random-init
+    40-256-256-256-(7+7) MLP, f32; a = tanh(mu + sigma * eps)) samples the action from the obs inside the timed loop,
+    then per env either a direct env step or target / pull-back / straight-line pre-check / RRT-Connect / densification /
+    waypoint execution on the kinematic env.  Host-orchestrated; every check / plan / env step a batched launch."""
     from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
     from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
     env = BatchKinematicPushEnv(E, device=device, seed=21, max_episode_steps=250)
     env.reset()
     ro = BatchMoPARollout(env, RolloutConfig())
+    torch.manual_seed(8)
+    nn = torch.nn
+    actor = nn.Sequential(nn.Linear(env.obs.shape[1], 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
+                          nn.Linear(256, 14)).to(device)
     g = torch.Generator(device=device)
     g.manual_seed(8)
-    acts = torch.rand(agent_steps + 1, E, 7, generator=g, dtype=torch.float64, device=device) * 2 - 1
-    out = ro.agent_step(acts[0])
+
+    def act():
+        with torch.no_grad():
+            mu, log_std = actor(env.obs.float()).chunk(2, dim=1)
+            eps = torch.randn(E, 7, generator=g, dtype=torch.float32, device=device)
+            return torch.tanh(mu + torch.exp(log_std.clamp(-10.0, 2.0)) * eps).double()
+    out = ro.agent_step(act())
     env.reset(out["done"].bool())
     torch.cuda.synchronize()
     n_env_steps = 0
     t0 = time.perf_counter()
     for t in range(agent_steps):
-        out = ro.agent_step(acts[1 + t])
+        out = ro.agent_step(act())
         n_env_steps += int((out["intra_steps"] + 1).sum().item())
         if bool(out["done"].any().item()):
             env.reset(out["done"].bool())
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c = {k: int(v.sum().item()) for k, v in ro.counters.items()}
-    return {"config": f"{ENV}, {E} envs, {agent_steps} agent steps of uniform random actions in [-1,1]^7 (omega 0.7), kinematic env",
+    return {"config": f"{ENV}, {E} envs, {agent_steps} agent steps; actions sampled by a random-init SAC actor (40-256-256-256-14 MLP, "
+                      "f32, tanh-Gaussian) from the obs (omega 0.7), kinematic env",
             "agent_steps_per_s": E * agent_steps / dt, "env_steps_per_s": n_env_steps / dt, "s_per_agent_step_batch": dt / agent_steps,
             "counters": c}
 

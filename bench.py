@@ -321,29 +321,21 @@ def main():
     N = E * S
     qa, rows = make_inputs(torch, pi, E, S, seed=1234 + rank, device=device, mode=args.mode)
     # Double-buffered verdict masks: the RCCL all-gather of step k (on RCCL's own stream) overlaps the validity kernel of
-    # step k+1; a buffer is only reused after the collective that reads it has completed.
-    valid2 = [torch.empty(N, dtype=torch.uint8, device=device) for _ in range(2)]
-    gathered2 = [torch.empty(world * N, dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
-    pending = [None, None]
+    # step k+1; a buffer is only reused after the collective that reads it has completed (mopa_rl_amd/dist.py).
+    from mopa_rl_amd.dist import OverlappedGather
+    og = OverlappedGather(N, torch.uint8, device)
 
     def step(k, events=None):
-        b = k & 1
-        if pending[b] is not None:
-            pending[b].wait()          # the current stream waits for the collective that still reads valid2[b]
-            pending[b] = None
+        out_k = og.buffer(k)
         if events is not None:
             events[0].record()
-        bp.is_valid(qa, rows, samples_per_env=S, out=valid2[b])
+        bp.is_valid(qa, rows, samples_per_env=S, out=out_k)
         if events is not None:
             events[1].record()
-        if world > 1:
-            pending[b] = dist.all_gather_into_tensor(gathered2[b], valid2[b], async_op=True)
+        og.launch(k)
 
     def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+        og.drain()
 
     def barrier():
         drain()
@@ -367,7 +359,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    valid = valid2[(args.steps - 1) & 1] if args.steps > 0 else valid2[0]
+    valid = og.local[(args.steps - 1) & 1] if args.steps > 0 else og.local[0]
 
     n_valid = int(valid.sum().item())
     if rank == 0:

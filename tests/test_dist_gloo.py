@@ -86,3 +86,48 @@ def test_shard_range_partition():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         shard_range(4, 2, 2)
+
+
+def _og_worker(rank, world, port, n, steps, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from mopa_rl_amd.dist import OverlappedGather
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    og = OverlappedGather(n, torch.uint8, torch.device("cpu"))
+    seen = []
+    for k in range(steps):
+        buf = og.buffer(k)                       # safe to overwrite: the gather of step k-2 has completed
+        buf.copy_(torch.full((n,), (17 * k + 3 * rank) % 251, dtype=torch.uint8))
+        og.launch(k)
+        if k >= 1:
+            seen.append(og.result(k - 1).clone())   # consume step k-1 while step k's collective is in flight
+    seen.append(og.result(steps - 1).clone())
+    og.drain()
+    if rank == 0:
+        q.put(torch.stack(seen).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_gather_double_buffering():
+    """bench.py's per-step exchange (mopa_rl_amd/dist.py::OverlappedGather) on 2 gloo ranks: every step's gathered masks
+    are that step's values from both ranks, although buffers are reused every second step."""
+    import torch.multiprocessing as mp
+    world, n, steps = 2, 1000, 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_og_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got.shape == (steps, world * n)
+    for k in range(steps):
+        for r in range(world):
+            assert (got[k, r * n:(r + 1) * n] == (17 * k + 3 * r) % 251).all(), (k, r)

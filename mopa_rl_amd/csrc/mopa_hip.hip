@@ -903,7 +903,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
             h.v5_ent_cap = cap;
             S->v5_lds_bytes = fixed + kWavesPerBlock * v5_lds_per_wave(nmg, cap);
             if (std::getenv("MOPA_DEBUG"))
-                fprintf(stderr, "[mopa] scene: nmg %d nmb %d pairs %d (+%d mesh) lds: wave-per-state %d, v2 %d, v5 %d (entry cap %d, fixed %d)\n", nmg, nmb,
+                fprintf(stderr, "[mopa] scene: nmg %d nmb %d save slots %d pairs %d (+%d mesh) lds: wave-per-state %d, v2 %d, v5 %d (entry cap %d, fixed %d)\n", nmg, nmb, n_save,
                         (int)gp_word.size(), (int)gp_word_mesh.size(), S->lds_bytes, S->v2_lds_bytes, S->v5_lds_bytes, cap, fixed);
         }
         // third generation (FP32 broad phase out of LDS): default wherever it applies; MOPA_VALID_KERNEL=v2 keeps the second

@@ -95,7 +95,33 @@ def planner_queries(torch, bp, pi, E, device):
     return start, goal
 
 
-def plan_section(torch, bp, pi, E, device):
+def plan_cpu_baseline(pi, start_h, goal_h, prm, status, plen, nchk, n_sample=1024):
+    """The oracle's RRT-Connect (kind="port") on the first n_sample queries: one thread, then a thread pool over queries on
+    the cores this process may use (ctypes calls release the GIL).  Also the parity check of those queries."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+    orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    n = min(n_sample, len(start_h))
+
+    def one(e):
+        st, path, chk, _ = orc.plan(start_h[e], goal_h[e], pi.spec.range, 0.005, prm["max_iters"], prm["max_nodes"], seed=prm["seed"],
+                                    env_id=e, max_path=prm["max_path"])
+        return st, len(path), chk
+    t0 = time.perf_counter()
+    res = [one(e) for e in range(n)]
+    t1 = time.perf_counter()
+    cores = host_cores()
+    with ThreadPoolExecutor(cores) as ex:
+        list(ex.map(one, range(n)))
+    t2 = time.perf_counter()
+    mism = sum(1 for e, (st, ln, chk) in enumerate(res) if st != status[e] or ln != plen[e] or chk != nchk[e])
+    return {"value": n / (t2 - t1), "unit": "plans/s", "cores": cores, "kind": "port", "single_thread_value": n / (t1 - t0),
+            "sample": f"the first {n} of the same queries through the oracle's orc_plan (same sample streams), one thread / a "
+                      f"pool of {cores} threads over queries; our C restatement, not OMPL",
+            "parity_mismatches_vs_oracle": mism}
+
+
+def plan_section(torch, bp, pi, E, device, with_cpu=True):
     """BASELINE.json configs[2]: E envs, each one RRT-Connect query (K3, one wave per env).  Reported next to, not
     inside, the headline metric."""
     import time as _t
@@ -109,11 +135,15 @@ def plan_section(torch, bp, pi, E, device):
         path, plen, status, nchk = bp.plan(start, goal, **prm)
     torch.cuda.synchronize()
     dt = (_t.perf_counter() - t0) / reps
-    return {"config": f"{ENV}, {E} envs, one RRT-Connect query each (range {pi.spec.range}, resolution 0.005, "
-                      f"{prm['max_iters']} iterations, {prm['max_nodes']} nodes/tree)",
-            "plans_per_s": E / dt, "ms_per_batch": dt * 1e3, "consumed_checks_per_s": float(nchk.sum().item()) / dt,
-            "success_rate": float((status == 0).float().mean().item()), "mean_path_len": float(plen.float().mean().item()),
-            "mean_checks_per_plan": float(nchk.float().mean().item())}
+    out = {"config": f"{ENV}, {E} envs, one RRT-Connect query each (range {pi.spec.range}, resolution 0.005, "
+                     f"{prm['max_iters']} iterations, {prm['max_nodes']} nodes/tree)",
+           "plans_per_s": E / dt, "ms_per_batch": dt * 1e3, "consumed_checks_per_s": float(nchk.sum().item()) / dt,
+           "success_rate": float((status == 0).float().mean().item()), "mean_path_len": float(plen.float().mean().item()),
+           "mean_checks_per_plan": float(nchk.float().mean().item())}
+    if with_cpu:
+        out["cpu_baseline"] = plan_cpu_baseline(pi, start.cpu().numpy(), goal.cpu().numpy(), prm, status.cpu().numpy(),
+                                                plen.cpu().numpy(), nchk.cpu().numpy())
+    return out
 
 
 def motion_section(torch, bp, pi, qa, rows, S, device):
@@ -398,7 +428,7 @@ def main():
                                            "note": "SQ_INSTS_VALU from the committed PMC pass / live kernel time"}
         if not args.no_plan and world == 1:
             out["motion"] = motion_section(torch, bp, pi, qa, rows, S, device)
-            out["planner"] = plan_section(torch, bp, pi, args.plan_envs, device)
+            out["planner"] = plan_section(torch, bp, pi, args.plan_envs, device, not args.no_cpu)
         if not args.no_env and world == 1:
             out["env_step"] = env_step_section(torch, pi, args.envs, device, 50, not args.no_cpu)
         if not args.no_env and world == 1:

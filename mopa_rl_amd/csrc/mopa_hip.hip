@@ -120,6 +120,7 @@ struct MopaScene {
     size_t mv_cap_seg = 0, mv_cap_states = 0, mv_scan_bytes = 0;
     int v5_lds_bytes = 0;
     int use_v5 = 0;
+    bool v5_cen_lds = true;   // FP32 centre table of a tile in LDS (false: read back from the pose slab; scenes with many moving geoms)
     bool v2_forced = false;   // MOPA_VALID_KERNEL=v2: lane-per-state kernel for every N >= 64 (tests, A/B runs)
     // planner workspace (mopa_planner.inc): both trees of every env, grown on demand
     double *plan_tree_q = nullptr;
@@ -895,16 +896,31 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         S->use_v2 = !(ev && std::string(ev) == "v1") && S->v2_lds_bytes <= kMaxLdsBytes;
         S->v2_forced = ev && std::string(ev) == "v2";
         {
-            // largest entry buffer (multiple of 64, 256..1024) that still lets two workgroups share a CU's 160 KiB of LDS
+            // largest entry buffer (multiple of 64, 256..1024) that still lets two workgroups share a CU's 160 KiB of LDS;
+            // if even the smallest does not fit with the FP32 centre table in LDS, the centres are read back from the slab
             const int fixed = h.n_dbl * 8 + ((h.n_int + 3) & ~3) * 4 + ((8 * (int)gp_word.size() + nmg + 3) & ~3) * 4;
+            const char *ec = std::getenv("MOPA_V5_CENTRES");       // "lds" / "slab": A/B runs and tests
+            bool cen_lds = true;
             int cap = kEntCapV5Max;
-            while (cap > 256 && fixed + kWavesPerBlock * v5_lds_per_wave(nmg, cap) > 80 * 1024) cap -= 64;
-            if (fixed + kWavesPerBlock * v5_lds_per_wave(nmg, cap) > 80 * 1024) cap = 768;   // one workgroup per CU anyway
+            for (int attempt = 0; attempt < 2; attempt++) {
+                cen_lds = attempt == 0;
+                if (ec && std::string(ec) == "slab") cen_lds = false;
+                const int n_cen = cen_lds ? nmg : 0;
+                cap = kEntCapV5Max;
+                while (cap > 256 && fixed + kWavesPerBlock * v5_lds_per_wave(n_cen, cap) > 80 * 1024) cap -= 64;
+                if (fixed + kWavesPerBlock * v5_lds_per_wave(n_cen, cap) <= 80 * 1024) break;
+                if (ec && std::string(ec) == "lds") break;
+            }
+            if (fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap) > 80 * 1024) {   // one workgroup per CU anyway
+                cap = 768;
+                cen_lds = !(ec && std::string(ec) == "slab");
+            }
+            S->v5_cen_lds = cen_lds;
             h.v5_ent_cap = cap;
-            S->v5_lds_bytes = fixed + kWavesPerBlock * v5_lds_per_wave(nmg, cap);
+            S->v5_lds_bytes = fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap);
             if (std::getenv("MOPA_DEBUG"))
-                fprintf(stderr, "[mopa] scene: nmg %d nmb %d save slots %d pairs %d (+%d mesh) lds: wave-per-state %d, v2 %d, v5 %d (entry cap %d, fixed %d)\n", nmg, nmb, n_save,
-                        (int)gp_word.size(), (int)gp_word_mesh.size(), S->lds_bytes, S->v2_lds_bytes, S->v5_lds_bytes, cap, fixed);
+                fprintf(stderr, "[mopa] scene: nmg %d nmb %d save slots %d pairs %d (+%d mesh) lds: wave-per-state %d, v2 %d, v5 %d (entry cap %d, fixed %d, centres in %s)\n", nmg, nmb, n_save,
+                        (int)gp_word.size(), (int)gp_word_mesh.size(), S->lds_bytes, S->v2_lds_bytes, S->v5_lds_bytes, cap, fixed, cen_lds ? "LDS" : "slab");
         }
         // third generation (FP32 broad phase out of LDS): default wherever it applies; MOPA_VALID_KERNEL=v2 keeps the second
         // ... unless it would get one workgroup per CU where the second generation still gets two (LDS: the FP32 centre
@@ -951,7 +967,8 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
                           (const void *)k_is_valid<true, true>, (const void *)k_check_motion, (const void *)k_debug_state<false>,
                           (const void *)k_debug_state<true>, (const void *)k_is_valid_v2<false, false>,
                           (const void *)k_is_valid_v2<true, false>, (const void *)k_is_valid_v2<false, true>,
-                          (const void *)k_is_valid_v2<true, true>, (const void *)k_is_valid_v5<false>, (const void *)k_is_valid_v5<true>})
+                          (const void *)k_is_valid_v2<true, true>, (const void *)k_is_valid_v5<false, true>, (const void *)k_is_valid_v5<true, true>,
+                          (const void *)k_is_valid_v5<false, false>, (const void *)k_is_valid_v5<true, false>})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
     plan_register_lds();
     *out = S;
@@ -1029,12 +1046,10 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
 #endif
         auto kern = min_dist ? k_is_valid_v2<true, false> : k_is_valid_v2<false, false>;   // main lists carry no mesh pair
         if (S->use_v5) {
-            if (min_dist)
-                hipLaunchKernelGGL(k_is_valid_v5<true>, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active,
-                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx, S->d_mpr);
-            else
-                hipLaunchKernelGGL(k_is_valid_v5<false>, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active,
-                                   qpos_env, (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx, S->d_mpr);
+            auto k5 = S->v5_cen_lds ? (min_dist ? k_is_valid_v5<true, true> : k_is_valid_v5<false, true>)
+                                    : (min_dist ? k_is_valid_v5<true, false> : k_is_valid_v5<false, false>);
+            hipLaunchKernelGGL(k5, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
+                               (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx, S->d_mpr);
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
                            (long long)samples_per_env, valid, min_dist, S->d_slab, 0, env_idx);

@@ -13,23 +13,31 @@ from conftest import SUPPORTED_ENVS, sample_states
 pytestmark = pytest.mark.gpu
 
 
-KERNELS = ["v1", "v2", "v5"]   # K1 generations: wave-per-state / lane-per-state (the library picks by batch size)
+# K1 generations: wave-per-state / lane-per-state (the library picks by batch size); "v5-lds" / "v5-slab" pin where the third
+# generation keeps a tile's FP32 centres (the library picks by LDS fit: slab for Lift and Assembly, LDS for Push and Pusher)
+KERNELS = ["v1", "v2", "v5", "v5-lds", "v5-slab"]
 
 
 def _scene_with_kernel(kernel, *args, **kw):
-    """Create a Scene with MOPA_VALID_KERNEL pinned (read once, at scene creation)."""
+    """Create a Scene with MOPA_VALID_KERNEL / MOPA_V5_CENTRES pinned (read once, at scene creation)."""
     import os
     from mopa_rl_amd import _lib
-    old = os.environ.get("MOPA_VALID_KERNEL")
+    pins = {}
     if kernel is not None:
-        os.environ["MOPA_VALID_KERNEL"] = kernel
+        gen, _, cen = kernel.partition("-")
+        pins["MOPA_VALID_KERNEL"] = gen
+        if cen:
+            pins["MOPA_V5_CENTRES"] = cen
+    old = {k: os.environ.get(k) for k in pins}
+    os.environ.update(pins)
     try:
         return _lib.Scene(*args, **kw)
     finally:
-        if old is None:
-            os.environ.pop("MOPA_VALID_KERNEL", None)
-        else:
-            os.environ["MOPA_VALID_KERNEL"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def _mk(env, oracle_mod, kernel=None):

@@ -409,7 +409,7 @@ def main():
             "valid_fraction": n_valid / N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_is_valid_v5<false>", "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
+                         "kernel": "k_is_valid_v5<false, true, false>", "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
                          "note": "path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see DESIGN.md"},
         }
         # HBM-side traffic of the same launch, from the committed rocprofv3 PMC passes (tools/profile.sh ->

@@ -120,6 +120,8 @@ struct MopaScene {
     size_t mv_cap_seg = 0, mv_cap_states = 0, mv_scan_bytes = 0;
     int v5_lds_bytes = 0;
     int use_v5 = 0;
+    long long *d_mesh_list = nullptr;   // [0] = count, then the states with a mesh pair past the main pass's broad phase
+    size_t mesh_list_cap = 0;
     bool v5_cen_lds = true;   // FP32 centre table of a tile in LDS (false: read back from the pose slab; scenes with many moving geoms)
     bool v2_forced = false;   // MOPA_VALID_KERNEL=v2: lane-per-state kernel for every N >= 64 (tests, A/B runs)
     // planner workspace (mopa_planner.inc): both trees of every env, grown on demand
@@ -728,12 +730,12 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     // of their own: the main pass (k_is_valid_v5 / v2) then carries no mesh code at all, and a second, light pass of
     // the MESH instantiation handles the handful of mesh pairs and folds its verdict into the first one's.
     std::vector<int32_t> mg_store(nmg, 0);
-    auto build_lists = [&](bool want_mesh, std::vector<int32_t> &padr, std::vector<int32_t> &pnum, std::vector<int32_t> &words) {
+    auto build_lists = [&](int mode /*0 = mesh-free pairs, 1 = mesh pairs, 2 = all*/, std::vector<int32_t> &padr, std::vector<int32_t> &pnum, std::vector<int32_t> &words) {
         padr.assign(nmg, 0); pnum.assign(nmg, 0); words.clear();
         std::vector<std::vector<PairE>> own(nmg);
         for (const PairE &e : pairs) {   // already sorted by cost class
             const bool is_mesh = (e.code == PC_PLANE_MESH || e.code == PC_CONVEX_MESH);
-            if (is_mesh != want_mesh) continue;
+            if (mode != 2 && is_mesh != (mode == 1)) continue;
             int s1 = g_slot[e.g1], s2 = g_slot[e.g2];
             int owner = (s2 > s1) ? s2 : s1;
             own[owner].push_back(e);
@@ -752,8 +754,13 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         }
     };
     std::vector<int32_t> mg_padr, mg_pnum, gp_word, mg_padr_mesh, mg_pnum_mesh, gp_word_mesh;
-    build_lists(false, mg_padr, mg_pnum, gp_word);
-    build_lists(true, mg_padr_mesh, mg_pnum_mesh, gp_word_mesh);
+    build_lists(0, mg_padr, mg_pnum, gp_word);
+    build_lists(1, mg_padr_mesh, mg_pnum_mesh, gp_word_mesh);
+    // The third-generation kernel culls the mesh pairs too (FP32, a few table entries more) -- not to evaluate them, but
+    // to tell the second pass which states have one within reach at all: almost none do, and that pass then skips
+    // whole tiles instead of posing every state again for nothing.
+    std::vector<int32_t> t5_padr = mg_padr, t5_pnum = mg_pnum, t5_word = gp_word;
+    if (!gp_word_mesh.empty()) build_lists(2, t5_padr, t5_pnum, t5_word);
 
     // v5: FP32 broad-phase table, one 32-byte entry per (owner geom, partner) pair:
     //   [0..2] partner centre (static partners) / a point of the plane, [3] partner bounding radius,
@@ -761,23 +768,26 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     //   [7] flags: bits 0..13 = low bits of gp_word (partner gid, code, cur_is_g2, pmov), 14..21 partner slot, 30 plane
     // Within a geom's range the entries are ordered [moving partners | static non-plane partners | planes] (the kernel
     // runs one branch-free loop per group); the group sizes follow the table: tab[8 n_gp + slot] = nmov | nstat<<8 | nplane<<16.
-    std::vector<int32_t> gp_tab(8 * gp_word.size() + nmg, 0);
+    const size_t n5 = t5_word.size();
+    std::vector<int32_t> gp_tab(8 * n5 + 3 * (size_t)nmg, 0);   // entries, then per geom: group counts, then (first entry, count)
     int max_pnum = 0;
     {
         auto f2i = [](double x) { float f = (float)x; int32_t i; std::memcpy(&i, &f, 4); return i; };
         for (int mslot = 0; mslot < nmg; mslot++) {
-            max_pnum = std::max(max_pnum, (int)mg_pnum[mslot]);
+            max_pnum = std::max(max_pnum, (int)t5_pnum[mslot]);
+            gp_tab[8 * n5 + nmg + 2 * mslot] = t5_padr[mslot];
+            gp_tab[8 * n5 + nmg + 2 * mslot + 1] = t5_pnum[mslot];
             std::vector<int> order[3];
-            for (int p = mg_padr[mslot]; p < mg_padr[mslot] + mg_pnum[mslot]; p++) {
-                const int w = gp_word[p];
+            for (int p = t5_padr[mslot]; p < t5_padr[mslot] + t5_pnum[mslot]; p++) {
+                const int w = t5_word[p];
                 const int grp = ((w >> 13) & 1) ? 0 : (m.geom_type[w & 0xff] == G_PLANE ? 2 : 1);
                 order[grp].push_back(p);
             }
-            gp_tab[8 * gp_word.size() + mslot] = (int)order[0].size() | ((int)order[1].size() << 8) | ((int)order[2].size() << 16);
-            size_t dst = (size_t)mg_padr[mslot];
+            gp_tab[8 * n5 + mslot] = (int)order[0].size() | ((int)order[1].size() << 8) | ((int)order[2].size() << 16);
+            size_t dst = (size_t)t5_padr[mslot];
             for (int grp = 0; grp < 3; grp++)
                 for (int p : order[grp]) {
-                    const int w = gp_word[p];
+                    const int w = t5_word[p];
                     const int pg = w & 0xff, pmov = (w >> 13) & 1;
                     int32_t *te = &gp_tab[8 * dst++];
                     te[3] = f2i(g_rbound[pg]);
@@ -872,7 +882,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.o_mg_geom = B.add_i(mg_geom); h.o_chain_adr = B.add_i(chain_adr); h.o_chain_len = B.add_i(chain_len);
     h.o_chain_items = B.add_i(chain_items); h.o_pairs = B.add_i(pk); h.o_pq_adr = B.add_i(pq_adr);
     h.o_act_adr = B.add_i(act_adr); h.o_act_so2 = B.add_i(act_so2);
-    h.n_save = n_save; h.n_gp = (int)gp_word.size();
+    h.n_save = n_save; h.n_gp = (int)t5_word.size();
     h.o_mb_load = B.add_i(mb_load); h.o_mb_save = B.add_i(mb_save); h.o_mb_mgadr = B.add_i(mb_mgadr); h.o_mb_mgnum = B.add_i(mb_mgnum);
     h.o_mg_padr = B.add_i(mg_padr); h.o_mg_pnum = B.add_i(mg_pnum); h.o_mg_store = B.add_i(mg_store); h.o_gp_word = B.add_i(gp_word);
     while (B.ints.size() & 7) B.ints.push_back(0);   // 32-byte align the packed records (scalar dwordx8 loads)
@@ -898,13 +908,14 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         {
             // largest entry buffer (multiple of 64, 256..1024) that still lets two workgroups share a CU's 160 KiB of LDS;
             // if even the smallest does not fit with the FP32 centre table in LDS, the centres are read back from the slab
-            const int fixed = h.n_dbl * 8 + ((h.n_int + 3) & ~3) * 4 + ((8 * (int)gp_word.size() + nmg + 3) & ~3) * 4;
+            const int fixed = h.n_dbl * 8 + ((h.n_int + 3) & ~3) * 4 + ((8 * h.n_gp + (gp_word_mesh.empty() ? 1 : 3) * nmg + 3) & ~3) * 4;
             const char *ec = std::getenv("MOPA_V5_CENTRES");       // "lds" / "slab": A/B runs and tests
             bool cen_lds = true;
             int cap = kEntCapV5Max;
             for (int attempt = 0; attempt < 2; attempt++) {
-                cen_lds = attempt == 0;
+                cen_lds = attempt == 0 && gp_word_mesh.empty();   // scenes with mesh pairs: the slab-centre instantiation carries the gate
                 if (ec && std::string(ec) == "slab") cen_lds = false;
+                if (ec && std::string(ec) == "lds" && gp_word_mesh.empty()) cen_lds = true;   // (mesh scenes: always slab + gate)
                 const int n_cen = cen_lds ? nmg : 0;
                 cap = kEntCapV5Max;
                 while (cap > 256 && fixed + kWavesPerBlock * v5_lds_per_wave(n_cen, cap) > 80 * 1024) cap -= 64;
@@ -913,7 +924,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
             }
             if (fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap) > 80 * 1024) {   // one workgroup per CU anyway
                 cap = 768;
-                cen_lds = !(ec && std::string(ec) == "slab");
+                cen_lds = gp_word_mesh.empty() && !(ec && std::string(ec) == "slab");
             }
             S->v5_cen_lds = cen_lds;
             h.v5_ent_cap = cap;
@@ -967,8 +978,9 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
                           (const void *)k_is_valid<true, true>, (const void *)k_check_motion, (const void *)k_debug_state<false>,
                           (const void *)k_debug_state<true>, (const void *)k_is_valid_v2<false, false>,
                           (const void *)k_is_valid_v2<true, false>, (const void *)k_is_valid_v2<false, true>,
-                          (const void *)k_is_valid_v2<true, true>, (const void *)k_is_valid_v5<false, true>, (const void *)k_is_valid_v5<true, true>,
-                          (const void *)k_is_valid_v5<false, false>, (const void *)k_is_valid_v5<true, false>})
+                          (const void *)k_is_valid_v2<true, true>, (const void *)k_is_valid_v5<false, true, false>, (const void *)k_is_valid_v5<true, true, false>,
+                          (const void *)k_is_valid_v5<false, false, false>, (const void *)k_is_valid_v5<true, false, false>,
+                          (const void *)k_is_valid_v5<false, false, true>, (const void *)k_is_valid_v5<true, false, true>})
         (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes);
     plan_register_lds();
     *out = S;
@@ -988,6 +1000,7 @@ extern "C" void mopa_scene_destroy(MopaScene *S) {
     if (S->d_slab) (void)hipFree(S->d_slab);
     if (S->d_mpr) (void)hipFree(S->d_mpr);
     if (S->d_gp_tab) (void)hipFree(S->d_gp_tab);
+    if (S->d_mesh_list) (void)hipFree(S->d_mesh_list);
     for (void *q : {(void *)S->mv_cnt, (void *)S->mv_off, (void *)S->mv_env, (void *)S->mv_q, (void *)S->mv_valid, S->mv_scan})
         if (q) (void)hipFree(q);
     delete S;
@@ -1045,22 +1058,40 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
         (void)hipMemsetAsync(d_prof, 0, 6 * 8, st);
 #endif
         auto kern = min_dist ? k_is_valid_v2<true, false> : k_is_valid_v2<false, false>;   // main lists carry no mesh pair
+        long long *mesh_list = nullptr;
+        if (S->use_v5 && !S->v5_cen_lds && S->n_mesh_gp > 0) {
+            if ((size_t)N > S->mesh_list_cap) {
+                if (S->d_mesh_list) (void)hipFree(S->d_mesh_list);
+                S->d_mesh_list = nullptr; S->mesh_list_cap = 0;
+                HIP_TRY(hipMalloc((void **)&S->d_mesh_list, ((size_t)N + 1) * sizeof(long long)));
+                S->mesh_list_cap = (size_t)N;
+            }
+            mesh_list = S->d_mesh_list;
+            HIP_TRY(hipMemsetAsync(mesh_list, 0, sizeof(long long), st));
+        }
         if (S->use_v5) {
-            auto k5 = S->v5_cen_lds ? (min_dist ? k_is_valid_v5<true, true> : k_is_valid_v5<false, true>)
-                                    : (min_dist ? k_is_valid_v5<true, false> : k_is_valid_v5<false, false>);
+            auto k5 = S->v5_cen_lds ? (min_dist ? k_is_valid_v5<true, true, false> : k_is_valid_v5<false, true, false>)
+                      : mesh_list   ? (min_dist ? k_is_valid_v5<true, false, true> : k_is_valid_v5<false, false, true>)
+                                    : (min_dist ? k_is_valid_v5<true, false, false> : k_is_valid_v5<false, false, false>);
             hipLaunchKernelGGL(k5, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
-                               (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx, S->d_mpr);
+                               (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx, S->d_mpr, mesh_list);
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                           (long long)samples_per_env, valid, min_dist, S->d_slab, 0, env_idx);
+                           (long long)samples_per_env, valid, min_dist, S->d_slab, 0, env_idx, (const long long *)nullptr);
         if (S->n_mesh_gp > 0) {
             // second pass: the mesh pairs only (MESH instantiation), verdict AND-ed / depth min-ed into the first pass's
             HIP_TRY(hipMemsetAsync(d_tail + 8, 0, 8, st));
             auto km = min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>;
             hipLaunchKernelGGL(km, grid, block, S->v2_lds_bytes, st, S->hdr_mesh, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                               (long long)samples_per_env, valid, min_dist, S->d_slab, 1, env_idx);
+                               (long long)samples_per_env, valid, min_dist, S->d_slab, 1, env_idx, (const long long *)mesh_list);
         }
         HIP_TRY(hipGetLastError());
+        if (mesh_list && std::getenv("MOPA_DEBUG_MESH")) {     // diagnostics: how many states the gate lets through
+            long long cnt = 0;
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(&cnt, mesh_list, sizeof(cnt), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[mopa] mesh gate: %lld of %lld states go to the second pass\n", cnt, (long long)N);
+        }
 #ifdef MOPA_V2_PROFILE
         {
             unsigned long long hp[6];

@@ -337,15 +337,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # test-only knobs: MOPA_BENCH_DEVICE pins every rank to one device and MOPA_BENCH_BACKEND=gloo swaps the collective
+    # backend, so that the world > 1 code path can be exercised end to end on a single-GPU box
+    dev_index = int(os.environ.get("MOPA_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("MOPA_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)   # "nccl" == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)   # "nccl" == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     pi = planner_inputs(ENV)
     scene = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold,
-                       range_=pi.spec.range, seed=0, device=local_rank)
+                       range_=pi.spec.range, seed=0, device=dev_index)
     bp = BatchPlanner(scene)
     E, S = args.envs, args.samples
     N = E * S

@@ -357,8 +357,8 @@ def main():
     E, S = args.envs, args.samples
     N = E * S
     qa, rows = make_inputs(torch, pi, E, S, seed=1234 + rank, device=device, mode=args.mode)
-    # Double-buffered verdict masks: the RCCL all-gather of step k (on RCCL's own stream) overlaps the validity kernel of
-    # step k+1; a buffer is only reused after the collective that reads it has completed (mopa_rl_amd/dist.py).
+    # Triple-buffered verdict masks: the RCCL all-gather of step k (on RCCL's own stream) overlaps the validity kernels of
+    # steps k+1 and k+2; a buffer is only reused after the collective that reads it has completed (mopa_rl_amd/dist.py).
     from mopa_rl_amd.dist import OverlappedGather
     og = OverlappedGather(N, torch.uint8, device)
 
@@ -396,7 +396,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    valid = og.local[(args.steps - 1) & 1] if args.steps > 0 else og.local[0]
+    valid = og.local[(args.steps - 1) % og.depth] if args.steps > 0 else og.local[0]
 
     n_valid = int(valid.sum().item())
     if rank == 0:
@@ -412,7 +412,7 @@ def main():
                                    + {"mixed": "states 50% uniform joint-box samples + 50% near-init N(0,0.3)", "near": "states near-init N(0,0.3)",
                                       "uniform": "states uniform in the joint box"}[args.mode],
                        "envs_per_gpu": E, "states_per_env": S, "pairs_checked_per_state": scene.npair_checked,
-                       "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(uint8 masks), overlapped with the next step's kernel" if world > 1 else "")},
+                       "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(uint8 masks), triple-buffered, overlapped with the next steps' kernels" if world > 1 else "")},
             "valid_fraction": n_valid / N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,

@@ -73,40 +73,43 @@ def all_reduce_mean_(flat):
 
 
 class OverlappedGather:
-    """Double-buffered all-gather of a fixed-size per-rank tensor (the uint8 verdict masks of a step), overlapped with
-    the producer of the NEXT step: `buffer(k)` hands out the local buffer of step k after waiting for the collective that
-    may still be reading it (the one launched two steps earlier), `launch(k)` starts the asynchronous all-gather of step
-    k on the backend's own stream, `result(k)` waits for it and returns the gathered tensor [world * n], `drain()` waits
-    for everything in flight.  With one rank nothing is communicated and `result` is the local buffer."""
+    """Multi-buffered all-gather of a fixed-size per-rank tensor (the uint8 verdict masks of a step), overlapped with
+    the producers of the NEXT steps: `buffer(k)` hands out the local buffer of step k after waiting for the collective
+    that may still be reading it (the one launched `depth` steps earlier), `launch(k)` starts the asynchronous all-gather
+    of step k on the backend's own stream, `result(k)` waits for it and returns the gathered tensor [world * n],
+    `drain()` waits for everything in flight.  depth = 3: the validity kernel is persistent and fills every CU, so the
+    collective of step k only gets CUs in the tail of kernel k+1 -- with two buffers kernel k+2 would then have to wait
+    for it; with three it has a whole kernel of slack.  With one rank nothing is communicated and `result` is the local
+    buffer."""
 
-    def __init__(self, n: int, dtype, device):
+    def __init__(self, n: int, dtype, device, depth: int = 3):
         import torch
         self.world, self.rank = world_info()
-        self.local = [torch.empty(n, dtype=dtype, device=device) for _ in range(2)]
-        self.gathered = [torch.empty(self.world * n, dtype=dtype, device=device) for _ in range(2)] if self.world > 1 else None
-        self.pending = [None, None]
+        self.depth = depth
+        self.local = [torch.empty(n, dtype=dtype, device=device) for _ in range(depth)]
+        self.gathered = [torch.empty(self.world * n, dtype=dtype, device=device) for _ in range(depth)] if self.world > 1 else None
+        self.pending = [None] * depth
+
+    def _wait(self, b: int):
+        if self.pending[b] is not None:
+            self.pending[b].wait()          # the current stream waits for the collective that still uses buffer b
+            self.pending[b] = None
 
     def buffer(self, k: int):
-        b = k & 1
-        if self.pending[b] is not None:
-            self.pending[b].wait()          # the current stream waits for the collective that still reads local[b]
-            self.pending[b] = None
+        b = k % self.depth
+        self._wait(b)
         return self.local[b]
 
     def launch(self, k: int):
         if self.world > 1:
-            b = k & 1
+            b = k % self.depth
             self.pending[b] = _dist().all_gather_into_tensor(self.gathered[b], self.local[b], async_op=True)
 
     def result(self, k: int):
-        b = k & 1
-        if self.pending[b] is not None:
-            self.pending[b].wait()
-            self.pending[b] = None
+        b = k % self.depth
+        self._wait(b)
         return self.gathered[b] if self.world > 1 else self.local[b]
 
     def drain(self):
-        for b in range(2):
-            if self.pending[b] is not None:
-                self.pending[b].wait()
-                self.pending[b] = None
+        for b in range(self.depth):
+            self._wait(b)

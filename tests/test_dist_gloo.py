@@ -114,7 +114,7 @@ def _og_worker(rank, world, port, n, steps, q):
 
 def test_overlapped_gather_double_buffering():
     """bench.py's per-step exchange (mopa_rl_amd/dist.py::OverlappedGather) on 2 gloo ranks: every step's gathered masks
-    are that step's values from both ranks, although buffers are reused every second step."""
+    are that step's values from both ranks, although buffers are reused every third step."""
     import torch.multiprocessing as mp
     world, n, steps = 2, 1000, 7
     ctx = mp.get_context("spawn")

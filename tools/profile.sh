@@ -13,7 +13,10 @@ run() {  # name, rocprof args...
   rocprofv3 "$@" --output-format csv -d $WORK/$name -o $name -- $BENCH > $OUT/${name}_bench.log 2>&1
   for f in $(find $WORK/$name -name "*.csv"); do
     sz=$(stat -c %s $f)
-    if [ $sz -lt 400000 ]; then cp $f $OUT/$(basename $f); else head -200 $f > $OUT/$(basename $f .csv)_head200.csv; fi
+    if [ $sz -lt 400000 ]; then cp $f $OUT/$(basename $f); else
+      head -200 $f > $OUT/$(basename $f .csv)_head200.csv
+      (head -1 $f; grep -E '"(void )?k_[a-z_0-9]+[<(]' $f | head -3000) > $OUT/$(basename $f .csv)_ours.csv   # rows of this library's kernels
+    fi
   done
 }
 run trace --kernel-trace --stats
@@ -24,6 +27,10 @@ BENCH=$BENCH_SAVE
 run pmc_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY
 run pmc_sq2 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE
+# the planner kernel's counters (bench with the planner section only)
+BENCH_SAVE=$BENCH; BENCH="python $R/bench.py --no-cpu --no-env --no-rollout --steps 2 --warmup 1"
+run pmc_plan --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY
+BENCH=$BENCH_SAVE
 run pmc_write --kernel-trace --pmc WRITE_SIZE
 ls -la $OUT
 echo "== kernel stats"; cat $OUT/trace_kernel_stats.csv 2>/dev/null

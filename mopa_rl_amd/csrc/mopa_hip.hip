@@ -128,6 +128,7 @@ struct MopaScene {
     double *plan_tree_q = nullptr;
     int32_t *plan_tree_parent = nullptr;
     size_t plan_q_bytes = 0, plan_p_bytes = 0;
+    unsigned long long *plan_ctr = nullptr;   // next env of a planner launch (persistent waves)
 };
 
 // ---------------------------------------------------------------------------
@@ -991,6 +992,7 @@ extern "C" void mopa_scene_destroy(MopaScene *S) {
     if (!S) return;
     if (S->plan_tree_q) (void)hipFree(S->plan_tree_q);
     if (S->plan_tree_parent) (void)hipFree(S->plan_tree_parent);
+    if (S->plan_ctr) (void)hipFree(S->plan_ctr);
     if (S->d_dbl) (void)hipFree(S->d_dbl);
     if (S->d_int) (void)hipFree(S->d_int);
     if (S->d_q) (void)hipFree(S->d_q);

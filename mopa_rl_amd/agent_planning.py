@@ -1,255 +1,199 @@
-"""Callers of the validity checker / planner.
+"""Batched forms of what the reference's agents and rollout runner do AROUND the planner (SURVEY.md section 8 rows
+A10-A11), for E environments at once on torch tensors:
 
-`PlanningMixin` restates, with the same names, arguments and return tuples, the planner-facing half of the
-reference's SAC/TD3 agents (rl/sac_agent.py:145-318, duplicated in rl/td3_agent.py): `is_planner_ac`,
-`convert2planner_displacement`, `invert_displacement`, `clip_qpos`, `simple_interpolate`, `plan`, `isValidState`.
-`handle_invalid_target` restates the invalid-target back-off of the rollout runner (rl/mopa_rollouts.py:119-143).
-Everything here is host-side numpy, exactly where the reference keeps it; validity comes from whatever object
-exposes `isValidState` / `plan` (the `PlannerAgent` mirror -> libmopa_hip.so).
+    is_planner_action          rl/sac_agent.py:148-153      some |a_j| beyond omega -> the step is a planner step
+    action_to_displacement     rl/sac_agent.py:158-175      policy output -> joint displacement (piecewise / normal)
+    displacement_to_action     rl/sac_agent.py:177-196      its inverse (used by the reuse_data relabelling)
+    JointLimits.clip_state     rl/sac_agent.py:237-260      a state beyond a joint limit is pulled inside by joint_margin
+    JointLimits.clip_target    rl/mopa_rollouts.py:119-131  a planner target is clipped onto the limits
+    simple_interpolate_batch   rl/sac_agent.py:262-318      straight line in steps <= 0.8 ac_scale, every step validated
+    handle_invalid_target_batch rl/mopa_rollouts.py:133-143 invalid target walked back toward the current state
 
-`simple_interpolate_batch` / `handle_invalid_target_batch` are the device-resident forms for E environments at once:
-the same rules evaluated with one batched validity launch per step instead of a Python loop per environment.
+The reference keeps these as per-environment numpy methods on its SAC/TD3 agents; its agents keep using their own.  The
+forms here exist for the batched rollout (rollout.py): one validity launch covers all environments, every arithmetic
+step is ordered as in the reference so results agree with it element for element.  They are checked against vectors
+produced by the reference's own code (tests/golden/ref_py_*.npz, tools/gen_ref_py_golden.py).
+
+Tensors may live on the GPU (product) or on the CPU (the host tests drive the same code with a CPU validity checker);
+validity always comes from the `bp` object passed in (`BatchPlanner`: libmopa_hip.so).
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple
+from typing import Sequence
 
 import numpy as np
 
 
-# ---------------------------------------------------------------------------
-# single-environment restatement (reference semantics, quirks included)
-# ---------------------------------------------------------------------------
-class PlanningMixin:
-    """Needs: self._config (omega, ac_space_type, action_range, timelimit, simple_planner_timelimit, interpolation,
-    joint_margin), self._planner, self._simple_planner (PlannerAgent-like), self._ref_joint_pos_indexes,
-    self._jnt_indices, self._jnt_minimum, self._jnt_maximum, self._is_jnt_limited, self._ac_low, self._ac_high
-    (bounds of ac_space['default'], reference: self._ac_space['default'].low[0] / .high[0])."""
-
-    # rl/sac_agent.py:148-153
-    def is_planner_ac(self, ac) -> bool:
-        a = np.asarray(ac["default"] if isinstance(ac, dict) else ac)[: len(self._ref_joint_pos_indexes)]
-        return bool(np.any(a < -self._config.omega) or np.any(a > self._config.omega))
-
-    # rl/sac_agent.py:155-156
-    def isValidState(self, state) -> bool:
-        return self._planner.isValidState(state)
-
-    # rl/sac_agent.py:158-175
-    def convert2planner_displacement(self, ac, ac_scale):
-        cfg = self._config
-        if cfg.ac_space_type == "normal":
-            return ac * cfg.action_range
-        if cfg.ac_space_type == "piecewise":
-            om = cfg.omega
-            return np.where(np.abs(ac) < om, ac / (om / ac_scale),
-                            np.sign(ac) * (ac_scale + (cfg.action_range - ac_scale) * ((np.abs(ac) - om) / (1 - om))))
-        raise NotImplementedError
-
-    # rl/sac_agent.py:177-196
-    def invert_displacement(self, displacement, ac_scale):
-        cfg = self._config
-        if cfg.ac_space_type == "normal":
-            return displacement / cfg.action_range
-        if cfg.ac_space_type == "piecewise":
-            om = cfg.omega
-            return np.where(np.abs(displacement) < ac_scale, displacement * (om / ac_scale),
-                            np.sign(displacement) * ((np.abs(displacement) - ac_scale)
-                                                     / ((cfg.action_range - ac_scale) / (1.0 - ac_scale))
-                                                     / ((1.0 - ac_scale) / (1.0 - om)) + om))
-        raise NotImplementedError
-
-    # rl/sac_agent.py:237-260
-    def clip_qpos(self, curr_qpos):
-        tmp_pos = curr_qpos.copy()
-        lim = self._is_jnt_limited[self._jnt_indices]
-        lo, hi = self._jnt_minimum[self._jnt_indices], self._jnt_maximum[self._jnt_indices]
-        if np.any(curr_qpos[lim] < lo[lim]) or np.any(curr_qpos[lim] > hi[lim]):
-            new = np.clip(curr_qpos.copy(), lo + self._config.joint_margin, hi - self._config.joint_margin)
-            new[np.invert(lim)] = tmp_pos[np.invert(lim)]
-            curr_qpos = new
-        return curr_qpos
-
-    # rl/sac_agent.py:262-318
-    def simple_interpolate(self, curr_qpos, target_qpos, ac_scale, use_planner=False):
-        success, exact = True, True
-        curr_qpos = self.clip_qpos(curr_qpos)
-        traj = []
-        n = len(self._ref_joint_pos_indexes)
-        min_action = self._ac_low * ac_scale * 0.8
-        max_action = self._ac_high * ac_scale * 0.8
-        assert max_action > min_action, "action space box is ill defined"
-        assert max_action > 0 and min_action < 0, "action space MAY be ill defined. Check this assertion"
-        diff = target_qpos[:n] - curr_qpos[:n]
-        out = np.where((diff > max_action) | (diff < min_action))[0]
-        out_diff = diff[out]
-        scales = np.where(out_diff > max_action, out_diff / max_action, out_diff / min_action)
-        scaling_factor = 1.0 if len(scales) == 0 else max(max(scales), 1.0)
-        scaled_ac = diff[:n] / scaling_factor
-        valid = True
-        interp_qpos = curr_qpos.copy()
-        for _ in range(int(scaling_factor)):
-            interp_qpos[:n] += scaled_ac
-            if not self._planner.isValidState(interp_qpos):
-                valid = False
-                break
-            traj.append(interp_qpos.copy())
-        if not valid and use_planner:
-            traj, success, valid, exact = self._simple_planner.plan(curr_qpos, target_qpos,
-                                                                    self._config.simple_planner_timelimit)
-            if not success:
-                traj, success, valid, exact = self._planner.plan(curr_qpos, target_qpos, self._config.timelimit)
-                if not success:
-                    traj = [target_qpos]
-                    success, exact = False, False
-        else:
-            if not valid:
-                success, exact = False, False
-            traj.append(target_qpos)
-        return np.array(traj), success, valid, exact
-
-    # rl/sac_agent.py:198-235
-    def plan(self, curr_qpos, target_qpos, ac_scale=None):
-        curr_qpos = self.clip_qpos(curr_qpos)
-        interpolation = True
-        traj, success, valid, exact = self.simple_interpolate(curr_qpos, target_qpos, ac_scale)
-        if not success:
-            if not exact:
-                traj, success, valid, exact = self._planner.plan(curr_qpos, target_qpos, self._config.timelimit)
-                interpolation = False
-                if self._config.interpolation and success:
-                    n = len(self._ref_joint_pos_indexes)
-                    new_traj = []
-                    start = curr_qpos
-                    for i in range(len(traj)):
-                        diff = traj[i] - start
-                        if np.any(diff[:n] < -ac_scale) or np.any(diff[:n] > ac_scale):
-                            inner, _, _, _ = self.simple_interpolate(start, traj[i], ac_scale, use_planner=True)
-                            new_traj.extend(inner)
-                        else:
-                            new_traj.append(traj[i])
-                        start = traj[i]
-                    traj = np.array(new_traj)
-        return traj, success, interpolation, valid, exact
-
-
-def clip_target_to_limits(target_qpos, jnt_minimum, jnt_maximum, is_jnt_limited):
-    """rl/mopa_rollouts.py:119-130: clip the planner target to the joint limits, unlimited joints untouched."""
-    tmp = target_qpos.copy()
-    out = np.clip(target_qpos, jnt_minimum, jnt_maximum)
-    out[np.invert(is_jnt_limited)] = tmp[np.invert(is_jnt_limited)]
-    return out
-
-
-def norm_seq(d):
-    """Euclidean norm with the squares summed left to right.  The reference calls np.linalg.norm (BLAS dot: the
-    summation order, hence the last bit, depends on the BLAS build); this fixed order is what the scalar and the
-    batched back-off share so that they agree bit for bit."""
-    acc = 0.0
-    for x in np.asarray(d, dtype=np.float64).ravel():
-        acc = acc + x * x
-    return float(np.sqrt(acc))
-
-
-def handle_invalid_target(pi, curr_qpos, target_qpos, step_size: float, num_trials: int):
-    """rl/mopa_rollouts.py:133-143: walk an invalid target back toward the current state in steps of
-    `step_size` (Euclidean, over the full qpos vector) until it is valid or `num_trials` is exhausted.
-    Returns (target_qpos, n_trials)."""
-    target_qpos = target_qpos.copy()
-    trial = 0
-    if not pi.isValidState(target_qpos):
-        while not pi.isValidState(target_qpos) and trial < num_trials:
-            d = curr_qpos - target_qpos
-            target_qpos += step_size * d / norm_seq(d)
-            trial += 1
-    return target_qpos, trial
-
-
-# ---------------------------------------------------------------------------
-# batched, device-resident forms (torch tensors on the GPU; validity through BatchPlanner)
-# ---------------------------------------------------------------------------
-def simple_interpolate_batch(bp, curr_qpos, target_qpos, ac_scale: float, ref_idx: Sequence[int], ac_low: float = -1.0,
-                             ac_high: float = 1.0, max_steps: int = 64):
-    """`simple_interpolate` (use_planner=False) for E envs at once.
-
-    curr_qpos / target_qpos: [E, nq] float64 CUDA tensors (curr already clipped).  Returns
-    (traj [E, max_steps+1, nq], traj_len [E], success [E] bool, n_steps [E]) where row e holds the
-    int(scaling_factor_e) interpolated states followed by the exact target -- the reference's `traj` -- and
-    success[e] is False when one of its interpolated states is invalid (then traj_len[e] counts the valid prefix
-    + the target, exactly as the reference returns it).  All E * max(n_steps) states are checked in ONE launch."""
+def _torch():
     import torch
+    return torch
+
+
+def is_planner_action(ac, omega: float):
+    """[E, n] -> [E] bool: any joint entry outside [-omega, omega]."""
+    return ((ac < -omega) | (ac > omega)).any(dim=-1)
+
+
+def action_to_displacement(ac, ac_scale: float, omega: float, action_range: float, ac_space_type: str = "piecewise"):
+    """Policy output in [-1, 1] -> joint displacement.  Inside omega the map is linear onto [-ac_scale, ac_scale]; beyond
+    it the remaining interval is stretched onto (ac_scale, action_range].  Divisions are by tensors: `tensor /
+    python_float` runs as a multiplication by the reciprocal on the GPU (1 ulp off IEEE division)."""
+    torch = _torch()
+    if ac_space_type == "normal":
+        return ac * action_range
+    if ac_space_type != "piecewise":
+        raise NotImplementedError(ac_space_type)
+    mag = ac.abs()
+    near = ac / torch.full_like(ac, omega / ac_scale)
+    beyond = (mag - omega) / torch.full_like(ac, 1 - omega)
+    far = torch.sign(ac) * (ac_scale + (action_range - ac_scale) * beyond)
+    return torch.where(mag < omega, near, far)
+
+
+def displacement_to_action(disp, ac_scale: float, omega: float, action_range: float, ac_space_type: str = "piecewise"):
+    """Inverse map on numpy arrays (host side: the relabelling works on recorded waypoints).  The far branch divides by
+    (action_range - ac_scale) / (1 - ac_scale) and then by (1 - ac_scale) / (1 - omega), in that order, as the
+    reference does (the two do not cancel to the algebraic inverse of `action_to_displacement`; kept as is)."""
+    disp = np.asarray(disp, dtype=np.float64)
+    if ac_space_type == "normal":
+        return disp / action_range
+    if ac_space_type != "piecewise":
+        raise NotImplementedError(ac_space_type)
+    mag = np.abs(disp)
+    stretch = (mag - ac_scale) / ((action_range - ac_scale) / (1.0 - ac_scale)) / ((1.0 - ac_scale) / (1.0 - omega))
+    return np.where(mag < ac_scale, disp * (omega / ac_scale), np.sign(disp) * (stretch + omega))
+
+
+class JointLimits:
+    """Per-qpos-address joint limits of a model, in the two precisions the reference uses them in.
+
+    The env clips planner *targets* against float64 limits (`env._jnt_minimum`, env/base.py:77-89).  The agents clip
+    *states* against `joint_space['default'].low/high`, a float32 gym Box (rl/sac_agent.py:56-57), and form the
+    margin-shrunk bounds in float32 too (`low + joint_margin` on a float32 array stays float32).  Both are kept."""
+
+    def __init__(self, lo, hi, limited, joint_margin: float, device=None):
+        torch = _torch()
+        lo, hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+        lim = np.asarray(limited, dtype=bool)
+        lo32, hi32 = lo.astype(np.float32), hi.astype(np.float32)
+        shrunk_lo = (lo32 + np.float32(joint_margin)).astype(np.float64)
+        shrunk_hi = (hi32 - np.float32(joint_margin)).astype(np.float64)
+        t = lambda a: torch.tensor(a, dtype=torch.float64, device=device)
+        inf = np.inf
+        self.limited = torch.tensor(lim, device=device)
+        self.lo, self.hi = t(np.where(lim, lo, -inf)), t(np.where(lim, hi, inf))
+        self.lo_state, self.hi_state = t(np.where(lim, lo32.astype(np.float64), -inf)), t(np.where(lim, hi32.astype(np.float64), inf))
+        self.lo_shrunk, self.hi_shrunk = t(np.where(lim, shrunk_lo, -inf)), t(np.where(lim, shrunk_hi, inf))
+        self._np = tuple(x.cpu().numpy() for x in (self.lo_state, self.hi_state, self.lo_shrunk, self.hi_shrunk))
+
+    def clip_target(self, q):
+        torch = _torch()
+        return torch.minimum(torch.maximum(q, self.lo), self.hi)          # unlimited entries have infinite bounds
+
+    def clip_state(self, q):
+        """Rows with some limited joint beyond its limit are clipped -- all their limited entries -- to the shrunk
+        bounds; the other rows pass through untouched."""
+        torch = _torch()
+        beyond = ((q < self.lo_state) | (q > self.hi_state)).any(dim=-1, keepdim=True)
+        return torch.where(beyond, torch.minimum(torch.maximum(q, self.lo_shrunk), self.hi_shrunk), q)
+
+
+    def clip_state_np(self, q):
+        """`clip_state` for one host-side row (numpy)."""
+        lo, hi, lo_s, hi_s = self._np
+        if np.any(q < lo) or np.any(q > hi):
+            return np.minimum(np.maximum(q, lo_s), hi_s)
+        return q
+
+
+def interpolation_steps(diff, ac_scale: float, ac_low: float = -1.0, ac_high: float = 1.0):
+    """Step count rule of the straight-line pre-check: with the per-step bound b = 0.8 ac_scale, the line is cut into
+    int(s) equal steps, s = max(1, max_j diff_j / (+-b)) over the joints that exceed the bound.  Returns (s [E], n [E])."""
+    torch = _torch()
+    lo_b, hi_b = ac_low * ac_scale * 0.8, ac_high * ac_scale * 0.8
+    zero = torch.zeros_like(diff)
+    over = torch.where(diff > hi_b, diff / torch.full_like(diff, hi_b), zero)
+    under = torch.where(diff < lo_b, diff / torch.full_like(diff, lo_b), zero)
+    s = torch.clamp(torch.maximum(over, under).amax(dim=1), min=1.0)
+    return s, s.to(torch.int64)        # int(): truncation
+
+
+def max_interpolation_steps(action_range: float, ac_scale: float) -> int:
+    """Upper bound of the step count for targets produced by `action_to_displacement` (|diff_j| <= action_range)."""
+    return int(np.floor(action_range / (0.8 * ac_scale) * (1 + 1e-12))) + 1
+
+
+def simple_interpolate_batch(bp, curr_qpos, target_qpos, ac_scale: float, ref_idx: Sequence[int], ac_low: float = -1.0,
+                             ac_high: float = 1.0, max_steps: int = 64, fixed_steps: int = 0):
+    """Straight-line pre-check for E envs at once.
+
+    curr_qpos / target_qpos: [E, nq] float64 tensors (curr already clipped by `JointLimits.clip_state`).  Returns
+    (traj [E, K+1, nq], traj_len [E], success [E] bool, n_steps [E]): row e holds its int(s_e) interpolated states
+    followed by the exact target, success[e] is False when one of them is invalid -- then traj_len[e] counts the valid
+    prefix + the target.  All E x K states are validated in ONE launch.  K = the largest step count of the batch (one
+    host read-back) or, with `fixed_steps` > 0, that constant (no read-back; rows that would need more raise later
+    through `n_steps`, callers pass `max_interpolation_steps`)."""
+    torch = _torch()
     E, nq = curr_qpos.shape
-    idx = torch.as_tensor(list(ref_idx), device=curr_qpos.device)
-    n = len(idx)
-    assert list(ref_idx) == list(range(n)), "the reference slices qpos[:n] (rl/sac_agent.py:275-278)"
-    min_action, max_action = ac_low * ac_scale * 0.8, ac_high * ac_scale * 0.8
-    diff = target_qpos[:, :n] - curr_qpos[:, :n]
-    # NB: `tensor / python_float` is evaluated as a multiplication by the reciprocal on the GPU (1 ulp off);
-    # dividing by a tensor keeps IEEE division, i.e. bit-identical waypoints to the numpy reference
-    t_max = torch.full_like(diff, max_action)
-    t_min = torch.full_like(diff, min_action)
-    scale_pos = torch.where(diff > max_action, diff / t_max, torch.zeros_like(diff))
-    scale_neg = torch.where(diff < min_action, diff / t_min, torch.zeros_like(diff))
-    scaling = torch.clamp(torch.maximum(scale_pos, scale_neg).amax(dim=1), min=1.0)
-    n_steps = scaling.to(torch.int64)                     # int() truncation, as the reference
-    if int(n_steps.max().item()) > max_steps:
-        raise ValueError(f"interpolation needs {int(n_steps.max().item())} steps > max_steps={max_steps}")
-    K = max(1, int(n_steps.max().item()))
-    scaled = diff / scaling[:, None]
-    # the reference accumulates `interp_qpos += scaled_ac` step by step: same order of additions => same rounding
-    acc = curr_qpos[:, :n].clone()
-    rows = []
-    for _ in range(K):
-        acc = acc + scaled
-        rows.append(acc)
-    steps = torch.stack(rows, dim=1)
-    q_active = steps.reshape(E * K, n).contiguous()
+    n = len(ref_idx)
+    if list(ref_idx) != list(range(n)):
+        raise ValueError("the interpolated joints must be qpos[:n] (the reference slices qpos[:len(ref_joint_pos_indexes)])")
     if n < bp.na:
         raise ValueError("planner has more active joints than the interpolated ones")
-    valid = bp.is_valid(q_active, curr_qpos.contiguous(), samples_per_env=K).reshape(E, K).bool()
+    diff = target_qpos[:, :n] - curr_qpos[:, :n]
+    scaling, n_steps = interpolation_steps(diff, ac_scale, ac_low, ac_high)
+    if fixed_steps > 0:
+        K = int(fixed_steps)
+    else:
+        K = max(1, int(n_steps.max().item()))
+        if K > max_steps:
+            raise ValueError(f"interpolation needs {K} steps > max_steps={max_steps}")
+    per_step = diff / scaling[:, None]
+    # running sum cur + d + d + ... as K dependent additions (k*d, or a parallel prefix sum, would round differently)
+    acc, rows = curr_qpos[:, :n], []
+    for _ in range(K):
+        acc = acc + per_step
+        rows.append(acc)
+    walk = torch.stack(rows, dim=1)
+    valid = bp.is_valid(walk.reshape(E * K, n).contiguous(), curr_qpos.contiguous(), samples_per_env=K).reshape(E, K).bool()
     k_idx = torch.arange(K, device=valid.device)[None, :]
-    in_range = k_idx < n_steps[:, None]
-    bad = (~valid) & in_range
-    first_bad = torch.where(bad.any(dim=1), torch.argmax(bad.int(), dim=1), n_steps)
-    success = ~bad.any(dim=1)
-    n_keep = torch.minimum(first_bad, n_steps)
+    bad = (~valid) & (k_idx < n_steps[:, None])
+    blocked = bad.any(dim=1)
+    n_keep = torch.where(blocked, torch.argmax(bad.int(), dim=1), n_steps).clamp(max=K)
     traj = curr_qpos[:, None, :].repeat(1, K + 1, 1)
-    traj[:, :K, :n] = steps
-    # the exact target goes right after the kept prefix
-    traj[torch.arange(E, device=traj.device), n_keep] = target_qpos
-    return traj, n_keep + 1, success, n_steps
+    traj[:, :K, :n] = walk
+    traj[torch.arange(E, device=traj.device), n_keep] = target_qpos          # the exact target right after the kept prefix
+    return traj, n_keep + 1, ~blocked, n_steps
 
 
 def handle_invalid_target_batch(bp, curr_qpos, target_qpos, step_size: float, num_trials: int):
-    """`handle_invalid_target` for E envs at once: every iteration moves the still-invalid targets one step and
-    re-checks all of them with one launch.  Returns (target_qpos [E, nq], n_trials [E], valid [E] bool)."""
-    import torch
+    """Back-off of invalid planner targets, host-orchestrated form (the product path is the one-launch
+    `BatchPlanner.pullback`; this form is its cross-check): every iteration moves the still-invalid targets by
+    step_size * d / |d|, d = current - target over the whole qpos vector, and re-validates them with one launch.
+    Returns (target [E, nq], n_trials [E], valid [E] bool).  |d| sums the squares left to right over the columns in
+    which some env differs from its current state (all-zero columns contribute +0.0 and cannot change a non-negative
+    running sum), the order `BatchPlanner.pullback` uses."""
+    torch = _torch()
     target = target_qpos.clone()
-    E, nq = target.shape
-    na = bp.na
-    act = torch.as_tensor(bp.scene.active_idx.astype("int64"), device=target.device)
+    E = target.shape[0]
+    act = torch.as_tensor(np.asarray(bp.scene.active_idx).astype("int64"), device=target.device)
 
-    def check(t):
-        # the target's own passive entries are part of the state being validated
+    def check(t):       # the target's own passive entries are part of the state being validated
         return bp.is_valid(t[:, act].contiguous(), t.contiguous(), samples_per_env=1).bool()
 
     valid = check(target)
     trials = torch.zeros(E, dtype=torch.int64, device=target.device)
-    # Columns in which no env's target differs from its current state stay that way (their step is 0 / norm = 0), and
-    # their squares are +0.0, which leaves a non-negative running sum bit-for-bit unchanged: the sequential sum below
-    # visits only the other columns (the arm joints), in the same left-to-right order as norm_seq.
     cols = torch.nonzero(((curr_qpos - target) != 0).any(dim=0)).flatten().tolist()
     for _ in range(num_trials):
         todo = ~valid
-        if not bool(todo.any().item()):
+        if not bool(todo.any()):
             break
         d = curr_qpos - target
         sq = d * d
         acc = torch.zeros_like(sq[:, 0])
         for c in cols:
             acc = acc + sq[:, c]
-        step = step_size * d / torch.sqrt(acc)[:, None]
-        target = torch.where(todo[:, None], target + step, target)
+        target = torch.where(todo[:, None], target + step_size * d / torch.sqrt(acc)[:, None], target)
         trials += todo.to(torch.int64)
         valid = torch.where(todo, check(target), valid)
     return target, trials, valid

@@ -247,6 +247,13 @@ class BatchKinematicPushEnv:
         return out
 
 
+def make_env(env_name: str, num_envs: int, **kwargs):
+    """Batched kinematic env by the reference's gym id (`gym.make(config.env, ...)`, rl/trainer.py:49)."""
+    if env_name == BatchKinematicPushEnv.env_name:
+        return BatchKinematicPushEnv(num_envs, **kwargs)
+    raise _lib.MopaError(f"no batched kinematic env for {env_name!r}")
+
+
 class SawyerPushObstacleKinematicEnv:
     """Single-env facade with the reference call shapes: `reset() -> ob`, `step(action, is_planner=False) ->
     (ob, reward, done, info)` with `ob` an OrderedDict of numpy arrays (env/base.py:229-246)."""

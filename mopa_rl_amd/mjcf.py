@@ -163,6 +163,11 @@ class CompiledModel:
     mesh_vertadr: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))     # [nmesh]
     mesh_vertnum: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))     # [nmesh]
     mesh_vert: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), dtype=np.float64)) # [nmeshvert,3]
+    # joint actuators (<actuator><position|motor|velocity joint=...>), in document order = MuJoCo's ctrl order
+    act_names: List[str] = field(default_factory=list)
+    act_joint: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))        # [nu] joint id
+    act_ctrllimited: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))  # [nu]
+    act_ctrlrange: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), dtype=np.float64))
     meta: Dict[str, object] = field(default_factory=dict)
 
     # ---- name lookups mirroring the mujoco-py calls the reference makes ----
@@ -195,13 +200,15 @@ class CompiledModel:
         "site_quat"
     ).split()
     _OPTIONAL = "geom_dataid mesh_vertadr mesh_vertnum mesh_vert".split()   # absent in scenes without collidable meshes
+    _ACT = "act_joint act_ctrllimited act_ctrlrange".split()                  # absent in scenes compiled before actuators were kept
     _LISTS = "body_names jnt_names all_geom_names geom_mesh site_names".split()
 
     def to_json(self) -> str:
         d = {"name": self.name, "nq": self.nq, "meta": self.meta}
         for k in self._LISTS:
             d[k] = getattr(self, k)
-        for k in self._ARRAYS + ([k for k in self._OPTIONAL] if len(self.mesh_vertnum) else []):
+        d["act_names"] = list(self.act_names)
+        for k in self._ARRAYS + ([k for k in self._OPTIONAL] if len(self.mesh_vertnum) else []) + self._ACT:
             a = getattr(self, k)
             d[k] = {"dtype": str(a.dtype), "shape": list(a.shape),
                     "data": [float(x).hex() if a.dtype.kind == "f" else int(x) for x in a.ravel()]}
@@ -213,7 +220,8 @@ class CompiledModel:
         kw = {"name": d["name"], "nq": d["nq"], "meta": d.get("meta", {})}
         for k in cls._LISTS:
             kw[k] = list(d[k])
-        for k in cls._ARRAYS + [k for k in cls._OPTIONAL if k in d]:
+        kw["act_names"] = list(d.get("act_names", []))
+        for k in cls._ARRAYS + [k for k in cls._OPTIONAL + cls._ACT if k in d]:
             e = d[k]
             if e["dtype"].startswith("float"):
                 a = np.array([float.fromhex(x) for x in e["data"]], dtype=np.float64)
@@ -546,6 +554,16 @@ class _Builder:
             # the geom frame follows the re-centred mesh; size = half extents of the hull's AABB (as MuJoCo reports it)
             g["pos"] = g["pos"] + _quat_rotate(g["quat"], centroid)
             g["size"] = 0.5 * (hv.max(0) - hv.min(0))
+        acts = []
+        jnames = [j["name"] for j in self.joints]
+        for sec in self.root.findall("actuator"):
+            for el in sec:
+                at = self._attrs(el, None)
+                if "joint" not in at:
+                    raise MjcfError(f"actuator <{el.tag}> without joint= is not supported by this MJCF subset")
+                acts.append({"name": at.get("name", ""), "joint": jnames.index(at["joint"]),
+                             "limited": int(at.get("ctrllimited", "false") == "true"),
+                             "range": (_floats(at.get("ctrlrange", "0 0")) + [0.0, 0.0])[:2]})
         nj = len(self.joints)
         jr = np.zeros((nj, 2))
         for i, j in enumerate(self.joints):
@@ -582,6 +600,9 @@ class _Builder:
             site_body=arr(self.sites, "body", np.int32),
             site_pos=arr(self.sites, "pos", np.float64, (len(self.sites), 3)),
             site_quat=arr(self.sites, "quat", np.float64, (len(self.sites), 4)),
+            act_names=[a["name"] for a in acts], act_joint=arr(acts, "joint", np.int32),
+            act_ctrllimited=arr(acts, "limited", np.int32),
+            act_ctrlrange=np.array([a["range"] for a in acts], dtype=np.float64).reshape(-1, 2),
             meta={"source": os.path.basename(self.xml_path)},
         )
 

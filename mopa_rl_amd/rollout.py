@@ -29,7 +29,8 @@ from typing import Dict, Optional
 import numpy as np
 
 from . import _lib
-from .agent_planning import handle_invalid_target_batch, simple_interpolate_batch
+from .agent_planning import (JointLimits, action_to_displacement, displacement_to_action, interpolation_steps,
+                             is_planner_action, simple_interpolate_batch)
 from .batch import BatchPlanner, _torch
 from .planner import ITERS_PER_SECOND
 from .scene import ENV_SPECS, planner_inputs
@@ -61,62 +62,42 @@ class RolloutConfig:
     seed: int = 1234
 
 
-def invert_displacement_np(displacement, ac_scale, cfg):
-    """rl/sac_agent.py:177-196 (numpy, as the host-side relabelling uses it)"""
-    if cfg.ac_space_type == "normal":
-        return displacement / cfg.action_range
-    om = cfg.omega
-    return np.where(np.abs(displacement) < ac_scale, displacement * (om / ac_scale),
-                    np.sign(displacement) * ((np.abs(displacement) - ac_scale) / ((cfg.action_range - ac_scale) / (1.0 - ac_scale))
-                                             / ((1.0 - ac_scale) / (1.0 - om)) + om))
-
-
 def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30):
     """The `reuse_data` relabelling of rl/mopa_rollouts.py:204-300 on the record of one `agent_step(..., record=True)`:
     for every env that executed a planner path with more than 3 waypoints, up to min(len, max_reuse_data) random
     (start, goal) waypoint pairs become extra transitions  ob_list[start] --inverse-displacement action--> ob_list[goal]
     with reward (meta_rew[goal] - meta_rew[start]) * gamma^-(start+1), done = done_list[goal],
     intra_steps = goal - start - 1, kept only if the relabelled action is a planner action inside [-1, 1].
-    `rng` is a numpy RandomState-like object (`randint(low, high)`); the reference draws from the global np.random.
+    `rng`: a numpy RandomState-like object (`randint(low, high)`) shared by all envs, or a callable env -> such an object
+    (the reference draws from the global np.random, one env per process).
     Returns a list of dicts (env, start, goal, ob, ac, rew, done, intra_steps, ob_next) of numpy values."""
     rec = out["record"]
     ob, mr, dn, wp = (rec[k].cpu().numpy() for k in ("ob", "meta_rew", "done", "waypoint"))
     nexec = rec["n_exec"].cpu().numpy()
     extra = []
     for e in np.where(nexec > 3)[0]:
+        draw = rng(int(e)) if callable(rng) else rng
         L = int(nexec[e])
-        pairs = []
+        seen = set()
         for _ in range(min(L, max_reuse_data)):
-            start = rng.randint(low=0, high=L - 1)
+            start = draw.randint(low=0, high=L - 1)
             if start + 1 > L - 1:
                 continue
-            goal = rng.randint(low=start + 1, high=L)
-            if (start, goal) in pairs:
+            goal = draw.randint(low=start + 1, high=L)
+            if (start, goal) in seen:
                 continue
-            pairs.append((start, goal))
-            ac = invert_displacement_np(wp[e, goal, :n_arm] - wp[e, start, :n_arm], cfg.ac_scale, cfg)   # env.form_action(traj[goal], traj[start])
-            if not (np.any(ac < -cfg.omega) or np.any(ac > cfg.omega)):      # pi.is_planner_ac
-                continue
-            if not (np.all(ac >= -1.0) and np.all(ac <= 1.0)):               # pi.valid_action
+            seen.add((start, goal))
+            # env.form_action(traj[goal], traj[start]) -> pi.invert_displacement
+            ac = displacement_to_action(wp[e, goal, :n_arm] - wp[e, start, :n_arm], cfg.ac_scale, cfg.omega, cfg.action_range,
+                                        cfg.ac_space_type)
+            is_planner = bool(np.any(ac < -cfg.omega) or np.any(ac > cfg.omega))
+            in_box = bool(np.all(ac >= -1.0) and np.all(ac <= 1.0))
+            if not (is_planner and in_box):
                 continue
             rew = (mr[e, goal] - mr[e, start]) * cfg.discount_factor ** (-(start + 1))
             extra.append({"env": int(e), "start": start, "goal": goal, "ob": ob[e, start], "ac": ac, "rew": float(rew),
                           "done": int(dn[e, goal]), "intra_steps": goal - start - 1, "ob_next": ob[e, goal]})
     return extra
-
-
-def convert2planner_displacement(ac, ac_scale, cfg):
-    """rl/sac_agent.py:158-175 on tensors (divisions by tensors: `tensor / python_float` is a reciprocal multiply)."""
-    torch = _torch()
-    if cfg.ac_space_type == "normal":
-        return ac * cfg.action_range
-    if cfg.ac_space_type != "piecewise":
-        raise NotImplementedError(cfg.ac_space_type)
-    om = cfg.omega
-    inner = ac / torch.full_like(ac, om / ac_scale)
-    frac = (ac.abs() - om) / torch.full_like(ac, 1 - om)
-    outer = torch.sign(ac) * (ac_scale + (cfg.action_range - ac_scale) * frac)
-    return torch.where(ac.abs() < om, inner, outer)
 
 
 class BatchMoPARollout:
@@ -141,12 +122,7 @@ class BatchMoPARollout:
         assert self.arm == list(range(self.n)), "the reference slices qpos[:n] (rl/sac_agent.py:275-278)"
         f = env.facts
         dev, f64 = env.device, torch.float64
-        lim = f.qpos_limited.astype(bool)
-        self._lo = torch.tensor(np.where(lim, f.qpos_min, -np.inf), dtype=f64, device=dev)
-        self._hi = torch.tensor(np.where(lim, f.qpos_max, np.inf), dtype=f64, device=dev)
-        self._lim = torch.tensor(lim, device=dev)
-        self._lo_m = torch.tensor(np.where(lim, f.qpos_min + self.cfg.joint_margin, -np.inf), dtype=f64, device=dev)
-        self._hi_m = torch.tensor(np.where(lim, f.qpos_max - self.cfg.joint_margin, np.inf), dtype=f64, device=dev)
+        self.limits = JointLimits(f.qpos_min, f.qpos_max, f.qpos_limited, self.cfg.joint_margin, device=dev)
         self.counters: Dict[str, "object"] = {k: torch.zeros(self.E, dtype=torch.int64, device=dev) for k in COUNTERS}
         self.t = 0     # agent steps taken (part of the RNG stream of the planner queries)
         self.main_iters = max(1, int(round(self.cfg.timelimit * ITERS_PER_SECOND)))
@@ -159,12 +135,8 @@ class BatchMoPARollout:
         self.simple_scene.close()
 
     def clip_qpos(self, q):
-        """`SACAgent.clip_qpos` (rl/sac_agent.py:237-260) per row: rows with a limited joint out of range are clipped to
-        [min + joint_margin, max - joint_margin]; other rows are untouched."""
-        torch = _torch()
-        out = ((q < self._lo) | (q > self._hi)).any(dim=1)
-        clipped = torch.minimum(torch.maximum(q, self._lo_m), self._hi_m)
-        return torch.where(out[:, None], clipped, q)
+        """`SACAgent.clip_qpos` (rl/sac_agent.py:237-260) per row, with the float32 limits the agents hold."""
+        return self.limits.clip_state(q)
 
     def _valid(self, q):
         return self.bp.is_valid(q[:, self.arm].contiguous(), q.contiguous(), samples_per_env=1).bool()
@@ -240,58 +212,49 @@ class BatchMoPARollout:
         return traj_t, lens, success, interpolation, valid, exact
 
     def _densify(self, trajs, seg_jobs, cur_h, ids_h):
-        """:210-233 -- every planner-path segment longer than ac_scale in some joint is replaced by
-        `simple_interpolate(start, end, ac_scale, use_planner=True)`; all interpolated states of all segments are
-        validated in ONE launch, the (rare) segments with an invalid interpolated state fall back to the single-query
-        planners exactly as the scalar code does."""
+        """rl/sac_agent.py:216-233 -- a planner-path segment longer than ac_scale in some joint is replaced by the
+        straight-line rule (steps <= 0.8 ac_scale from the segment's clipped start, then the segment's end).  All segments
+        of all envs are cut at once and all their interior states validated in ONE launch; the (rare) segments with an
+        invalid interior state fall back to the single-query planners: simple planner, main planner, else [end]
+        (:300-313)."""
         torch = _torch()
-        cfg, n = self.cfg, self.n
-        max_action, min_action = 1.0 * cfg.ac_scale * 0.8, -1.0 * cfg.ac_scale * 0.8
-        pieces, states_all, owner = [], [], []
-        for (m, i, start, end) in seg_jobs:
-            diff = end[:n] - start[:n]
-            out = np.where((diff > max_action) | (diff < min_action))[0]
-            od = diff[out]
-            scales = np.where(od > max_action, od / max_action, od / min_action)
-            sf = 1.0 if len(scales) == 0 else max(max(scales), 1.0)
-            scaled = diff / sf
-            interp, rows = start.copy(), []
-            for _ in range(int(sf)):
-                interp = interp.copy()
-                interp[:n] += scaled
-                rows.append(interp)
-            pieces.append(rows)
-            states_all.extend(rows)
-            owner.extend([len(pieces) - 1] * len(rows))
-        ok = np.ones(len(states_all), dtype=bool)
-        if states_all:
-            q = torch.tensor(np.array(states_all), device=self.env.device)
-            ok = self._valid(q).cpu().numpy()
-        owner = np.array(owner, dtype=np.int64)
+        cfg, n, nq = self.cfg, self.n, self.nq
+        S = len(seg_jobs)
+        starts = np.stack([self.limits.clip_state_np(j[2]) for j in seg_jobs])      # :266 clip_qpos on every segment start
+        ends = np.stack([j[3] for j in seg_jobs])
+        bound = cfg.ac_scale * 0.8
+        diff = ends[:, :n] - starts[:, :n]
+        ratio = np.maximum(np.where(diff > bound, diff / bound, 0.0), np.where(diff < -bound, diff / -bound, 0.0))
+        scale = np.maximum(ratio.max(axis=1), 1.0)
+        count = scale.astype(np.int64)                                              # int(): truncation
+        per_step = diff / scale[:, None]
+        K = int(count.max())
+        walk = np.repeat(starts[:, None, :], K, axis=1)
+        acc = starts[:, :n].copy()
+        for k in range(K):                                                          # K dependent additions, as the scalar rule
+            acc = acc + per_step
+            walk[:, k, :n] = acc
+        live = np.arange(K)[None, :] < count[:, None]
+        verdict = np.ones((S, K), dtype=bool)
+        verdict[live] = self._valid(torch.tensor(walk[live], device=self.env.device)).cpu().numpy()
+        clear = verdict.all(axis=1)
         replacement = {}
-        for k, (m, i, start, end) in enumerate(seg_jobs):
-            v = ok[owner == k]
-            if v.all():
-                replacement[(m, i)] = pieces[k] + [end]
+        for k, (m, i, _, end) in enumerate(seg_jobs):
+            if clear[k]:
+                replacement[(m, i)] = list(walk[k, :count[k]]) + [end]
                 continue
-            # simple planner, then main planner, then give up with [target] (rl/sac_agent.py:303-313)
             e = int(ids_h[m])
-            res = None
+            found = None
             for scene, iters, base in ((self.simple_scene, self.simple_iters, 1), (self.scene, self.main_iters, 2)):
-                st, p, _ = scene.plan(start, end, max_iters=iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path,
+                st, p, _ = scene.plan(starts[k], end, max_iters=iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path,
                                       seed=cfg.seed + self.t, env_id=self.E * base + e)
                 if st == 0:
-                    tr = [start]
-                    for s in range(1, len(p)):
-                        tr.append(tr[-1] + (p[s] - p[s - 1]))
-                    res = tr[1:]
+                    # SamplingBasedPlanner.plan: start + running sum of successive differences; PlannerAgent drops row 0
+                    found = list(np.add.accumulate(np.vstack([starts[k][None], p[1:] - p[:-1]]), axis=0)[1:])
                     break
-            replacement[(m, i)] = res if res is not None else [end]
-        for m in sorted({mm for (mm, _, _, _) in seg_jobs}):
-            new = []
-            for i in range(len(trajs[m])):
-                new.extend(replacement.get((m, i), [trajs[m][i]]))
-            trajs[m] = np.array(new)
+            replacement[(m, i)] = found if found is not None else [end]
+        for m in sorted({j[0] for j in seg_jobs}):
+            trajs[m] = np.array([row for i in range(len(trajs[m])) for row in replacement.get((m, i), [trajs[m][i]])])
 
     # ------------------------------------------------------------------
     def agent_step(self, ac, record: bool = False):
@@ -322,17 +285,17 @@ class BatchMoPARollout:
         prev_ob = env.obs.clone()
         cur = env.qpos.clone()
         ar = torch.arange(E, device=dev)
-        is_pl = ((a < -cfg.omega) | (a > cfg.omega)).any(dim=1)
+        is_pl = is_planner_action(a, cfg.omega)
         plan_ok = torch.zeros(E, dtype=torch.bool, device=dev)
         path_len = torch.zeros(E, dtype=torch.int64, device=dev)
         traj_pad = None
         pl_idx = torch.nonzero(is_pl).flatten()
         if len(pl_idx):
-            disp = convert2planner_displacement(a[pl_idx], cfg.ac_scale, cfg)
+            disp = action_to_displacement(a[pl_idx], cfg.ac_scale, cfg.omega, cfg.action_range, cfg.ac_space_type)
             target = cur[pl_idx].clone()
             target[:, :n] += disp
             # np.clip to the joint limits, unlimited entries restored (:121-131)
-            target = torch.where(self._lim, torch.minimum(torch.maximum(target, self._lo), self._hi), target)
+            target = self.limits.clip_target(target)
             if cfg.invalid_target_handling:
                 target, _, tv = self.bp.pullback(cur[pl_idx].contiguous(), target.contiguous(), cfg.step_size, cfg.num_trials)
                 tv = tv.bool()

@@ -1,7 +1,8 @@
-"""Batched rollout step (mopa_rl_amd/rollout.py) against a per-env scalar restatement of the
-reference loop (rl/mopa_rollouts.py:70-375 + rl/sac_agent.py:148-318) that runs entirely on the CPU oracle
-(validity, RRT-Connect, kinematic env).  Same actions, same RNG streams => every env must end every agent step in the
-same state with the same SMDP reward / done / intra_steps / counters, bit for bit."""
+"""Batched rollout step (mopa_rl_amd/rollout.py) against fixtures produced by running the reference's own
+rollout runner in the build container (tools/gen_ref_py_golden.py): same actions, same RNG streams => every env must end
+every agent step in the same state with the same SMDP reward / done / intra_steps / counters."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,207 +11,90 @@ pytestmark = pytest.mark.gpu
 ENV = "SawyerPushObstacle-v0"
 
 
-class _Cfg:
-    pass
-
-
 def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 
 
-class OrcAgent:
-    """PlannerAgent-like (rl/planner_agent.py:42-58 over sampling_based_planner.py:57-100) on the CPU oracle."""
-
-    def __init__(self, orc, range_, max_nodes, max_path, ids):
-        self.orc, self.range, self.max_nodes, self.max_path, self.ids = orc, range_, max_nodes, max_path, ids
-        self.seed, self.calls = 0, 0
-
-    def isValidState(self, q):
-        return bool(self.orc.is_valid(np.asarray(q, dtype=np.float64))[0])
-
-    def plan(self, start, goal, timelimit):
-        iters = max(1, int(round(timelimit * 2000)))
-        env_id = self.ids[min(self.calls, len(self.ids) - 1)]
-        self.calls += 1
-        st, path, _, _ = self.orc.plan(start, goal, self.range, max_iters=iters, max_nodes=self.max_nodes, seed=self.seed,
-                                       env_id=env_id, max_path=self.max_path)
-        if st != 0:
-            return np.full((1, len(start)), float(st)), False, st != -5, st != -4
-        tr = [np.asarray(start, dtype=np.float64)]
-        for s in range(1, len(path)):
-            tr.append(tr[-1] + (path[s] - path[s - 1]))
-        return np.array(tr[1:]), True, True, True
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def _scalar_agent(pi, facts, cfg, main, simple):
-    from mopa_rl_amd.agent_planning import PlanningMixin
-    from mopa_rl_amd.scene import qpos_joint_arrays
-
-    class Agent(PlanningMixin):
-        pass
-
-    a = Agent()
-    c = _Cfg()
-    for k in ("omega", "ac_space_type", "action_range", "timelimit", "simple_planner_timelimit", "interpolation", "joint_margin"):
-        setattr(c, k, getattr(cfg, k))
-    a._config, a._planner, a._simple_planner = c, main, simple
-    a._ref_joint_pos_indexes = list(facts.arm_qpos_idx)
-    a._jnt_indices, a._jnt_minimum, a._jnt_maximum, a._is_jnt_limited = qpos_joint_arrays(pi.model)
-    a._ac_low, a._ac_high = -1.0, 1.0
-    return a
-
-
-def _scalar_agent_step(e, E, t, ac, ref, agent, main, simple, cfg, counters):
-    """one iteration of the reference's `while not done` loop for env e (mopa_rollouts.py:70-375)"""
-    from mopa_rl_amd.agent_planning import clip_target_to_limits, handle_invalid_target
-    n = 7
-    main.seed = simple.seed = cfg.seed + t
-    main.calls = simple.calls = 0
-    main.ids, simple.ids = [e, 2 * E + e], [E + e]
-
-    def env_step(a, is_planner, flag):
-        acts = np.zeros((ref.E, n))
-        acts[e] = a
-        ref._call(e, acts, is_planner, flag)
-        return float(ref.reward[e]), int(ref.done[e])
-
-    curr = ref.qpos[e].copy()
-    if agent.is_planner_ac(ac):
-        disp = agent.convert2planner_displacement(ac[:n], cfg.ac_scale)
-        target = curr.copy()
-        target[:n] += disp
-        target = clip_target_to_limits(target, agent._jnt_minimum[agent._jnt_indices], agent._jnt_maximum[agent._jnt_indices],
-                                       agent._is_jnt_limited[agent._jnt_indices])
-        if cfg.invalid_target_handling and not agent.isValidState(target):
-            target, _ = handle_invalid_target(agent, curr, target, cfg.step_size, cfg.num_trials)[:2]
-        if agent.isValidState(target):
-            traj, success, interpolation, valid, exact = agent.plan(curr, target, ac_scale=cfg.ac_scale)
-        else:
-            success, valid, exact = False, False, True
-        if success:
-            counters["interpolation" if interpolation else "mp"][e] += 1
-            meta, done, intra = 0.0, 0, 0
-            for i, nxt in enumerate(traj):
-                r, done = env_step(nxt[:n] - ref.qpos[e, :n], True, 1)
-                meta += (cfg.discount_factor ** i) * r
-                intra = i
-                if done:
-                    break
-            out = (meta, done, intra)
-        else:
-            counters["mp_fail"][e] += 1
-            counters["approximate"][e] += int(not exact)
-            counters["invalid"][e] += int(not valid)
-            r, done = env_step(np.zeros(n), False, 0)
-            out = (r, done, 0)
-    else:
-        counters["rl"][e] += 1
-        r, done = env_step(ac[:n] / cfg.omega, False, 1)
-        out = (r, done, 0)
-    ref.has_prev[e] = 0
-    return out
-
-
-def test_batched_rollout_equals_scalar_oracle_rollout(oracle_mod):
+def _load_state(env, qpos, ep_len):
+    """put every env into a recorded state (qpos row + episode length), fresh `_prev_state`, refreshed obs"""
     import torch
-    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv, push_env_facts
-    from mopa_rl_amd.rollout import COUNTERS, BatchMoPARollout, RolloutConfig
-    from mopa_rl_amd.scene import planner_inputs
-    E, T = 96, 5
-    cfg = RolloutConfig(max_nodes=512, max_path=128, timelimit=0.15)       # 300 RRT iterations keep the CPU side quick
-    env = BatchKinematicPushEnv(E, seed=5, max_episode_steps=12)
+    env.set_state(torch.tensor(qpos, device=env.device))
+    env.ep_len.copy_(torch.tensor(ep_len, dtype=torch.int32, device=env.device))
+
+
+def _make(G, E, **kw):
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    timelimit, max_nodes, max_path, seed, max_episode_steps, num_trials = G["params"]
+    env = make_env(ENV, E, seed=0, max_episode_steps=int(max_episode_steps))
     env.reset()
-    ro = BatchMoPARollout(env, cfg)
+    cfg = RolloutConfig(timelimit=float(timelimit), max_nodes=int(max_nodes), max_path=int(max_path), seed=int(seed),
+                        num_trials=int(num_trials), **kw)
+    return env, BatchMoPARollout(env, cfg)
 
-    pi = planner_inputs(ENV)
-    facts = push_env_facts(pi.model)
-    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, cfg.contact_threshold)
-    ref = oracle_mod.OraclePushEnv(orc, facts, E, ac_scale=cfg.ac_scale, max_episode_steps=12)
-    ref.set_state(env.qpos.cpu().numpy())
-    main = OrcAgent(orc, cfg.range, cfg.max_nodes, cfg.max_path, [0])
-    simple = OrcAgent(orc, cfg.simple_planner_range, cfg.max_nodes, cfg.max_path, [0])
-    agent = _scalar_agent(pi, facts, cfg, main, simple)
-    counters = {k: np.zeros(E, dtype=np.int64) for k in COUNTERS}
 
-    rng = np.random.default_rng(0)
-    seen = {k: 0 for k in COUNTERS}
+def test_batched_rollout_equals_reference_rollout_runner():
+    """Every agent step of every env against the REFERENCE'S OWN `MoPARolloutRunner.run` (rl/mopa_rollouts.py:70-375), run in
+    the build container env by env on the same scripted actions with the reference's SACAgent / PlannerAgent /
+    SamplingBasedPlanner / env classes (tests/golden/ref_py_rollout_push.npz, tools/gen_ref_py_golden.py; validity, RRT-Connect
+    and FK underneath came from the CPU oracle, the physics from its kinematic limit).  Joint states, done flags,
+    intra_steps and the six counters must be identical; rewards and observations agree to round-off (the reference uses
+    np.tanh / np.linalg.norm, the kernel its own correctly-rounded-to-1-ulp tanh and a fixed summation order)."""
+    import torch
+    from mopa_rl_amd.rollout import COUNTERS
+    G = np.load(os.path.join(GOLD, "ref_py_rollout_push.npz"))
+    E, T = G["ac"].shape[:2]
+    env, ro = _make(G, E)
     for t in range(T):
-        ac = rng.uniform(-1, 1, size=(E, 7)) * rng.choice([0.6, 0.9, 1.0], size=(E, 1))
-        if t == 2:      # far targets towards the table / bin: blocked straight lines and invalid targets
-            ac[: E // 2, 1] = 1.0
-            ac[: E // 2, 3] = -1.0
-        out = ro.agent_step(torch.tensor(ac, device=env.device))
-        want = [_scalar_agent_step(e, E, t, ac[e], ref, agent, main, simple, cfg, counters) for e in range(E)]
-        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(ref.qpos)), f"step {t}: qpos"
-        assert np.array_equal(_bits(out["rew"].cpu().numpy()), _bits(np.array([w[0] for w in want]))), f"step {t}: reward"
-        assert np.array_equal(out["done"].cpu().numpy(), np.array([w[1] for w in want])), f"step {t}: done"
-        assert np.array_equal(out["intra_steps"].cpu().numpy(), np.array([w[2] for w in want])), f"step {t}: intra_steps"
-        assert np.array_equal(env.ep_len.cpu().numpy(), ref.ep_len), f"step {t}: ep_len"
-        assert np.array_equal(_bits(out["ob_next"].cpu().numpy()), _bits(ref.obs)), f"step {t}: ob_next"
-        for k in COUNTERS:
-            assert np.array_equal(ro.counters[k].cpu().numpy(), counters[k]), f"step {t}: counter {k}"
-        # episodes that ended are reset on both sides to the same fresh state
-        d = out["done"].bool()
-        if bool(d.any()):
-            env.reset(d)
-            dm = d.cpu().numpy()
-            q = env.qpos.cpu().numpy()
-            ref.qpos[dm] = q[dm]
-            ref.ep_len[dm] = 0
-            ref.has_prev[dm] = 0
-            for e in np.where(dm)[0]:
-                ref._call(e, None, 0, 1)
-    for k in COUNTERS:
-        seen[k] = int(counters[k].sum())
-    # every branch of the loop was exercised
-    assert seen["rl"] > 0 and seen["interpolation"] > 0 and seen["mp"] > 0 and seen["mp_fail"] > 0 and seen["invalid"] > 0, seen
+        _load_state(env, G["qpos_start"][:, t], G["ep_len_start"][:, t])
+        before = {k: ro.counters[k].clone() for k in COUNTERS}
+        ro.t = t
+        out = ro.agent_step(torch.tensor(G["ac"][:, t], device=env.device))
+        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(G["qpos_end"][:, t])), f"step {t}: qpos"
+        assert np.array_equal(out["done"].cpu().numpy().astype(np.int64), G["done"][:, t]), f"step {t}: done"
+        assert np.array_equal(out["intra_steps"].cpu().numpy(), G["intra"][:, t]), f"step {t}: intra_steps"
+        got_c = np.stack([(ro.counters[k] - before[k]).cpu().numpy() for k in COUNTERS], axis=1)
+        assert np.array_equal(got_c, G["counters"][:, t]), f"step {t}: counters"
+        np.testing.assert_allclose(out["rew"].cpu().numpy(), G["rew"][:, t], rtol=1e-12, atol=1e-13, err_msg=f"step {t}: reward")
+        np.testing.assert_allclose(out["ob"].cpu().numpy(), G["ob"][:, t], rtol=0, atol=1e-12, err_msg=f"step {t}: ob")
+        np.testing.assert_allclose(out["ob_next"].cpu().numpy(), G["ob_next"][:, t], rtol=0, atol=1e-12, err_msg=f"step {t}: ob_next")
+    tot = G["counters"].sum(axis=(0, 1))
+    assert (tot > 0).all(), dict(zip(COUNTERS, tot))           # every branch of the loop is in the fixture
+    assert G["done"].sum() > 0 and G["intra"].max() >= 8
 
 
-def test_reuse_data_relabelling(oracle_mod):
-    """`reuse_transitions` (rl/mopa_rollouts.py:204-300) on a recorded step: same random draws => the same relabelled
-    transitions as a direct transcription of the reference loop over the recorded lists; rewards telescope correctly."""
+def test_reuse_data_relabelling_equals_reference():
+    """`reuse_transitions` against the relabelled sub-trajectory transitions the reference's runner emitted (reuse_data=True,
+    rl/mopa_rollouts.py:204-300) on the same steps with the same random draws."""
     import torch
-    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
-    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig, invert_displacement_np, reuse_transitions
-    E = 64
-    cfg = RolloutConfig(max_nodes=512, max_path=128, timelimit=0.15)
-    env = BatchKinematicPushEnv(E, seed=9)
-    env.reset()
-    ro = BatchMoPARollout(env, cfg)
-    rng = np.random.default_rng(1)
-    ac = rng.uniform(-1, 1, size=(E, 7))
-    ac[:, 0] = np.sign(ac[:, 0]) * rng.uniform(0.85, 1.0, E)          # far targets: long interpolated paths
-    out = ro.agent_step(torch.tensor(ac, device=env.device), record=True)
-    rec = out["record"]
-    nexec = rec["n_exec"].cpu().numpy()
-    assert np.array_equal(nexec, np.where(out["plan_ok"].cpu().numpy(), out["intra_steps"].cpu().numpy() + 1, 0))
-    assert (nexec > 3).sum() > 10
-    # the last recorded waypoint carries the step's SMDP return and final obs
-    idx = torch.nonzero(out["plan_ok"]).flatten()
-    last = rec["n_exec"][idx] - 1
-    assert torch.equal(rec["meta_rew"][idx, last].view(torch.int64), out["rew"][idx].view(torch.int64))
-    assert torch.equal(rec["ob"][idx, last].view(torch.int64), out["ob_next"][idx].view(torch.int64))
-    got = reuse_transitions(out, cfg, 7, np.random.RandomState(5))
-    # direct transcription of the reference loop
-    ob, mr, dn, wp = (rec[k].cpu().numpy() for k in ("ob", "meta_rew", "done", "waypoint"))
-    rs = np.random.RandomState(5)
-    want = []
-    for e in np.where(nexec > 3)[0]:
-        ob_list, pairs = list(ob[e, :nexec[e]]), []
-        for _ in range(min(len(ob_list), 30)):
-            start = rs.randint(low=0, high=len(ob_list) - 1)
-            if start + 1 > len(ob_list) - 1:
-                continue
-            goal = rs.randint(low=start + 1, high=len(ob_list))
-            if (start, goal) in pairs:
-                continue
-            pairs.append((start, goal))
-            a = invert_displacement_np(wp[e, goal, :7] - wp[e, start, :7], cfg.ac_scale, cfg)
-            if (np.any(a < -cfg.omega) or np.any(a > cfg.omega)) and np.all(a >= -1) and np.all(a <= 1):
-                want.append((int(e), start, goal, (mr[e, goal] - mr[e, start]) * cfg.discount_factor ** (-(start + 1)), goal - start - 1))
-    assert [(t["env"], t["start"], t["goal"], t["rew"], t["intra_steps"]) for t in got] == want and len(got) > 5
-    for t in got[:20]:
-        assert np.array_equal(t["ob"], ob[t["env"], t["start"]]) and np.array_equal(t["ob_next"], ob[t["env"], t["goal"]])
+    from mopa_rl_amd.rollout import reuse_transitions
+    G = np.load(os.path.join(GOLD, "ref_py_rollout_push_reuse.npz"))
+    E, T = G["ac"].shape[:2]
+    env, ro = _make(G, E)
+    n_checked = 0
+    for t in range(T):
+        _load_state(env, G["qpos_start"][:, t], G["ep_len_start"][:, t])
+        ro.t = t
+        out = ro.agent_step(torch.tensor(G["ac"][:, t], device=env.device), record=True)
+        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(G["qpos_end"][:, t])), f"step {t}: qpos"
+        rec = out["record"]
+        nexec = rec["n_exec"].cpu().numpy()
+        assert np.array_equal(nexec, np.where(out["plan_ok"].cpu().numpy(), out["intra_steps"].cpu().numpy() + 1, 0))
+        got = reuse_transitions(out, ro.cfg, 7, lambda e: np.random.RandomState(1000 * e + t))
+        sel = G["x_t"] == t
+        want_env = G["x_env"][sel]
+        assert [g["env"] for g in got] == list(want_env), f"step {t}"
+        assert [g["intra_steps"] for g in got] == list(G["x_intra"][sel]) and [g["done"] for g in got] == list(G["x_done"][sel])
+        if len(got):
+            assert np.array_equal(_bits(np.array([g["ac"] for g in got])), _bits(G["x_ac"][sel])), f"step {t}: relabelled actions"
+            np.testing.assert_allclose([g["rew"] for g in got], G["x_rew"][sel], rtol=1e-12, atol=1e-13)
+            np.testing.assert_allclose(np.array([g["ob"] for g in got]), G["x_ob"][sel], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(np.array([g["ob_next"] for g in got]), G["x_ob_next"][sel], rtol=0, atol=1e-12)
+        n_checked += len(got)
+    assert n_checked == len(G["x_env"]) and n_checked > 30
 
 
 def test_pullback_kernel_equals_host_form(oracle_mod):

@@ -1,0 +1,89 @@
+"""A10 against the reference's own `SACAgent.simple_interpolate` / `SACAgent.plan` (rl/sac_agent.py:198-318), run in the
+build container on the Push scene with validity + RRT-Connect supplied by the CPU oracle (tests/golden/
+ref_py_agent_push.npz, tools/gen_ref_py_golden.py).  The batched forms must return the same waypoints bit for bit, the
+same lengths and the same success / interpolation / valid / exact flags.
+
+CPU leg: the batched code on CPU tensors with the oracle as validity checker (pins the host logic).  GPU leg: the
+product path -- HIP validity (K1), HIP RRT-Connect (K3) -- through BatchMoPARollout.plan."""
+import os
+import types
+
+import numpy as np
+import pytest
+
+ENV = "SawyerPushObstacle-v0"
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_agent_push.npz"))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+class OracleBP:
+    """BatchPlanner look-alike over the CPU oracle (test infrastructure)."""
+
+    def __init__(self, orc):
+        self.orc, self.na, self.nq = orc, orc.na, orc.nq
+        self.scene = types.SimpleNamespace(active_idx=orc.active_idx)
+
+    def is_valid(self, q_active, qpos_env, samples_per_env=None, **kw):
+        import torch
+        v, _ = self.orc.is_valid_batch(q_active.numpy(), qpos_env.numpy(), samples_per_env=samples_per_env, want_min_dist=False)
+        return torch.from_numpy(v)
+
+
+def _check_si(traj, tlen, success):
+    K = len(G["cur"])
+    for k in range(K):
+        assert int(tlen[k]) == G["si_len"][k], k
+        assert bool(success[k]) == bool(G["si_flags"][k, 0]), k
+        assert np.array_equal(_bits(traj[k, :tlen[k]]), _bits(G["si_traj"][k, :G["si_len"][k]])), k
+    assert 0 < G["si_flags"][:, 0].sum() < K
+
+
+def test_simple_interpolate_batch_equals_reference_cpu(oracle_mod):
+    import torch
+    from mopa_rl_amd.agent_planning import JointLimits, max_interpolation_steps, simple_interpolate_batch
+    from mopa_rl_amd.scene import planner_inputs, qpos_joint_arrays
+    pi = planner_inputs(ENV)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    idx, lo, hi, lim = qpos_joint_arrays(pi.model)
+    jl = JointLimits(lo[idx], hi[idx], lim[idx], pi.spec.joint_margin)
+    cur = jl.clip_state(torch.tensor(G["cur"]))
+    tgt = torch.tensor(G["tgt"])
+    traj, tlen, success, nst = simple_interpolate_batch(OracleBP(orc), cur, tgt, 0.05, pi.ref_joint_pos_indexes)
+    _check_si(traj.numpy(), tlen.numpy(), success.numpy())
+    # a fixed step budget (no host read-back of the step count) gives the same rows
+    fixed = max_interpolation_steps(0.5, 0.05)
+    assert fixed >= int(nst.max())
+    traj2, tlen2, success2, _ = simple_interpolate_batch(OracleBP(orc), cur, tgt, 0.05, pi.ref_joint_pos_indexes, fixed_steps=fixed)
+    _check_si(traj2.numpy(), tlen2.numpy(), success2.numpy())
+
+
+@pytest.mark.gpu
+def test_plan_batch_equals_reference_gpu():
+    import torch
+    from mopa_rl_amd.agent_planning import simple_interpolate_batch
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    timelimit, max_nodes, max_path, seed, ac_scale = G["params"]
+    K = len(G["cur"])
+    env = make_env(ENV, K, seed=0)
+    env.reset()
+    ro = BatchMoPARollout(env, RolloutConfig(timelimit=float(timelimit), max_nodes=int(max_nodes), max_path=int(max_path), seed=int(seed)))
+    cur, tgt = torch.tensor(G["cur"], device="cuda"), torch.tensor(G["tgt"], device="cuda")
+    v = ro._valid(tgt).cpu().numpy()
+    assert np.array_equal(v.astype(np.int64), G["tgt_valid"])
+    traj, tlen, success, _ = simple_interpolate_batch(ro.bp, ro.clip_qpos(cur), tgt, float(ac_scale), ro.arm)
+    _check_si(traj.cpu().numpy(), tlen.cpu().numpy(), success.cpu().numpy())
+    ids = torch.arange(K, device="cuda")
+    traj, lens, success, interpolation, valid, exact = ro.plan(cur, tgt, ids)
+    traj, lens = traj.cpu().numpy(), lens.cpu().numpy()
+    F = G["plan_flags"]
+    for k in range(K):
+        assert (bool(success[k]), bool(valid[k]), bool(exact[k])) == (bool(F[k, 0]), bool(F[k, 2]), bool(F[k, 3])), k
+        if success[k]:
+            assert bool(interpolation[k]) == bool(F[k, 1]), k
+            assert lens[k] == G["plan_len"][k], k
+            assert np.array_equal(_bits(traj[k, :lens[k]]), _bits(G["plan_traj"][k, :lens[k]])), k
+    assert (F[:, 0] & (1 - F[:, 1])).sum() >= 5 and (F[:, 2] == 0).sum() >= 5      # RRT paths and invalid goals both present

@@ -25,6 +25,15 @@ def _load_state(env, qpos, ep_len):
     env.ep_len.copy_(torch.tensor(ep_len, dtype=torch.int32, device=env.device))
 
 
+def _check_qpos(got, want, pulled_back, msg):
+    """Joint states are identical bit for bit -- except in steps whose target went through the invalid-target back-off: the
+    reference divides by np.linalg.norm (a BLAS dot, summation order build-dependent), the kernel sums the squares left to
+    right, so those targets agree to the last bit or two only."""
+    exact = pulled_back == 0
+    assert np.array_equal(_bits(got[exact]), _bits(want[exact])), msg
+    np.testing.assert_allclose(got[~exact], want[~exact], rtol=0, atol=1e-14, err_msg=msg)
+
+
 def _make(G, E, **kw):
     from mopa_rl_amd.kinematic_env import make_env
     from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
@@ -53,7 +62,7 @@ def test_batched_rollout_equals_reference_rollout_runner():
         before = {k: ro.counters[k].clone() for k in COUNTERS}
         ro.t = t
         out = ro.agent_step(torch.tensor(G["ac"][:, t], device=env.device))
-        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(G["qpos_end"][:, t])), f"step {t}: qpos"
+        _check_qpos(env.qpos.cpu().numpy(), G["qpos_end"][:, t], G["pulled_back"][:, t], f"step {t}: qpos")
         assert np.array_equal(out["done"].cpu().numpy().astype(np.int64), G["done"][:, t]), f"step {t}: done"
         assert np.array_equal(out["intra_steps"].cpu().numpy(), G["intra"][:, t]), f"step {t}: intra_steps"
         got_c = np.stack([(ro.counters[k] - before[k]).cpu().numpy() for k in COUNTERS], axis=1)
@@ -79,7 +88,7 @@ def test_reuse_data_relabelling_equals_reference():
         _load_state(env, G["qpos_start"][:, t], G["ep_len_start"][:, t])
         ro.t = t
         out = ro.agent_step(torch.tensor(G["ac"][:, t], device=env.device), record=True)
-        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(G["qpos_end"][:, t])), f"step {t}: qpos"
+        _check_qpos(env.qpos.cpu().numpy(), G["qpos_end"][:, t], G["pulled_back"][:, t], f"step {t}: qpos")
         rec = out["record"]
         nexec = rec["n_exec"].cpu().numpy()
         assert np.array_equal(nexec, np.where(out["plan_ok"].cpu().numpy(), out["intra_steps"].cpu().numpy() + 1, 0))
@@ -89,7 +98,7 @@ def test_reuse_data_relabelling_equals_reference():
         assert [g["env"] for g in got] == list(want_env), f"step {t}"
         assert [g["intra_steps"] for g in got] == list(G["x_intra"][sel]) and [g["done"] for g in got] == list(G["x_done"][sel])
         if len(got):
-            assert np.array_equal(_bits(np.array([g["ac"] for g in got])), _bits(G["x_ac"][sel])), f"step {t}: relabelled actions"
+            np.testing.assert_allclose(np.array([g["ac"] for g in got]), G["x_ac"][sel], rtol=0, atol=1e-12, err_msg=f"step {t}: relabelled actions")
             np.testing.assert_allclose([g["rew"] for g in got], G["x_rew"][sel], rtol=1e-12, atol=1e-13)
             np.testing.assert_allclose(np.array([g["ob"] for g in got]), G["x_ob"][sel], rtol=0, atol=1e-12)
             np.testing.assert_allclose(np.array([g["ob_next"] for g in got]), G["x_ob_next"][sel], rtol=0, atol=1e-12)

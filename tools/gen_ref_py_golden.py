@@ -352,7 +352,8 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
     nq = pi.model.nq
     out = dict(ac=AC, qpos_start=np.zeros((E, T, nq)), ep_len_start=np.zeros((E, T), dtype=np.int64), qpos_end=np.zeros((E, T, nq)),
                rew=np.zeros((E, T)), done=np.zeros((E, T), dtype=np.int64), intra=np.zeros((E, T), dtype=np.int64),
-               counters=np.zeros((E, T, len(COUNTERS)), dtype=np.int64), ob=None, ob_next=None)
+               counters=np.zeros((E, T, len(COUNTERS)), dtype=np.int64), ob=None, ob_next=None,
+               pulled_back=np.zeros((E, T), dtype=np.int64))
     extra = []              # reuse_data transitions: (e, t, ob, ac, rew, done, intra_steps, ob_next)
     for e in range(E):
         env = make_ref_env(env_name, seed=100 + e, max_episode_steps=P["max_episode_steps"])
@@ -365,7 +366,14 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
             np.random.seed(1000 * e + t)                    # the reuse_data relabelling draws from the global numpy RNG
             out["qpos_start"][e, t] = env.sim.data.qpos
             out["ep_len_start"][e, t] = env._episode_length
-            return OrderedDict(default=AC[e, t].copy()), None, None
+            a = OrderedDict(default=AC[e, t].copy())
+            if agent.is_planner_ac(a):      # will the runner's back-off move this step's target?  (it divides by np.linalg.norm,
+                n = len(env.ref_joint_pos_indexes)    # a BLAS dot whose summation order is build-dependent: such steps are compared to round-off)
+                tq = env.sim.data.qpos.copy()
+                tq[env.ref_joint_pos_indexes] += agent.convert2planner_displacement(a["default"][:n], env._ac_scale)
+                tq = np.clip(tq, env._jnt_minimum[env.jnt_indices], env._jnt_maximum[env.jnt_indices])
+                out["pulled_back"][e, t] = int(not agent.isValidState(tq))
+            return a, None, None
 
         agent.act = act
         runner = object.__new__(MoPARolloutRunner)

@@ -48,17 +48,21 @@ def host_cores():
     return n
 
 
-def make_inputs(torch, pi, E, S, seed, device, mode="mixed"):
+def make_inputs(torch, pi, E, S, seed, device, mode="mixed", env=None):
     """States for E envs x S states: first half of every env's block uniform in the joint box (what the RRT
     sampler draws), second half near the env's initial pose (what motion validation sees).  Per-env passive
-    block: gripper slides U(-0.008, 0.015), cube pose nominal + U(+-0.05) in xy."""
+    block: gripper slides uniform in their joint range, the free-jointed object (cube / can / furniture) at its nominal pose
+    + U(+-0.05) in xy."""
+    from mopa_rl_amd.mjcf import JNT_FREE
     from mopa_rl_amd.scene import default_qpos
+    env = env or pi.spec.env
+    m = pi.model
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     na = len(pi.ref_joint_pos_indexes)
     lo = torch.tensor(pi.jnt_minimum, dtype=torch.float64, device=device)
     hi = torch.tensor(pi.jnt_maximum, dtype=torch.float64, device=device)
-    q0 = torch.tensor(default_qpos(ENV, pi.model), dtype=torch.float64, device=device)
+    q0 = torch.tensor(default_qpos(env, m), dtype=torch.float64, device=device)
     u = torch.rand(E, S, na, generator=g, dtype=torch.float64, device=device)
     qa = lo + (hi - lo) * u
     n = torch.randn(E, S, na, generator=g, dtype=torch.float64, device=device) * 0.3
@@ -66,9 +70,14 @@ def make_inputs(torch, pi, E, S, seed, device, mode="mixed"):
     half = {"mixed": S // 2, "near": 0, "uniform": S}[mode]
     qa[:, half:, :] = near[:, half:, :]
     rows = q0.repeat(E, 1)
-    rows[:, 7:9] = -0.008 + 0.023 * torch.rand(E, 2, generator=g, dtype=torch.float64, device=device)
-    cube = pi.model.get_joint_qpos_addr("cube")
-    rows[:, cube:cube + 2] += -0.05 + 0.1 * torch.rand(E, 2, generator=g, dtype=torch.float64, device=device)
+    for name in ("rc_close", "lc_close"):
+        if name in m.jnt_names:
+            j = m.joint_name2id(name)
+            a, (r0, r1) = int(m.jnt_qposadr[j]), m.jnt_range[j]
+            rows[:, a] = r0 + (r1 - r0) * torch.rand(E, generator=g, dtype=torch.float64, device=device)
+    free = [int(m.jnt_qposadr[j]) for j in range(len(m.jnt_names)) if m.jnt_type[j] == JNT_FREE]
+    if free:
+        rows[:, free[0]:free[0] + 2] += -0.05 + 0.1 * torch.rand(E, 2, generator=g, dtype=torch.float64, device=device)
     return qa.reshape(E * S, na).contiguous(), rows.contiguous()
 
 
@@ -265,7 +274,10 @@ def rollout_section(torch, pi, E, device, agent_steps):
 
 def ik_section(torch, device, E=8192):
     """BASELINE.json configs[4]'s IK piece: E damped-LS IK problems (env/inverse_kinematics.py:18-135 restated, K5) on
-    SawyerAssemblyObstacle: grip-site targets N(nominal, 0.15 m), max_steps 100, tol 1e-2 as the rollouts call it."""
+    SawyerAssemblyObstacle with POSITION + ORIENTATION targets, as the reference's IK action space poses them
+    (rl/trainer.py:106-110 adds "quat" for 3-D envs, rl/mopa_rollouts.py:690-705 then always passes target_quat):
+    target = grip-site pose of a perturbed arm configuration (reachable by construction), max_steps 100, tol 1e-2.
+    The position-only form is timed next to it."""
     from mopa_rl_amd.ik import BatchIK
     from mopa_rl_amd.scene import ENV_SPECS, default_qpos, load_scene
     env = "SawyerAssemblyObstacle-v0"
@@ -275,21 +287,41 @@ def ik_section(torch, device, E=8192):
     g.manual_seed(0)
     q0 = torch.tensor(default_qpos(env, m), device=device).repeat(E, 1)
     q0[:, :7] += 0.2 * torch.randn(E, 7, generator=g, dtype=torch.float64, device=device)
+    # targets: solve a throw-away position problem from a perturbed pose, read the site pose it ends in
+    qt = q0.clone()
+    qt[:, :7] += 0.15 * torch.randn(E, 7, generator=g, dtype=torch.float64, device=device)
     tg = (torch.tensor([0.6, 0.0, 1.1], dtype=torch.float64, device=device)
           + 0.15 * torch.randn(E, 3, generator=g, dtype=torch.float64, device=device)).contiguous()
-    for _ in range(2):
-        r = ik.solve(q0.clone(), tg, max_steps=100, tol=1e-2)
-    torch.cuda.synchronize()
-    reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        r = ik.solve(q0.clone(), tg, max_steps=100, tol=1e-2)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    return {"config": f"{env}, {E} IK problems (7 joints, grip_site position target), max_steps 100, tol 1e-2",
-            "solves_per_s": E / dt, "ms_per_batch": dt * 1e3, "success_rate": float(r.success.float().mean().item()),
-            "mean_iterations": float((r.steps.float() + 1).mean().item()),
-            "iterations_per_s": float((r.steps.float() + 1).sum().item()) / dt}
+    ax = torch.randn(E, 3, generator=g, dtype=torch.float64, device=device)
+    ax = ax / ax.norm(dim=1, keepdim=True)
+    ang = 0.6 * torch.rand(E, 1, generator=g, dtype=torch.float64, device=device)
+    dq = torch.cat([torch.cos(ang / 2), torch.sin(ang / 2) * ax], dim=1)
+    # current site orientation of q0 from the env kernel's obs would need an env; a fixed nominal orientation composed with
+    # a random rotation of up to 0.6 rad poses the same kind of problem
+    nominal = torch.tensor([0.0, 0.7071067811865476, 0.7071067811865476, 0.0], dtype=torch.float64, device=device)
+
+    def qmul(a, b):
+        aw, ax_, ay, az = a.unbind(-1)
+        bw, bx, by, bz = b.unbind(-1)
+        return torch.stack([aw * bw - ax_ * bx - ay * by - az * bz, aw * bx + ax_ * bw + ay * bz - az * by,
+                            aw * by - ax_ * bz + ay * bw + az * bx, aw * bz + ax_ * by - ay * bx + az * bw], dim=-1)
+    tquat = qmul(nominal.expand(E, 4), dq).contiguous()
+    out = {"config": f"{env}, {E} IK problems (7 joints, grip_site), max_steps 100, tol 1e-2"}
+    for key, quat in (("pos_quat", tquat), ("pos", None)):
+        for _ in range(2):
+            r = ik.solve(q0.clone(), tg, quat, max_steps=100, tol=1e-2)
+        torch.cuda.synchronize()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = ik.solve(q0.clone(), tg, quat, max_steps=100, tol=1e-2)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[key] = {"target": "position + orientation (6 x 7 Jacobian)" if quat is not None else "position (3 x 7 Jacobian)",
+                    "solves_per_s": E / dt, "ms_per_batch": dt * 1e3, "success_rate": float(r.success.float().mean().item()),
+                    "mean_iterations": float((r.steps.float() + 1).mean().item()),
+                    "iterations_per_s": float((r.steps.float() + 1).sum().item()) / dt}
+    return out
 
 
 def cpu_baseline(pi, qa_host, rows_host, S, budget_states):

@@ -33,8 +33,14 @@
  * caller owns every buffer; the library never frees caller memory.  All
  * floating point data is IEEE double, C-contiguous.  `stream` is a
  * hipStream_t passed as void* (NULL = the default stream); batch calls are
- * asynchronous on that stream.  A MopaScene may be used from one host thread
- * at a time.
+ * asynchronous on that stream.  Streams: a scene keeps its launch scratch per
+ * stream, so calls on DIFFERENT streams may be in flight at the same time (e.g.
+ * validity on one stream while the planner runs on another); calls on the same
+ * stream are ordered by the stream.  Host threads: one at a time per object for
+ * the single-query forms (they share a staging buffer); the batch forms may be
+ * called from several threads as long as each uses its own stream.  Devices:
+ * every entry point runs on its object's device and restores the caller's
+ * current device before returning.
  */
 #ifndef MOPA_HIP_H
 #define MOPA_HIP_H
@@ -101,7 +107,8 @@ typedef struct MopaSceneDesc {
     const int32_t *passive_qpos_idx;   /* [n_passive] qpos addresses NOT planned over */
     int32_t n_ignored;
     const int32_t *ignored_pairs;      /* [n_ignored,2] ordered (lo,hi) MuJoCo geom ids */
-    double contact_threshold;          /* state invalid iff some non-ignored dist <= this (negative in the reference) */
+    double contact_threshold;          /* state invalid iff some non-ignored dist <= this; must be <= 0 (negative in the
+                                          reference); > 0 is rejected with MOPA_ERR_UNSUPPORTED: the broad phase culls at zero margin */
     double range;                      /* RRT-Connect maxDistance (KinematicPlanner.cpp:102-104) */
     double resolution;                 /* validity checking resolution; the reference hard-codes 0.005 (:87) */
     uint64_t seed;                     /* KinematicPlanner.cpp:95 */
@@ -132,6 +139,9 @@ int mopa_scene_num_active(const MopaScene *scene);
 int mopa_scene_active_idx(const MopaScene *scene, int32_t *out /*[na]*/);
 int mopa_scene_num_pairs(const MopaScene *scene);   /* non-ignored candidate pairs checked per state */
 int mopa_scene_lds_bytes(const MopaScene *scene);
+/* name of the validity kernel mopa_is_valid_batch dispatches for a batch of N states on this scene ("k_is_valid_v5",
+ * "k_is_valid_v2" or "k_is_valid"); the benchmark labels its roofline line and selects profiler rows with it */
+int mopa_scene_valid_kernel(const MopaScene *scene, int64_t N, char *out, int32_t cap /* >= 24 */);
 
 /* N states: state i = qpos_env[i / samples_per_env] with its active entries replaced by q_active[i].
  * valid[i] = 1 iff no non-ignored pair has dist <= contact_threshold.
@@ -258,15 +268,19 @@ int mopa_env_desired_batch(MopaEnv *env, int64_t E, const double *qpos_dev /*[E,
                            double *desired_dev /*[E,n_arm]*/, void *stream);
 
 /* ======================================================================================================
- *  batched damped-least-squares IK of a site position: replaces
- * qpos_from_site_pose(env, site, target_pos, joint_names=..., max_steps, tol, ...)   env/inverse_kinematics.py:18-135
+ *  batched damped-least-squares IK of a site pose: replaces
+ * qpos_from_site_pose(env, site, target_pos, target_quat, joint_names=..., max_steps, tol, ...)   env/inverse_kinematics.py:18-135
  * with nullspace_method :274-281.  Per env and iteration:
- *   err = target - site_xpos; success if |err| < tol;
- *   J = d site_xpos / d q over the movable joints (hinge: axis x (p_site - anchor), slide: axis);
+ *   err_pos = target_pos - site_xpos;
+ *   with an orientation target (:88-93): err_rot = mju_quat2Vel(target_quat * conj(mju_mat2Quat(site_xmat)), 1);
+ *   err_norm = |err_pos| (+ rot_weight |err_rot|); success if err_norm < tol;
+ *   J = [jacp; jacr] over the movable joints (hinge: axis x (p_site - anchor) / axis, slide: axis / 0) -- 3 x n for a
+ *       position target, 6 x n with an orientation target (:38-44,101-105);
  *   dq = (J^T J + regularization_strength I)^-1 J^T err   (always regularised, as the reference calls it, :113-115);
- *   give up if |err| / |dq| > progress_thresh; |dq| capped at max_update_norm; qpos[movable] += dq.
- * Position targets only (the reference's optional target_quat branch is not served).  The linear solve is an
- * unpivoted Cholesky factorisation (the reference uses LAPACK LU through np.linalg.solve): equal to round-off.
+ *   give up if err_norm / |dq| > progress_thresh; |dq| capped at max_update_norm; qpos[movable] += dq.
+ * The reference's third mode (target_quat without target_pos) raises inside numpy (6-row Jacobian against a 3-vector)
+ * and is not offered.  The linear solve is an unpivoted Cholesky factorisation (the reference uses LAPACK LU through
+ * np.linalg.solve): equal to round-off (tests/golden/ref_py_ik.npz: 1e-12 on whole solves, equal step counts).
  * ====================================================================================================== */
 typedef struct MopaIkDesc {
     MopaModel model;              /* body / joint arrays */
@@ -274,6 +288,7 @@ typedef struct MopaIkDesc {
     const int32_t *joint_ids;     /* [n_joints] model joint ids (hinge / slide, one per body) */
     int32_t site_body;            /* body carrying the site */
     double site_off[3];           /* site position in that body's frame */
+    double site_quat[4];          /* site orientation in that body's frame, wxyz (all zero = identity) */
     int32_t device;               /* HIP device ordinal, -1 = current */
 } MopaIkDesc;
 
@@ -281,9 +296,11 @@ typedef struct MopaIk MopaIk;
 
 int mopa_ik_create(const MopaIkDesc *desc, MopaIk **out);
 void mopa_ik_destroy(MopaIk *ik);
-/* E independent IK problems; qpos rows are updated in place (IKResult.qpos); err_norm / steps / success as IKResult. */
+/* E independent IK problems; qpos rows are updated in place (IKResult.qpos); err_norm / steps / success as IKResult.
+ * target_quat_dev NULL = position target only (rot_weight ignored). */
 int mopa_ik_solve_batch(MopaIk *ik, int64_t E, double *qpos_dev /*[E,nq] in/out*/, const double *target_pos_dev /*[E,3]*/,
-                        int32_t max_steps, double tol, double max_update_norm, double progress_thresh, double regularization_strength,
+                        const double *target_quat_dev /*[E,4] wxyz or NULL*/, double rot_weight, int32_t max_steps, double tol,
+                        double max_update_norm, double progress_thresh, double regularization_strength,
                         double *err_norm_dev /*[E]*/, int32_t *steps_dev /*[E]*/, uint8_t *success_dev /*[E]*/, void *stream);
 
 #ifdef __cplusplus

@@ -24,7 +24,7 @@ _ip = C.POINTER(C.c_int32)
 # every symbol include/mopa_hip.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
     "mopa_last_error", "mopa_version", "mopa_device_count", "mopa_scene_create", "mopa_scene_destroy",
-    "mopa_scene_num_active", "mopa_scene_active_idx", "mopa_scene_num_pairs", "mopa_scene_lds_bytes",
+    "mopa_scene_num_active", "mopa_scene_active_idx", "mopa_scene_num_pairs", "mopa_scene_lds_bytes", "mopa_scene_valid_kernel",
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
@@ -70,7 +70,7 @@ class MopaEnvDesc(C.Structure):
 
 class MopaIkDesc(C.Structure):
     _fields_ = [("model", MopaModel), ("n_joints", C.c_int32), ("joint_ids", _ip), ("site_body", C.c_int32),
-                ("site_off", C.c_double * 3), ("device", C.c_int32)]
+                ("site_off", C.c_double * 3), ("site_quat", C.c_double * 4), ("device", C.c_int32)]
 
 
 class MopaPlanParams(C.Structure):
@@ -128,7 +128,9 @@ def lib() -> C.CDLL:
     L.mopa_ik_create.argtypes = [C.POINTER(MopaIkDesc), C.POINTER(vp)]
     L.mopa_ik_destroy.argtypes = [vp]
     L.mopa_ik_destroy.restype = None
-    L.mopa_ik_solve_batch.argtypes = [vp, C.c_int64, vp, vp, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, vp, vp, vp, vp]
+    L.mopa_ik_solve_batch.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                      vp, vp, vp, vp]
+    L.mopa_scene_valid_kernel.argtypes = [vp, C.c_int64, C.c_char_p, C.c_int32]
     _lib = L
     return L
 
@@ -243,6 +245,12 @@ class Scene:
         check(lib().mopa_plan(self._h, sp, gp, C.byref(prm), path.ctypes.data_as(_dp), C.byref(plen), C.byref(st),
                               C.byref(chk)))
         return st.value, path[:plen.value].copy(), chk.value
+
+    def valid_kernel(self, n_states: int) -> str:
+        """name of the validity kernel `mopa_is_valid_batch` dispatches for a batch of n_states"""
+        buf = C.create_string_buffer(32)
+        check(lib().mopa_scene_valid_kernel(self._h, int(n_states), buf, 32))
+        return buf.value.decode()
 
     def planner_status(self) -> bytes:
         return lib().mopa_planner_status(self._h)

@@ -200,6 +200,79 @@ MOPA_HD double mopa_tanh_pos(double x) {
     return (1.0 - t) / (1.0 + t);
 }
 
+// Deterministic atan2 (IK orientation error; same operation sequence as the CPU checker): a = min/max in [0,1], reduction
+// atan(a) = atan(c) + atan((a - c) / (1 + a c)) with c in {0, tan(pi/8), 1} so that |t| <= tan(pi/16), odd Taylor series of
+// atan(t) to t^25 in Horner form, quadrant fix-ups.  atan2(0, 0) = 0.
+MOPA_HD double mopa_atan2(double y, double x) {
+    const double PI = 3.14159265358979311600e+00, PI_2 = 1.57079632679489655800e+00;
+    const double T1 = 1.98912367379658006912e-01, T3 = 6.68178637919298919998e-01;
+    const double C1 = 4.14213562373095048802e-01, A1 = 3.92699081698724139500e-01, A2 = 7.85398163397448279000e-01;
+    const double ax = fabs(x), ay = fabs(y);
+    const double hi = (ax > ay) ? ax : ay, lo = (ax > ay) ? ay : ax;
+    double r = 0.0;
+    if (hi > 0.0) {
+        const double a = lo / hi;
+        double c = 0.0, base = 0.0;
+        if (a >= T3) { c = 1.0; base = A2; }
+        else if (a >= T1) { c = C1; base = A1; }
+        const double t = (a - c) / fma(a, c, 1.0);
+        const double z = t * t;
+        double p = 1.0 / 25.0;
+        p = fma(p, z, -1.0 / 23.0);
+        p = fma(p, z, 1.0 / 21.0);
+        p = fma(p, z, -1.0 / 19.0);
+        p = fma(p, z, 1.0 / 17.0);
+        p = fma(p, z, -1.0 / 15.0);
+        p = fma(p, z, 1.0 / 13.0);
+        p = fma(p, z, -1.0 / 11.0);
+        p = fma(p, z, 1.0 / 9.0);
+        p = fma(p, z, -1.0 / 7.0);
+        p = fma(p, z, 1.0 / 5.0);
+        p = fma(p, z, -1.0 / 3.0);
+        r = base + fma(t * z, p, t);
+        if (ay > ax) r = PI_2 - r;
+    }
+    if (x < 0.0) r = PI - r;
+    return (y < 0.0) ? -r : r;
+}
+
+// [3P] mju_mat2Quat: largest-component branch, then mju_normalize4
+MOPA_HD Q4 mj_mat2quat(const double *m) {
+    Q4 q;
+    if (m[0] + m[4] + m[8] > 0.0) {
+        q.w = 0.5 * sqrt(1.0 + m[0] + m[4] + m[8]);
+        q.x = 0.25 * (m[7] - m[5]) / q.w;
+        q.y = 0.25 * (m[2] - m[6]) / q.w;
+        q.z = 0.25 * (m[3] - m[1]) / q.w;
+    } else if (m[0] > m[4] && m[0] > m[8]) {
+        q.x = 0.5 * sqrt(1.0 + m[0] - m[4] - m[8]);
+        q.w = 0.25 * (m[7] - m[5]) / q.x;
+        q.y = 0.25 * (m[1] + m[3]) / q.x;
+        q.z = 0.25 * (m[2] + m[6]) / q.x;
+    } else if (m[4] > m[8]) {
+        q.y = 0.5 * sqrt(1.0 - m[0] + m[4] - m[8]);
+        q.w = 0.25 * (m[2] - m[6]) / q.y;
+        q.x = 0.25 * (m[1] + m[3]) / q.y;
+        q.z = 0.25 * (m[5] + m[7]) / q.y;
+    } else {
+        q.z = 0.5 * sqrt(1.0 - m[0] - m[4] + m[8]);
+        q.w = 0.25 * (m[3] - m[1]) / q.z;
+        q.x = 0.25 * (m[2] + m[6]) / q.z;
+        q.y = 0.25 * (m[5] + m[7]) / q.z;
+    }
+    return quat_normalize(q);
+}
+// [3P] mju_quat2Vel with dt = 1: rotation axis * angle, angle in (-pi, pi]
+MOPA_HD V3 mj_quat2vel(Q4 q) {
+    V3 ax{q.x, q.y, q.z};
+    const double s = sqrt(fma(ax.z, ax.z, fma(ax.y, ax.y, ax.x * ax.x)));
+    if (s < kMinVal) ax = V3{1.0, 0.0, 0.0};
+    else if (fabs(s - 1.0) > kMinVal) { const double inv = 1.0 / s; ax.x *= inv; ax.y *= inv; ax.z *= inv; }
+    double speed = 2.0 * mopa_atan2(s, q.w);
+    if (speed > 3.14159265358979311600e+00) speed = speed - 2.0 * 3.14159265358979311600e+00;
+    return V3{ax.x * speed, ax.y * speed, ax.z * speed};
+}
+
 // ---------------------------------------------------------------------------
 // One posed primitive as the narrow phase sees it.  `p` points at 15 doubles:
 // pos[3] mat[9] size[3] (LDS on the device, plain memory on the host).

@@ -22,6 +22,8 @@
 #include <string>
 #include <vector>
 
+#include <map>
+#include <mutex>
 #include "../../include/mopa_hip.h"
 #include "mopa_device.hpp"
 
@@ -32,6 +34,7 @@ using namespace mopa;
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
 constexpr int kMaxLdsBytes = 160 * 1024;   // LDS per CU on gfx950
+constexpr double kV5MaxReach = 32.0;        // metres: beyond this the FP32 broad phase is not used (see mopa_scene_create)
 static void plan_register_lds();            // defined with K3 (mopa_planner.inc)
 static int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -43,6 +46,31 @@ static int fail(int code, const std::string &msg) {
         if (_e != hipSuccess)                                                                      \
             return fail(MOPA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
     } while (0)
+
+// Every entry point runs on its object's device and leaves the caller's current device as it found it (a torch process
+// that touches several GPUs keeps its own notion of "current").
+class DeviceGuard {
+    int prev_ = -1;
+    bool ok_ = false, switched_ = false;
+public:
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev_) != hipSuccess) return;
+        if (prev_ != device) {
+            if (hipSetDevice(device) != hipSuccess) return;
+            switched_ = true;
+        }
+        ok_ = true;
+    }
+    ~DeviceGuard() {
+        if (switched_) (void)hipSetDevice(prev_);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+    bool ok() const { return ok_; }
+};
+#define ON_DEVICE(dev)                                                        \
+    DeviceGuard _guard(dev);                                                  \
+    if (!_guard.ok()) return fail(MOPA_ERR_HIP, "cannot switch to the object's HIP device")
 
 extern "C" const char *mopa_last_error(void) { return g_err.c_str(); }
 extern "C" const char *mopa_version(void) { return "mopa_hip 0.1.0 (gfx950)"; }
@@ -80,6 +108,20 @@ struct SceneHdr {
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = 64 * kWavesPerBlock;
 
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;     // bytes
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+struct StreamScratch {
+    DevBuf slab;        // lane-per-state kernels: pose slabs of the launch's waves + [profile words | tile counter]
+    DevBuf mpr;         // v5: per-wave ring of deferred cylinder pairs
+    DevBuf mesh_list;   // [0] = count, then the states with a mesh pair past the main pass's broad phase
+    size_t slab_waves = 0;
+    DevBuf mv_cnt, mv_off, mv_env, mv_q, mv_valid, mv_scan;   // expanded motion validation (mopa_motion.inc)
+    DevBuf plan_q, plan_p, plan_ctr;                          // planner: both trees of every env, env counter (mopa_planner.inc)
+};
+
 struct MopaScene {
     int device = 0;
     SceneHdr hdr{};
@@ -105,31 +147,41 @@ struct MopaScene {
     double *d_dbg = nullptr;
     size_t dbg_doubles = 0;
     int n_cu = 256;
-    // v2 kernel resources
-    double *d_slab = nullptr;
-    double *d_mpr = nullptr;      // v5: per-wave ring of deferred cylinder pairs
-    size_t slab_waves = 0;
     int v2_lds_bytes = 0;
     int use_v2 = 1;
     int32_t *d_gp_tab = nullptr;   // v5: FP32 broad-phase table [n_gp][8]
-    // expanded motion validation (mopa_motion.inc): per-segment counts / offsets, expanded states, their env rows, verdicts
-    int32_t *mv_cnt = nullptr, *mv_off = nullptr, *mv_env = nullptr;
-    double *mv_q = nullptr;
-    uint8_t *mv_valid = nullptr;
-    void *mv_scan = nullptr;
-    size_t mv_cap_seg = 0, mv_cap_states = 0, mv_scan_bytes = 0;
     int v5_lds_bytes = 0;
     int use_v5 = 0;
-    long long *d_mesh_list = nullptr;   // [0] = count, then the states with a mesh pair past the main pass's broad phase
-    size_t mesh_list_cap = 0;
     bool v5_cen_lds = true;   // FP32 centre table of a tile in LDS (false: read back from the pose slab; scenes with many moving geoms)
     bool v2_forced = false;   // MOPA_VALID_KERNEL=v2: lane-per-state kernel for every N >= 64 (tests, A/B runs)
-    // planner workspace (mopa_planner.inc): both trees of every env, grown on demand
-    double *plan_tree_q = nullptr;
-    int32_t *plan_tree_parent = nullptr;
-    size_t plan_q_bytes = 0, plan_p_bytes = 0;
-    unsigned long long *plan_ctr = nullptr;   // next env of a planner launch (persistent waves)
+    // Launch scratch, one set PER STREAM: a scene may be driven from several streams at once (validity on one stream while
+    // the planner or the previous step's motion check runs on another); calls on the same stream are ordered by the
+    // stream.  Buffers only ever grow; an outgrown buffer may still be read by kernels in flight, so it is retired and
+    // freed with the scene, never on the hot path.
+    std::mutex mu;
+    std::map<hipStream_t, StreamScratch> scratch;
+    std::vector<void *> retired;
 };
+
+static StreamScratch &scratch_for(MopaScene *S, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(S->mu);
+    return S->scratch[st];       // std::map: references stay valid across later insertions
+}
+// make `b` hold at least `bytes`; returns a HIP error code
+static hipError_t grow(MopaScene *S, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return hipSuccess;
+    const size_t want = std::max(bytes, b.cap + b.cap / 2);
+    void *np = nullptr;
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess) return e;
+    if (b.p) {
+        std::lock_guard<std::mutex> lock(S->mu);
+        S->retired.push_back(b.p);
+    }
+    b.p = np;
+    b.cap = want;
+    return hipSuccess;
+}
 
 // ---------------------------------------------------------------------------
 // device helpers
@@ -488,6 +540,29 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     if (m.nq <= 0 || m.nbody <= 0 || m.ngeom < 0) return fail(MOPA_ERR_INVALID_ARG, "empty model");
     if (m.ngeom > 255) return fail(MOPA_ERR_LIMIT, "more than 255 collidable geoms");
     if (m.npair > 65535) return fail(MOPA_ERR_LIMIT, "more than 65535 candidate pairs");
+    // The broad phase culls at zero margin: with a threshold > 0 a pair at distance (0, thr] would be reported or not
+    // depending on the cull, and MuJoCo's own contact list (dist < margin) would have to be reproduced.  The reference
+    // passes negative thresholds (config/sawyer.py:98-100, config/pusher.py:79-81); 0 keeps "any penetration".
+    if (desc->contact_threshold > 0.0) return fail(MOPA_ERR_UNSUPPORTED, "contact_threshold > 0 is not supported (the broad phase culls at zero margin)");
+    // FP32 broad phase (third-generation kernel): its conservativeness proof assumes coordinates of a few metres (absolute
+    // slack 2e-5 m vs the float rounding of a coordinate).  `reach` bounds every model-determined coordinate; larger scenes
+    // use the FP64 cull of the second generation.  Free-joint positions come from qpos at run time and are the caller's
+    // responsibility (the Sawyer world box is +-1.2 m x 2 m, env/sawyer/sawyer.py:52-53).
+    double reach = 0.0;
+    {
+        std::vector<double> rb(m.nbody, 0.0);
+        for (int b = 1; b < m.nbody; b++) {
+            const double *p = m.body_pos + 3 * b;
+            rb[b] = rb[m.body_parent[b]] + sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+            for (int j = m.body_jntadr[b]; j >= 0 && j < m.body_jntadr[b] + m.body_jntnum[b]; j++)
+                if (m.jnt_type[j] == J_SLIDE && m.jnt_limited[j]) rb[b] += std::max(fabs(m.jnt_range[2 * j]), fabs(m.jnt_range[2 * j + 1]));
+        }
+        for (int g = 0; g < m.ngeom; g++) {
+            if (m.geom_type[g] == G_PLANE) continue;
+            const double *p = m.geom_pos + 3 * g, *z = m.geom_size + 3 * g;
+            reach = std::max(reach, rb[m.geom_body[g]] + sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) + sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]));
+        }
+    }
 
     MopaScene *S = new MopaScene();
     S->nq = m.nq;
@@ -938,7 +1013,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         // ... unless it would get one workgroup per CU where the second generation still gets two (LDS: the FP32 centre
         // table grows with the number of moving geoms; SawyerLift: 19 of them)
         const bool v5_fits2 = S->v5_lds_bytes <= 80 * 1024, v2_fits2 = S->v2_lds_bytes <= 80 * 1024;
-        S->use_v5 = !(ev && std::string(ev) == "v2") && S->use_v2 && max_pnum <= 64 && S->v5_lds_bytes <= kMaxLdsBytes &&
+        S->use_v5 = !(ev && std::string(ev) == "v2") && S->use_v2 && max_pnum <= 64 && S->v5_lds_bytes <= kMaxLdsBytes && reach <= kV5MaxReach &&
                     (v5_fits2 || !v2_fits2 || (ev && std::string(ev) == "v5"));
         if (ev && std::string(ev) == "v5") S->v2_forced = true;   // "v5" also forces the lane-per-state path for every N >= 64
     }
@@ -951,10 +1026,11 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     int ndev = mopa_device_count();
     if (ndev <= 0) { delete S; return fail(MOPA_ERR_HIP, "no HIP device visible: libmopa_hip has no CPU fallback"); }
     if (desc->device >= 0) {
-        hipError_t e = hipSetDevice(desc->device);
-        if (e != hipSuccess) { delete S; return fail(MOPA_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e)); }
-    }
-    if (hipGetDevice(&S->device) != hipSuccess) { delete S; return fail(MOPA_ERR_HIP, "hipGetDevice failed"); }
+        if (desc->device >= ndev) { delete S; return fail(MOPA_ERR_INVALID_ARG, "device ordinal out of range"); }
+        S->device = desc->device;
+    } else if (hipGetDevice(&S->device) != hipSuccess) { delete S; return fail(MOPA_ERR_HIP, "hipGetDevice failed"); }
+    DeviceGuard guard(S->device);      // the caller's current device is restored on every exit path
+    if (!guard.ok()) { delete S; return fail(MOPA_ERR_HIP, "cannot switch to the requested HIP device"); }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, S->device) == hipSuccess) S->n_cu = prop.multiProcessorCount;
     auto up = [&](void **dst, const void *src, size_t bytes) -> hipError_t {
@@ -990,21 +1066,17 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
 
 extern "C" void mopa_scene_destroy(MopaScene *S) {
     if (!S) return;
-    if (S->plan_tree_q) (void)hipFree(S->plan_tree_q);
-    if (S->plan_tree_parent) (void)hipFree(S->plan_tree_parent);
-    if (S->plan_ctr) (void)hipFree(S->plan_ctr);
-    if (S->d_dbl) (void)hipFree(S->d_dbl);
-    if (S->d_int) (void)hipFree(S->d_int);
-    if (S->d_q) (void)hipFree(S->d_q);
-    if (S->d_valid) (void)hipFree(S->d_valid);
-    if (S->d_md) (void)hipFree(S->d_md);
-    if (S->d_dbg) (void)hipFree(S->d_dbg);
-    if (S->d_slab) (void)hipFree(S->d_slab);
-    if (S->d_mpr) (void)hipFree(S->d_mpr);
-    if (S->d_gp_tab) (void)hipFree(S->d_gp_tab);
-    if (S->d_mesh_list) (void)hipFree(S->d_mesh_list);
-    for (void *q : {(void *)S->mv_cnt, (void *)S->mv_off, (void *)S->mv_env, (void *)S->mv_q, (void *)S->mv_valid, S->mv_scan})
+    DeviceGuard guard(S->device);
+    (void)hipDeviceSynchronize();      // nothing of this scene may still be running when its tables go away
+    for (void *q : {(void *)S->d_dbl, (void *)S->d_int, (void *)S->d_q, (void *)S->d_valid, (void *)S->d_md, (void *)S->d_dbg, (void *)S->d_gp_tab})
         if (q) (void)hipFree(q);
+    for (auto &kv : S->scratch) {
+        StreamScratch &sc = kv.second;
+        for (DevBuf *b : {&sc.slab, &sc.mpr, &sc.mesh_list, &sc.mv_cnt, &sc.mv_off, &sc.mv_env, &sc.mv_q, &sc.mv_valid, &sc.mv_scan, &sc.plan_q,
+                          &sc.plan_p, &sc.plan_ctr})
+            if (b->p) (void)hipFree(b->p);
+    }
+    for (void *q : S->retired) (void)hipFree(q);
     delete S;
 }
 
@@ -1016,6 +1088,15 @@ extern "C" int mopa_scene_active_idx(const MopaScene *S, int32_t *out) {
 }
 extern "C" int mopa_scene_num_pairs(const MopaScene *S) { return S ? S->hdr.npair : -1; }
 extern "C" int mopa_scene_lds_bytes(const MopaScene *S) { return S ? S->lds_bytes : -1; }
+
+extern "C" int mopa_scene_valid_kernel(const MopaScene *S, int64_t N, char *out, int32_t cap) {
+    if (!S || !out || cap < 24) return fail(MOPA_ERR_INVALID_ARG, "null argument / buffer under 24 bytes");
+    const int64_t v2_min = S->v2_forced ? 64 : std::max<int64_t>(64, (int64_t)S->n_cu * 36);
+    const char *name = "k_is_valid";
+    if (S->use_v2 && N >= v2_min) name = S->use_v5 ? "k_is_valid_v5" : "k_is_valid_v2";
+    std::snprintf(out, (size_t)cap, "%s", name);
+    return MOPA_OK;
+}
 
 static int grid_for(const MopaScene *S, int64_t N) {
     int64_t blocks = (N + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -1029,6 +1110,7 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
     if (!S || !valid || (N > 0 && (!q_active || !qpos_env))) return fail(MOPA_ERR_INVALID_ARG, "null argument");
     if (N < 0 || samples_per_env <= 0) return fail(MOPA_ERR_INVALID_ARG, "N < 0 or samples_per_env <= 0");
     if (N == 0) return MOPA_OK;
+    ON_DEVICE(S->device);
     hipStream_t st = (hipStream_t)stream;
     dim3 block(kBlock);
     // Kernel choice: the lane-per-state kernel needs ~175 us for a 64-state tile however few tiles there are, the
@@ -1041,19 +1123,17 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
         int64_t tiles = (N + 63) / 64;
         int64_t blocks = std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)S->n_cu * 2);
         size_t waves = (size_t)blocks * kWavesPerBlock;
-        if (waves > S->slab_waves) {
-            if (S->d_slab) (void)hipFree(S->d_slab);
-            S->d_slab = nullptr; S->slab_waves = 0;
-            size_t want = std::max(waves, (size_t)S->n_cu * 2 * kWavesPerBlock);
-            HIP_TRY(hipMalloc((void **)&S->d_slab, (want * (size_t)(S->hdr.nmg + S->hdr.n_save) * kSlabStride + 16) * sizeof(double)));
-            if (S->d_mpr) (void)hipFree(S->d_mpr);
-            S->d_mpr = nullptr;
-            HIP_TRY(hipMalloc((void **)&S->d_mpr, want * (size_t)kMprCapV5 * kMprRow * sizeof(double)));
-            S->slab_waves = want;
+        StreamScratch &sc = scratch_for(S, st);
+        if (waves > sc.slab_waves) {
+            const size_t want = std::max(waves, (size_t)S->n_cu * 2 * kWavesPerBlock);
+            HIP_TRY(grow(S, sc.slab, (want * (size_t)(S->hdr.nmg + S->hdr.n_save) * kSlabStride + 16) * sizeof(double)));
+            HIP_TRY(grow(S, sc.mpr, want * (size_t)kMprCapV5 * kMprRow * sizeof(double)));
+            sc.slab_waves = want;
         }
+        double *const d_slab = sc.slab.as<double>();
         dim3 grid((unsigned)blocks);
         // [6 profile words | 2 pad | tile counter] live right behind the slabs of this launch's waves
-        double *d_tail = S->d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride;
+        double *d_tail = d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride;
         HIP_TRY(hipMemsetAsync(d_tail + 8, 0, 8, st));
 #ifdef MOPA_V2_PROFILE
         unsigned long long *d_prof = (unsigned long long *)d_tail;
@@ -1062,13 +1142,8 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
         auto kern = min_dist ? k_is_valid_v2<true, false> : k_is_valid_v2<false, false>;   // main lists carry no mesh pair
         long long *mesh_list = nullptr;
         if (S->use_v5 && !S->v5_cen_lds && S->n_mesh_gp > 0) {
-            if ((size_t)N > S->mesh_list_cap) {
-                if (S->d_mesh_list) (void)hipFree(S->d_mesh_list);
-                S->d_mesh_list = nullptr; S->mesh_list_cap = 0;
-                HIP_TRY(hipMalloc((void **)&S->d_mesh_list, ((size_t)N + 1) * sizeof(long long)));
-                S->mesh_list_cap = (size_t)N;
-            }
-            mesh_list = S->d_mesh_list;
+            HIP_TRY(grow(S, sc.mesh_list, ((size_t)N + 1) * sizeof(long long)));
+            mesh_list = sc.mesh_list.as<long long>();
             HIP_TRY(hipMemsetAsync(mesh_list, 0, sizeof(long long), st));
         }
         if (S->use_v5) {
@@ -1076,16 +1151,16 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
                       : mesh_list   ? (min_dist ? k_is_valid_v5<true, false, true> : k_is_valid_v5<false, false, true>)
                                     : (min_dist ? k_is_valid_v5<true, false, false> : k_is_valid_v5<false, false, false>);
             hipLaunchKernelGGL(k5, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
-                               (long long)N, (long long)samples_per_env, valid, min_dist, S->d_slab, env_idx, S->d_mpr, mesh_list);
+                               (long long)N, (long long)samples_per_env, valid, min_dist, d_slab, env_idx, sc.mpr.as<double>(), mesh_list);
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                           (long long)samples_per_env, valid, min_dist, S->d_slab, 0, env_idx, (const long long *)nullptr);
+                           (long long)samples_per_env, valid, min_dist, d_slab, 0, env_idx, (const long long *)nullptr);
         if (S->n_mesh_gp > 0) {
             // second pass: the mesh pairs only (MESH instantiation), verdict AND-ed / depth min-ed into the first pass's
             HIP_TRY(hipMemsetAsync(d_tail + 8, 0, 8, st));
             auto km = min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>;
             hipLaunchKernelGGL(km, grid, block, S->v2_lds_bytes, st, S->hdr_mesh, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                               (long long)samples_per_env, valid, min_dist, S->d_slab, 1, env_idx, (const long long *)mesh_list);
+                               (long long)samples_per_env, valid, min_dist, d_slab, 1, env_idx, (const long long *)mesh_list);
         }
         HIP_TRY(hipGetLastError());
         if (mesh_list && std::getenv("MOPA_DEBUG_MESH")) {     // diagnostics: how many states the gate lets through
@@ -1127,6 +1202,7 @@ extern "C" int mopa_check_motion_batch(MopaScene *S, const double *qa, const dou
     if (!S || !valid || (N > 0 && (!qa || !qb || !qpos_env))) return fail(MOPA_ERR_INVALID_ARG, "null argument");
     if (N < 0 || samples_per_env <= 0) return fail(MOPA_ERR_INVALID_ARG, "N < 0 or samples_per_env <= 0");
     if (N == 0) return MOPA_OK;
+    ON_DEVICE(S->device);
     hipStream_t st = (hipStream_t)stream;
     // large batches: expand every segment into its states, validate them with the lane-per-state kernel, AND per segment
     const int64_t big = S->v2_forced ? 64 : std::max<int64_t>(64, (int64_t)S->n_cu * 16);
@@ -1151,6 +1227,7 @@ static int upload_state(MopaScene *S, const double *qpos_host) {
 
 extern "C" int mopa_is_valid_state(MopaScene *S, const double *qpos_host, int32_t *valid_out, double *min_dist_out) {
     if (!S || !qpos_host || !valid_out) return fail(MOPA_ERR_INVALID_ARG, "null argument");
+    ON_DEVICE(S->device);
     int rc = upload_state(S, qpos_host);
     if (rc) return rc;
     rc = mopa_is_valid_batch(S, S->d_q + S->nq, S->d_q, 1, 1, S->d_valid, min_dist_out ? S->d_md : nullptr, nullptr);
@@ -1163,6 +1240,7 @@ extern "C" int mopa_is_valid_state(MopaScene *S, const double *qpos_host, int32_
 }
 
 static int run_debug(MopaScene *S, const double *qpos_host) {
+    ON_DEVICE(S->device);
     int rc = upload_state(S, qpos_host);
     if (rc) return rc;
     hipLaunchKernelGGL(S->hdr.has_mesh ? k_debug_state<true> : k_debug_state<false>, dim3(1), dim3(kBlock), S->lds_bytes, nullptr, S->hdr, S->d_dbl, S->d_int, S->d_q + S->nq,
@@ -1176,6 +1254,7 @@ extern "C" int mopa_debug_fk(MopaScene *S, const double *qpos_host, double *gpos
     if (!S || !qpos_host || !gpos || !gmat) return fail(MOPA_ERR_INVALID_ARG, "null argument");
     int rc = run_debug(S, qpos_host);
     if (rc) return rc;
+    ON_DEVICE(S->device);
     std::vector<double> rec((size_t)kGeomStride * S->hdr.ng);
     HIP_TRY(hipMemcpy(rec.data(), S->d_dbg, rec.size() * 8, hipMemcpyDeviceToHost));
     for (int g = 0; g < S->hdr.ng; g++) {
@@ -1189,6 +1268,7 @@ extern "C" int mopa_debug_pair_dist(MopaScene *S, const double *qpos_host, doubl
     if (!S || !qpos_host || !dist) return fail(MOPA_ERR_INVALID_ARG, "null argument");
     int rc = run_debug(S, qpos_host);
     if (rc) return rc;
+    ON_DEVICE(S->device);
     std::vector<double> d(S->hdr.npair);
     if (!d.empty()) HIP_TRY(hipMemcpy(d.data(), S->d_dbg + (size_t)kGeomStride * S->hdr.ng, d.size() * 8, hipMemcpyDeviceToHost));
     for (int p = 0; p < S->npair_model; p++) dist[p] = (S->pair_slot[p] >= 0) ? d[S->pair_slot[p]] : MOPA_FAR;

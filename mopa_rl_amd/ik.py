@@ -1,8 +1,9 @@
 """Batched damped-least-squares IK -- mirrors reference env/inverse_kinematics.py:18-135
-(`qpos_from_site_pose`, position targets) on libmopa_hip.so (kernel K5 `k_ik_solve`, one lane per env).
+(`qpos_from_site_pose`: position targets, or position + orientation targets as the MoPA+IK rollouts call it,
+rl/mopa_rollouts.py:690-705) on libmopa_hip.so (kernel K5 `k_ik_solve`, one lane per env).
 
     ik = BatchIK(model, site="grip_site", joint_names=[...])
-    res = ik.solve(qpos, target_pos, max_steps=100, tol=1e-2)      # IKResult of GPU tensors; qpos updated in place
+    res = ik.solve(qpos, target_pos, target_quat, max_steps=100, tol=1e-2)   # IKResult of GPU tensors; qpos updated in place
 
 `qpos_from_site_pose(model, qpos, site, target_pos, joint_names, ...)` is the single-problem form with the reference's
 argument names and return type (`IKResult(qpos, err_norm, steps, success)`); the reference passes a live env, here the
@@ -37,6 +38,7 @@ class BatchIK:
         keep.append(ji)
         d.n_joints, d.joint_ids = len(ji), jp
         d.site_body, d.site_off, d.device = self.site_body, (C.c_double * 3)(*self.site_off), int(device)
+        d.site_quat = (C.c_double * 4)(*np.asarray(model.site_quat[si], dtype=np.float64))
         h = C.c_void_p()
         _lib.check(L.mopa_ik_create(C.byref(d), C.byref(h)))
         self._h = h
@@ -53,23 +55,25 @@ class BatchIK:
         except Exception:
             pass
 
-    def solve(self, qpos, target_pos, max_steps: int = 100, tol: float = 1e-14, max_update_norm: float = 2.0,
-              progress_thresh: float = 20.0, regularization_strength: float = 3e-2, stream=None) -> IKResult:
-        """qpos [E, nq] (updated in place), target_pos [E, 3]: contiguous float64 GPU tensors.  Defaults are the
-        reference's (inverse_kinematics.py:24-30); the rollouts call it with max_steps=100, tol=1e-2."""
+    def solve(self, qpos, target_pos, target_quat=None, max_steps: int = 100, rot_weight: float = 1.0, tol: float = 1e-14,
+              max_update_norm: float = 2.0, progress_thresh: float = 20.0, regularization_strength: float = 3e-2, stream=None) -> IKResult:
+        """qpos [E, nq] (updated in place), target_pos [E, 3], target_quat [E, 4] wxyz or None: contiguous float64 GPU tensors.
+        Defaults are the reference's (inverse_kinematics.py:24-30); the rollouts call it with max_steps=100, tol=1e-2."""
         torch = _torch()
-        for t, name, cols in ((qpos, "qpos", self.nq), (target_pos, "target_pos", 3)):
+        checks = [(qpos, "qpos", self.nq), (target_pos, "target_pos", 3)] + ([(target_quat, "target_quat", 4)] if target_quat is not None else [])
+        for t, name, cols in checks:
             if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous() or t.dim() != 2 or t.shape[1] != cols:
                 raise _lib.MopaError(f"{name} must be a contiguous float64 GPU tensor of shape [E, {cols}]")
         E = qpos.shape[0]
-        if target_pos.shape[0] != E:
-            raise _lib.MopaError("qpos and target_pos disagree on E")
+        if target_pos.shape[0] != E or (target_quat is not None and target_quat.shape[0] != E):
+            raise _lib.MopaError("qpos and targets disagree on E")
         err = torch.zeros(E, dtype=torch.float64, device=qpos.device)
         steps = torch.zeros(E, dtype=torch.int32, device=qpos.device)
         succ = torch.zeros(E, dtype=torch.uint8, device=qpos.device)
-        _lib.check(_lib.lib().mopa_ik_solve_batch(self._h, E, _ptr(qpos), _ptr(target_pos), int(max_steps), float(tol),
-                                                  float(max_update_norm), float(progress_thresh), float(regularization_strength),
-                                                  _ptr(err), _ptr(steps), _ptr(succ), _stream_handle(stream)))
+        _lib.check(_lib.lib().mopa_ik_solve_batch(self._h, E, _ptr(qpos), _ptr(target_pos),
+                                                  _ptr(target_quat) if target_quat is not None else None, float(rot_weight),
+                                                  int(max_steps), float(tol), float(max_update_norm), float(progress_thresh),
+                                                  float(regularization_strength), _ptr(err), _ptr(steps), _ptr(succ), _stream_handle(stream)))
         return IKResult(qpos=qpos, err_norm=err, steps=steps, success=succ)
 
 
@@ -78,14 +82,16 @@ def qpos_from_site_pose(model, qpos, site, target_pos=None, target_quat=None, jo
                         regularization_strength=3e-2) -> IKResult:
     """Single problem, reference argument names (inverse_kinematics.py:18-31)."""
     torch = _torch()
-    if target_quat is not None:
-        raise NotImplementedError("orientation targets (target_quat) are not served")
     if target_pos is None:
-        raise ValueError("At least one of `target_pos` or `target_quat` must be specified")
+        if target_quat is None:
+            raise ValueError("At least one of `target_pos` or `target_quat` must be specified")
+        raise NotImplementedError("an orientation target without a position target is not served (the reference itself fails on "
+                                  "it: a 6-row Jacobian against a 3-vector, inverse_kinematics.py:101-116)")
     if joint_names is None:
         raise NotImplementedError("joint_names=None (all dofs) is not served: pass the movable joints")
     ik = BatchIK(model, site, list(joint_names))
     q = torch.tensor(np.asarray(qpos, dtype=np.float64)[None], device="cuda")
     t = torch.tensor(np.asarray(target_pos, dtype=np.float64)[None], device="cuda")
-    r = ik.solve(q, t, max_steps, tol, max_update_norm, progress_thresh, regularization_strength)
+    tq = torch.tensor(np.asarray(target_quat, dtype=np.float64)[None], device="cuda") if target_quat is not None else None
+    r = ik.solve(q, t, tq, max_steps, rot_weight, tol, max_update_norm, progress_thresh, regularization_strength)
     return IKResult(qpos=r.qpos[0].cpu().numpy(), err_norm=float(r.err_norm[0]), steps=int(r.steps[0]), success=bool(r.success[0]))

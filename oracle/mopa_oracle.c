@@ -218,6 +218,80 @@ double orc_tanh_pos(double x) {
     return (1.0 - t) / (1.0 + t);
 }
 
+/* deterministic atan2 shared (as a specification) with the HIP IK kernel: a = min/max in [0,1]; reduction
+ * atan(a) = atan(c) + atan((a - c) / (1 + a c)) with c in {0, tan(pi/8), 1} so that |t| <= tan(pi/16); odd Taylor series of
+ * atan(t) to t^25 (|t|^27/27 < 5e-21), Horner in t^2; quadrant fix-ups.  atan2(0, 0) = 0. */
+double orc_atan2(double y, double x) {
+    const double PI = 3.14159265358979311600e+00, PI_2 = 1.57079632679489655800e+00;
+    const double T1 = 1.98912367379658006912e-01 /* tan(pi/16) */, T3 = 6.68178637919298919998e-01 /* tan(3pi/16) */;
+    const double C1 = 4.14213562373095048802e-01 /* tan(pi/8) */, A1 = 3.92699081698724139500e-01 /* pi/8 */,
+                 A2 = 7.85398163397448279000e-01 /* pi/4 */;
+    const double ax = fabs(x), ay = fabs(y);
+    const double hi = (ax > ay) ? ax : ay, lo = (ax > ay) ? ay : ax;
+    double r = 0.0;
+    if (hi > 0.0) {
+        const double a = lo / hi;
+        double c = 0.0, base = 0.0;
+        if (a >= T3) { c = 1.0; base = A2; }
+        else if (a >= T1) { c = C1; base = A1; }
+        const double t = (a - c) / fma(a, c, 1.0);
+        const double z = t * t;
+        double p = 1.0 / 25.0;
+        p = fma(p, z, -1.0 / 23.0);
+        p = fma(p, z, 1.0 / 21.0);
+        p = fma(p, z, -1.0 / 19.0);
+        p = fma(p, z, 1.0 / 17.0);
+        p = fma(p, z, -1.0 / 15.0);
+        p = fma(p, z, 1.0 / 13.0);
+        p = fma(p, z, -1.0 / 11.0);
+        p = fma(p, z, 1.0 / 9.0);
+        p = fma(p, z, -1.0 / 7.0);
+        p = fma(p, z, 1.0 / 5.0);
+        p = fma(p, z, -1.0 / 3.0);
+        r = base + fma(t * z, p, t);
+        if (ay > ax) r = PI_2 - r;
+    }
+    if (x < 0.0) r = PI - r;
+    return (y < 0.0) ? -r : r;
+}
+
+/* [3P] MuJoCo's quaternion helpers the IK calls through dm_control (env/inverse_kinematics.py:88-92), restated from the
+ * published engine_util_spatial.c: mju_mat2Quat (largest-component branch, then normalisation), mju_negQuat (conjugate),
+ * mju_mulQuat, mju_quat2Vel (axis * angle, angle in (-pi, pi], divided by dt = 1). */
+static void mj_mat2quat(double *q, const double *m) {
+    if (m[0] + m[4] + m[8] > 0.0) {
+        q[0] = 0.5 * sqrt(1.0 + m[0] + m[4] + m[8]);
+        q[1] = 0.25 * (m[7] - m[5]) / q[0];
+        q[2] = 0.25 * (m[2] - m[6]) / q[0];
+        q[3] = 0.25 * (m[3] - m[1]) / q[0];
+    } else if (m[0] > m[4] && m[0] > m[8]) {
+        q[1] = 0.5 * sqrt(1.0 + m[0] - m[4] - m[8]);
+        q[0] = 0.25 * (m[7] - m[5]) / q[1];
+        q[2] = 0.25 * (m[1] + m[3]) / q[1];
+        q[3] = 0.25 * (m[2] + m[6]) / q[1];
+    } else if (m[4] > m[8]) {
+        q[2] = 0.5 * sqrt(1.0 - m[0] + m[4] - m[8]);
+        q[0] = 0.25 * (m[2] - m[6]) / q[2];
+        q[1] = 0.25 * (m[1] + m[3]) / q[2];
+        q[3] = 0.25 * (m[5] + m[7]) / q[2];
+    } else {
+        q[3] = 0.5 * sqrt(1.0 - m[0] - m[4] + m[8]);
+        q[0] = 0.25 * (m[3] - m[1]) / q[3];
+        q[1] = 0.25 * (m[2] + m[6]) / q[3];
+        q[2] = 0.25 * (m[5] + m[7]) / q[3];
+    }
+    quat_normalize(q);     /* [3P] mju_normalize4 */
+}
+static void mj_quat2vel(double *res, const double *q) {
+    double ax[3] = {q[1], q[2], q[3]};
+    const double s = sqrt(fma(ax[2], ax[2], fma(ax[1], ax[1], ax[0] * ax[0])));
+    if (s < 1e-15) { ax[0] = 1.0; ax[1] = 0.0; ax[2] = 0.0; }        /* [3P] mju_normalize3 */
+    else if (fabs(s - 1.0) > 1e-15) { const double inv = 1.0 / s; ax[0] *= inv; ax[1] *= inv; ax[2] *= inv; }
+    double speed = 2.0 * orc_atan2(s, q[0]);
+    if (speed > 3.14159265358979311600e+00) speed = speed - 2.0 * 3.14159265358979311600e+00;
+    res[0] = ax[0] * speed; res[1] = ax[1] * speed; res[2] = ax[2] * speed;
+}
+
 /* ------------------------------------------------------------------ */
 /* scene                                                               */
 /* ------------------------------------------------------------------ */
@@ -1444,7 +1518,9 @@ void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, doubl
 /* ------------------------------------------------------------------ */
 /*  damped-least-squares IK of a site position        */
 /* ------------------------------------------------------------------ */
-/* Restates reference env/inverse_kinematics.py:18-135 (`qpos_from_site_pose`, position target only) with
+/* Restates reference env/inverse_kinematics.py:18-135 (`qpos_from_site_pose`; position target, or position + orientation
+ * target: 6 x n Jacobian [jacp; jacr], err = [target_pos - site_xpos; quat2Vel(target_quat * conj(site_xquat))],
+ * err_norm = |err_pos| + rot_weight |err_rot|, :38-44,88-107) with
  * `nullspace_method` :274-281: per iteration  err = target - site_xpos;  stop (success) if |err| < tol;
  * J = site position Jacobian w.r.t. the movable joints ([3P] mj_jacSite: hinge column = axis x (p_site - anchor),
  * slide column = axis);  dq = (J^T J + lambda I)^-1 J^T err  (the reference passes `regularization_strength`
@@ -1479,21 +1555,40 @@ static void ik_chol_solve(double H[ORC_IK_MAXJ][ORC_IK_MAXJ], const double *g, d
 }
 
 void orc_ik_solve(const OrcScene *s, int n_joints, const int32_t *joint_ids, int site_body, const double *site_off,
-                  double *qpos, const double *target_pos, int max_steps, double tol, double max_update_norm,
-                  double progress_thresh, double reg_strength, double *err_norm_out, int32_t *steps_out, uint8_t *success_out) {
+                  const double *site_quat, double *qpos, const double *target_pos, const double *target_quat, double rot_weight,
+                  int max_steps, double tol, double max_update_norm, double progress_thresh, double reg_strength,
+                  double *err_norm_out, int32_t *steps_out, uint8_t *success_out) {
     double *buf = (double *)malloc(sizeof(double) * 16 * s->nbody);
     double *xpos = buf, *xquat = buf + 3 * s->nbody, *xmat = buf + 7 * s->nbody;
     double err_norm = 0.0;
     int steps = 0, success = 0;
+    const int nrow = target_quat ? 6 : 3;
+    double smat_local[9];
+    if (site_quat) quat2mat(smat_local, site_quat);
     for (steps = 0; steps < max_steps; steps++) {
         fk_bodies(s, qpos, xpos, xquat, xmat, 0);
-        double psite[3], err[3];
+        double psite[3], err[6] = {0, 0, 0, 0, 0, 0};
         frame_pos(psite, xpos, xmat, site_body, site_off);
         sub3(err, target_pos, psite);
         err_norm = norm3(err);
+        if (target_quat) {
+            /* :88-93  site_xquat = mat2Quat(site_xmat); err_rot = quat2Vel(target_quat * conj(site_xquat), 1) */
+            double smat[9], sq[4], nq[4], eq[4];
+            const double *bm = xmat + 9 * site_body;
+            if (site_quat) {
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++)
+                        smat[3 * r + c] = fma(bm[3 * r + 2], smat_local[6 + c], fma(bm[3 * r + 1], smat_local[3 + c], bm[3 * r] * smat_local[c]));
+            } else memcpy(smat, bm, sizeof smat);
+            mj_mat2quat(sq, smat);
+            nq[0] = sq[0]; nq[1] = -sq[1]; nq[2] = -sq[2]; nq[3] = -sq[3];
+            quat_mul(eq, target_quat, nq);
+            mj_quat2vel(err + 3, eq);
+            err_norm = err_norm + norm3(err + 3) * rot_weight;
+        }
         if (err_norm < tol) { success = 1; break; }
-        double J[3][ORC_IK_MAXJ];
-        for (int k = 0; k < ORC_IK_MAXJ; k++) J[0][k] = J[1][k] = J[2][k] = 0.0;
+        double J[6][ORC_IK_MAXJ];
+        for (int k = 0; k < ORC_IK_MAXJ; k++) for (int r = 0; r < 6; r++) J[r][k] = 0.0;
         for (int k = 0; k < n_joints; k++) {
             const int j = joint_ids[k];
             /* owning body and whether it is an ancestor (or the body) of the site's body */
@@ -1511,13 +1606,19 @@ void orc_ik_solve(const OrcScene *s, int n_joints, const int32_t *joint_ids, int
             if (s->jnt_type[j] == J_SLIDE) { c[0] = axis[0]; c[1] = axis[1]; c[2] = axis[2]; }
             else { sub3(r, psite, anchor); cross3(c, axis, r); }
             J[0][k] = c[0]; J[1][k] = c[1]; J[2][k] = c[2];
+            if (s->jnt_type[j] != J_SLIDE) { J[3][k] = axis[0]; J[4][k] = axis[1]; J[5][k] = axis[2]; }   /* [3P] jacr: hinge = axis, slide = 0 */
         }
         double H[ORC_IK_MAXJ][ORC_IK_MAXJ], g[ORC_IK_MAXJ], x[ORC_IK_MAXJ];
         for (int i = 0; i < ORC_IK_MAXJ; i++) {
-            for (int j2 = 0; j2 < ORC_IK_MAXJ; j2++)
-                H[i][j2] = fma(J[2][i], J[2][j2], fma(J[1][i], J[1][j2], J[0][i] * J[0][j2]));
+            for (int j2 = 0; j2 < ORC_IK_MAXJ; j2++) {
+                double h = fma(J[2][i], J[2][j2], fma(J[1][i], J[1][j2], J[0][i] * J[0][j2]));
+                if (nrow == 6) h = fma(J[5][i], J[5][j2], fma(J[4][i], J[4][j2], fma(J[3][i], J[3][j2], h)));
+                H[i][j2] = h;
+            }
             H[i][i] = (i < n_joints) ? H[i][i] + reg_strength : 1.0;   /* padding rows: identity */
-            g[i] = fma(J[2][i], err[2], fma(J[1][i], err[1], J[0][i] * err[0]));
+            double gi = fma(J[2][i], err[2], fma(J[1][i], err[1], J[0][i] * err[0]));
+            if (nrow == 6) gi = fma(J[5][i], err[5], fma(J[4][i], err[4], fma(J[3][i], err[3], gi)));
+            g[i] = gi;
         }
         ik_chol_solve(H, g, x);
         double un2 = 0.0;

@@ -118,11 +118,15 @@ void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, doubl
                         int32_t *ep_len, const double *action, int is_planner, const uint8_t *move_mask, double *obs,
                         double *reward, uint8_t *done, uint8_t *success, int nthreads);
 
-/*  damped-LS IK of a site position, one env, in place on qpos -- see mopa_oracle.c */
+/*  damped-LS IK of a site pose, one env, in place on qpos -- see mopa_oracle.c.
+ * site_quat: orientation of the site in its body's frame (NULL = identity); target_quat NULL = position target only. */
 void orc_ik_solve(const OrcScene *s, int n_joints, const int32_t *joint_ids /*model joint ids, <= 8*/, int site_body,
-                  const double *site_off /*[3]*/, double *qpos /*[nq] in/out*/, const double *target_pos /*[3]*/, int max_steps,
+                  const double *site_off /*[3]*/, const double *site_quat /*[4] or NULL*/, double *qpos /*[nq] in/out*/,
+                  const double *target_pos /*[3]*/, const double *target_quat /*[4] wxyz or NULL*/, double rot_weight, int max_steps,
                   double tol, double max_update_norm, double progress_thresh, double reg_strength, double *err_norm_out,
                   int32_t *steps_out, uint8_t *success_out);
+/* deterministic atan2 shared (as a specification) with the HIP IK kernel */
+double orc_atan2(double y, double x);
 
 #ifdef __cplusplus
 }

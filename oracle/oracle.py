@@ -78,8 +78,10 @@ def lib():
         L.orc_env_step.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), _dp, _dp, _u8p, _ip, _dp, C.c_int, C.c_int, _dp, _dp,
                                    _u8p, _u8p]
         L.orc_ik_solve.restype = None
-        L.orc_ik_solve.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, _dp, _dp, C.c_int, C.c_double, C.c_double, C.c_double,
-                                   C.c_double, _dp, _ip, _u8p]
+        L.orc_ik_solve.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
+                                   C.c_double, C.c_double, C.c_double, _dp, _ip, _u8p]
+        L.orc_atan2.restype = C.c_double
+        L.orc_atan2.argtypes = [C.c_double, C.c_double]
         L.orc_env_step_batch.restype = None
         L.orc_env_step_batch.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), C.c_int64, _dp, _dp, _u8p, _ip, _dp, C.c_int, _u8p,
                                          _dp, _dp, _u8p, _u8p, C.c_int]
@@ -106,6 +108,10 @@ class OrcEnvDesc(C.Structure):
         ("ac_scale", C.c_double), ("distance_threshold", C.c_double), ("success_reward", C.c_double),
         ("max_episode_steps", C.c_int32),
     ]
+
+
+def atan2(y: float, x: float) -> float:
+    return lib().orc_atan2(float(y), float(x))
 
 
 def exp_(x: float) -> float:
@@ -304,14 +310,16 @@ class OracleScene:
         return valid
 
     def ik_solve(self, qpos, target_pos, joint_ids, site_body, site_off, max_steps=100, tol=1e-2, max_update_norm=2.0,
-                 progress_thresh=20.0, reg_strength=3e-2):
+                 progress_thresh=20.0, reg_strength=3e-2, target_quat=None, site_quat=None, rot_weight=1.0):
         """damped-LS IK (env/inverse_kinematics.py:18-135 restated); returns (qpos, err_norm, steps, success)"""
         q = np.ascontiguousarray(qpos, dtype=np.float64).copy()
         t, tp = _d(target_pos); ji, jp = _i(joint_ids); so, sp = _d(site_off)
+        tq, tqp = _d(target_quat) if target_quat is not None else (None, None)
+        sq, sqp = _d(site_quat) if site_quat is not None else (None, None)
         en, st, su = C.c_double(0), C.c_int32(0), C.c_uint8(0)
-        lib().orc_ik_solve(self._h, len(ji), jp, int(site_body), sp, q.ctypes.data_as(_dp), tp, int(max_steps), float(tol),
-                           float(max_update_norm), float(progress_thresh), float(reg_strength), C.byref(en),
-                           C.byref(st), C.byref(su))
+        lib().orc_ik_solve(self._h, len(ji), jp, int(site_body), sp, sqp, q.ctypes.data_as(_dp), tp, tqp, float(rot_weight),
+                           int(max_steps), float(tol), float(max_update_norm), float(progress_thresh), float(reg_strength),
+                           C.byref(en), C.byref(st), C.byref(su))
         return q, en.value, st.value, bool(su.value)
 
     def plan(self, start, goal, range_: float, resolution: float = 0.005, max_iters: int = 2000,

@@ -61,3 +61,13 @@ def test_bad_arguments_are_status_codes_not_crashes():
     assert L.mopa_scene_num_active(None) == -1
     L.mopa_scene_destroy(None)                           # no-op
     assert L.mopa_planner_status(None) == b"none"
+
+
+def test_positive_contact_threshold_is_rejected():
+    """the broad phase culls at zero margin: a threshold > 0 would make verdicts depend on the cull (include/mopa_hip.h);
+    the check precedes device selection, so it is observable without a GPU"""
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs("SawyerPushObstacle-v0")
+    with pytest.raises(_lib.MopaError, match="contact_threshold"):
+        _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, 0.001)

@@ -1,5 +1,8 @@
-"""GPU parity of K5 (`k_ik_solve`, batched damped-LS IK) against oracle/mopa_oracle.c:orc_ik_solve: solved joint
-vectors, residual norms, step counts and success flags must be equal bit for bit."""
+"""GPU parity of K5 (`k_ik_solve`, batched damped-LS IK; position and position + orientation targets) against
+oracle/mopa_oracle.c:orc_ik_solve -- solved joint vectors, residual norms, step counts and success flags equal bit for bit --
+and against the reference's own `qpos_from_site_pose` (tests/golden/ref_py_ik.npz) to round-off."""
+import os
+
 import numpy as np
 import pytest
 
@@ -12,7 +15,8 @@ def _bits(a):
 
 @pytest.mark.parametrize("env", ["SawyerPushObstacle-v0", "SawyerAssemblyObstacle-v0", "SawyerLiftObstacle-v0"])
 @pytest.mark.parametrize("tol,n_joints", [(1e-2, 7), (1e-6, 7), (1e-2, 4)])
-def test_ik_bit_identical_to_oracle(env, tol, n_joints, oracle_mod):
+@pytest.mark.parametrize("with_quat", [False, True])
+def test_ik_bit_identical_to_oracle(env, tol, n_joints, with_quat, oracle_mod):
     import torch
     from mopa_rl_amd.ik import BatchIK
     from mopa_rl_amd.scene import default_qpos, planner_inputs
@@ -27,7 +31,7 @@ def test_ik_bit_identical_to_oracle(env, tol, n_joints, oracle_mod):
     adrs = [m.get_joint_qpos_addr(j) for j in pi.spec.robot_joints]
     q[:, adrs] += rng.normal(0, 0.25, (E, 7))
     # targets: site position of a perturbed arm pose (reachable), a third of them pushed far away (unreachable)
-    tgt = np.zeros((E, 3))
+    tgt, tquat = np.zeros((E, 3)), np.zeros((E, 4))
     for e in range(E):
         qq = q[e].copy()
         qq[adrs] += rng.normal(0, 0.3, 7)
@@ -37,13 +41,17 @@ def test_ik_bit_identical_to_oracle(env, tol, n_joints, oracle_mod):
                       [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
         tgt[e] = xpos[ik.site_body] + R @ ik.site_off
+        tquat[e] = xquat[ik.site_body]          # orientation of the perturbed pose (grip_site carries no rotation of its own)
     tgt[::3] += rng.normal(0, 1.5, (len(tgt[::3]), 3))
+    flip = rng.normal(size=(E, 4))
+    tquat[1::5] = flip[1::5] / np.linalg.norm(flip[1::5], axis=1, keepdims=True)      # arbitrary orientations, some > 90 deg away
     tq = torch.tensor(q, device="cuda")
-    res = ik.solve(tq, torch.tensor(tgt, device="cuda"), max_steps=100, tol=tol)
+    res = ik.solve(tq, torch.tensor(tgt, device="cuda"), torch.tensor(tquat, device="cuda") if with_quat else None, max_steps=100, tol=tol)
     gq, ge, gs, gok = res.qpos.cpu().numpy(), res.err_norm.cpu().numpy(), res.steps.cpu().numpy(), res.success.cpu().numpy()
     n_ok = 0
     for e in range(E):
-        oq, oe, os_, ook = orc.ik_solve(q[e], tgt[e], ik.joint_ids, ik.site_body, ik.site_off, max_steps=100, tol=tol)
+        oq, oe, os_, ook = orc.ik_solve(q[e], tgt[e], ik.joint_ids, ik.site_body, ik.site_off, max_steps=100, tol=tol,
+                                        target_quat=tquat[e] if with_quat else None)
         assert np.array_equal(_bits(gq[e]), _bits(oq)), (e, np.abs(gq[e] - oq).max())
         assert _bits(ge[e]) == _bits(oe) and gs[e] == os_ and bool(gok[e]) == ook, e
         n_ok += ook
@@ -74,6 +82,30 @@ def test_single_problem_form_and_errors():
     assert res.success == ook and res.qpos.shape == q.shape and res.steps == os_ > 0
     assert np.array_equal(res.qpos, oq) and res.err_norm == oe
     with pytest.raises(NotImplementedError):
-        qpos_from_site_pose(m, q, "grip_site", target_pos=target, target_quat=np.array([1.0, 0, 0, 0]), joint_names=["right_j0"])
+        qpos_from_site_pose(m, q, "grip_site", target_quat=np.array([1.0, 0, 0, 0]), joint_names=["right_j0"])
     with pytest.raises(_lib.MopaError):
         BatchIK(m, "grip_site", ["cube"])           # a free joint cannot be an IK joint
+
+
+@pytest.mark.parametrize("env,tag", [("SawyerAssemblyObstacle-v0", "assembly"), ("SawyerPushObstacle-v0", "push")])
+def test_ik_equals_reference_qpos_from_site_pose(env, tag):
+    """K5 against the REFERENCE'S OWN `qpos_from_site_pose` + `nullspace_method` (env/inverse_kinematics.py, run in the build
+    container over the oracle's FK: tools/gen_ref_py_golden.py), position-only and position + orientation targets, with the
+    rollouts' arguments (max_steps=100, tol=1e-2)."""
+    import torch
+    from mopa_rl_amd.ik import BatchIK
+    from mopa_rl_amd.scene import ENV_SPECS, load_scene
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_ik.npz"))
+    m = load_scene(ENV_SPECS[env].scene)
+    ik = BatchIK(m, "grip_site", ENV_SPECS[env].robot_joints)
+    uq = G[f"{tag}_use_quat"].astype(bool)
+    for sel, quat in ((uq, True), (~uq, False)):
+        q = torch.tensor(G[f"{tag}_qpos"][sel], device="cuda")
+        tp = torch.tensor(G[f"{tag}_target_pos"][sel], device="cuda")
+        tq = torch.tensor(G[f"{tag}_target_quat"][sel], device="cuda") if quat else None
+        r = ik.solve(q, tp, tq, max_steps=100, tol=1e-2)
+        np.testing.assert_allclose(r.qpos.cpu().numpy(), G[f"{tag}_qpos_out"][sel], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(r.err_norm.cpu().numpy(), G[f"{tag}_err_norm"][sel], rtol=0, atol=1e-10)
+        assert np.array_equal(r.steps.cpu().numpy(), G[f"{tag}_steps"][sel])
+        assert np.array_equal(r.success.cpu().numpy().astype(np.int64), G[f"{tag}_success"][sel])
+    assert 0 < G[f"{tag}_success"].sum() < len(uq) and uq.sum() > 20

@@ -428,40 +428,48 @@ def test_reference_api_end_to_end():
         assert not success and not valid and traj.shape == (1, pi.model.nq) and np.all(traj == -5)
 
 
-def test_full_size_batch_properties(oracle_mod):
-    """BASELINE.json's full single-GPU size (4096 envs x 256 states = 1 048 576 checks, the bench workload) through
-    size-independent properties: (i) both K1 generations agree on every state, (ii) verdicts and depths are equivariant
-    under a permutation of the states within each env (no dependence on tile / lane / queue position),
-    (iii) a state checked as a zero-length motion gets the same verdict, (iv) a random 16k-state subset equals the
-    CPU oracle bit for bit."""
+@pytest.mark.parametrize("env,prod,want_kernel", [
+    ("SawyerPushObstacle-v0", "v5-lds", "k_is_valid_v5"),       # what bench.py times (the library's own choice for Push)
+    ("SawyerPushObstacle-v0", "v5-slab", "k_is_valid_v5"),
+    ("SawyerLiftObstacle-v0", None, "k_is_valid_v5"),           # library's choice: slab centres + mesh gate + gated mesh pass
+    ("SawyerAssemblyObstacle-v0", None, "k_is_valid_v5"),       # library's choice: slab centres (34 moving geoms)
+])
+def test_full_size_batch_properties(env, prod, want_kernel, oracle_mod):
+    """BASELINE.json's full single-GPU size (4096 envs x 256 states = 1 048 576 checks, the bench workload) through the
+    PRODUCTION kernel and size-independent properties: (i) it agrees with both older K1 generations on every state
+    (verdicts and depths), with and without the per-state early-out, (ii) verdicts and depths are equivariant under a
+    permutation of the states within each env (no dependence on tile / lane / queue position), (iii) a state checked as a
+    zero-length motion gets the same verdict, (iv) a random 16k-state subset equals the CPU oracle bit for bit."""
     import torch
-    from bench import ENV, make_inputs
+    from bench import make_inputs
     from mopa_rl_amd.batch import BatchPlanner
     from mopa_rl_amd.scene import planner_inputs
-    pi = planner_inputs(ENV)
+    pi = planner_inputs(env)
     E, S = 4096, 256
     dev = torch.device("cuda:0")
     qa, rows = make_inputs(torch, pi, E, S, 1234, dev)
-    sc2 = _scene_with_kernel("v2", pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
-    sc1 = _scene_with_kernel("v1", pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
-    bp2, bp1 = BatchPlanner(sc2), BatchPlanner(sc1)
+    mk = lambda k: _scene_with_kernel(k, pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+    scp, sc2, sc1 = mk(prod), mk("v2"), mk("v1")
+    assert scp.valid_kernel(E * S) == want_kernel and sc2.valid_kernel(E * S) == "k_is_valid_v2" and sc1.valid_kernel(E * S) == "k_is_valid"
+    bpp, bp2, bp1 = BatchPlanner(scp), BatchPlanner(sc2), BatchPlanner(sc1)
+    vp_, mdp_ = bpp.is_valid(qa, rows, samples_per_env=S, want_min_dist=True)
+    vpe = bpp.is_valid(qa, rows, samples_per_env=S)                      # early-out instantiation (what the bench times)
     v2, md2 = bp2.is_valid(qa, rows, samples_per_env=S, want_min_dist=True)
-    v2e = bp2.is_valid(qa, rows, samples_per_env=S)                      # early-out instantiation
     v1, md1 = bp1.is_valid(qa, rows, samples_per_env=S, want_min_dist=True)
-    assert torch.equal(v1, v2) and torch.equal(v2, v2e)
-    assert torch.equal(md1.view(torch.int64), md2.view(torch.int64))
-    assert 0.2 < v2.float().mean().item() < 0.8
+    assert torch.equal(v1, v2) and torch.equal(v2, vp_) and torch.equal(vp_, vpe)
+    assert torch.equal(md1.view(torch.int64), md2.view(torch.int64)) and torch.equal(md2.view(torch.int64), mdp_.view(torch.int64))
+    assert 0.1 < vp_.float().mean().item() < 0.9
     # (ii) permute the states inside every env
     g = torch.Generator(device=dev)
     g.manual_seed(3)
     perm = torch.argsort(torch.rand(E, S, generator=g, device=dev), dim=1)
     flat = (perm + torch.arange(E, device=dev)[:, None] * S).reshape(-1)
-    vp, mdp = bp2.is_valid(qa[flat].contiguous(), rows, samples_per_env=S, want_min_dist=True)
-    assert torch.equal(vp, v2[flat]) and torch.equal(mdp.view(torch.int64), md2[flat].view(torch.int64))
+    vq, mdq = bpp.is_valid(qa[flat].contiguous(), rows, samples_per_env=S, want_min_dist=True)
+    assert torch.equal(vq, vp_[flat]) and torch.equal(mdq.view(torch.int64), mdp_[flat].view(torch.int64))
     # (iii) zero-length motions
     sub = slice(0, 65536)
-    mv = bp2.check_motion(qa[sub].contiguous(), qa[sub].contiguous(), rows, samples_per_env=S)
-    assert torch.equal(mv, v2[sub])
+    mv = bpp.check_motion(qa[sub].contiguous(), qa[sub].contiguous(), rows, samples_per_env=S)
+    assert torch.equal(mv, vp_[sub])
     # (iv) oracle on a random subset
     idx = torch.randperm(E * S, generator=g, device=dev)[:16384].sort().values
     qh, rh = qa[idx].cpu().numpy(), rows.cpu().numpy()
@@ -471,7 +479,42 @@ def test_full_size_batch_properties(oracle_mod):
     for e in np.unique(envs):
         m = envs == e
         ov[m], omd[m] = orc_batch(oracle_mod, pi, qh[m], rh[e:e + 1])
-    assert np.array_equal(ov, v2[idx].cpu().numpy()) and np.array_equal(_bits(omd), _bits(md2[idx].cpu().numpy()))
+    assert np.array_equal(ov, vpe[idx].cpu().numpy()) and np.array_equal(_bits(omd), _bits(mdp_[idx].cpu().numpy()))
+
+
+def test_two_streams_share_a_scene(oracle_mod):
+    """A scene keeps its launch scratch (pose slabs, deferred-pair ring, tile counter, mesh work list, motion / planner
+    buffers) per stream: validity launches of different batches on two streams, in flight together, give the results of
+    the same launches run one after the other -- for the plain third-generation path (Push) and the gated mesh path (Lift)."""
+    import torch
+    from bench import make_inputs
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import planner_inputs
+    dev = torch.device("cuda:0")
+    for env in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0"):
+        pi, sc, _ = _mk(env, oracle_mod)
+        bp = BatchPlanner(sc)
+        S = 64
+        qa1, rows1 = make_inputs(torch, pi, 1024, S, 1, dev)
+        qa2, rows2 = make_inputs(torch, pi, 2048, S, 2, dev)
+        ref1, ref2 = bp.is_valid(qa1, rows1, samples_per_env=S).clone(), bp.is_valid(qa2, rows2, samples_per_env=S).clone()
+        mref = bp.check_motion(qa1[:8192].contiguous(), qa1[8192:16384].contiguous(), rows1, samples_per_env=S).clone()
+        torch.cuda.synchronize()
+        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+        outs = []
+        for it in range(12):
+            o1, o2 = torch.empty_like(ref1), torch.empty_like(ref2)
+            with torch.cuda.stream(s1):
+                bp.is_valid(qa1, rows1, samples_per_env=S, out=o1, stream=s1)
+            with torch.cuda.stream(s2):
+                bp.is_valid(qa2, rows2, samples_per_env=S, out=o2, stream=s2)
+                m2 = bp.check_motion(qa1[:8192].contiguous(), qa1[8192:16384].contiguous(), rows1, samples_per_env=S, stream=s2) if it % 4 == 0 else None
+            outs.append((o1, o2, m2))
+        torch.cuda.synchronize()
+        for o1, o2, m2 in outs:
+            assert torch.equal(o1, ref1) and torch.equal(o2, ref2)
+            assert m2 is None or torch.equal(m2, mref)
+        assert 0.05 < ref1.float().mean().item() < 0.95
 
 
 _ORC_CACHE = {}

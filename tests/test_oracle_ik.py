@@ -92,3 +92,48 @@ def test_ik_leaves_other_joints_alone_and_handles_zero_steps(oracle_mod):
                                   np.delete(q, [int(m.jnt_qposadr[j]) for j in jids[:4]]))
     q3, e3, s3, ok3 = orc.ik_solve(q, p + [0.05, -0.04, 0.03], jids, sb, so, max_steps=1, tol=1e-9)
     assert not ok3 and s3 == 0
+
+
+@pytest.mark.parametrize("env,tag", [("SawyerAssemblyObstacle-v0", "assembly"), ("SawyerPushObstacle-v0", "push")])
+def test_oracle_ik_equals_reference_qpos_from_site_pose(env, tag, oracle_mod):
+    """orc_ik_solve against vectors produced by the REFERENCE'S OWN `qpos_from_site_pose` / `nullspace_method`
+    (env/inverse_kinematics.py:18-135,274-281; tests/golden/ref_py_ik.npz, tools/gen_ref_py_golden.py), position-only and
+    position + orientation targets: same joint vectors to round-off (np.linalg.solve vs Cholesky, np.arctan2 vs the shared
+    atan2), same iteration counts and success flags."""
+    import os
+    from mopa_rl_amd.scene import ENV_SPECS, load_scene
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_ik.npz"))
+    m = load_scene(ENV_SPECS[env].scene)
+    orc = oracle_mod.OracleScene(m, [], [], 0.0)
+    si = m.site_name2id("grip_site")
+    jids = [m.joint_name2id(j) for j in ENV_SPECS[env].robot_joints]
+    K = len(G[f"{tag}_qpos"])
+    for k in range(K):
+        uq = bool(G[f"{tag}_use_quat"][k])
+        q, en, st, su = orc.ik_solve(G[f"{tag}_qpos"][k], G[f"{tag}_target_pos"][k], jids, int(m.site_body[si]), m.site_pos[si],
+                                     max_steps=100, tol=1e-2, target_quat=G[f"{tag}_target_quat"][k] if uq else None,
+                                     site_quat=m.site_quat[si])
+        np.testing.assert_allclose(q, G[f"{tag}_qpos_out"][k], rtol=0, atol=1e-10, err_msg=str(k))
+        assert abs(en - G[f"{tag}_err_norm"][k]) < 1e-10 and st == G[f"{tag}_steps"][k] and su == bool(G[f"{tag}_success"][k]), k
+
+
+def test_nullspace_method_linear_solve(oracle_mod):
+    """the regularised normal-equation solve on its own: (J^T J + 0.03 I) x = J^T d from the reference's `nullspace_method`
+    (3 x 7 and 6 x 7 Jacobians) vs a Cholesky solve in numpy with the kernel's operation order"""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_ik.npz"))
+    for J, d, rows, want in zip(G["ns_J"], G["ns_delta"], G["ns_rows"], G["ns_out"]):
+        J, d = J[:rows], d[:rows]
+        H = J.T @ J + 0.03 * np.eye(7)
+        L = np.linalg.cholesky(H)
+        x = np.linalg.solve(L.T, np.linalg.solve(L, J.T @ d))
+        np.testing.assert_allclose(x, want, rtol=1e-11, atol=1e-13)
+
+
+def test_atan2_matches_libm(oracle_mod):
+    rng = np.random.default_rng(0)
+    xs, ys = rng.normal(size=4000), rng.normal(size=4000)
+    got = np.array([oracle_mod.atan2(y, x) for x, y in zip(xs, ys)])
+    assert np.abs(got - np.arctan2(ys, xs)).max() < 1e-15
+    for y, x in [(0, 0), (0, 1), (0, -1), (1, 0), (-1, 0), (1e-300, 1), (1, 1e-300), (0.198912367379658, 1.0), (0.668178637919299, 1.0)]:
+        assert abs(oracle_mod.atan2(y, x) - np.arctan2(y, x)) < 1e-15

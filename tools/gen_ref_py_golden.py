@@ -420,12 +420,61 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
          params=np.array([P["timelimit"], P["max_nodes"], P["max_path"], P["seed"], P["max_episode_steps"], P["num_trials"]]), **out)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# section "ik": env/inverse_kinematics.py:qpos_from_site_pose (+ nullspace_method) on the reference env over FakeSim (f3)
+# ------------------------------------------------------------------------------------------------------------------
+def gen_ik():
+    from env.inverse_kinematics import nullspace_method, qpos_from_site_pose
+    rng = np.random.default_rng(5)
+    out = {}
+    # nullspace_method on its own (:274-281): random Jacobians / errors, 3 x 7 and 6 x 7
+    Js, ds, xs = [], [], []
+    for k in range(40):
+        J = rng.normal(0, 0.5, (6 if k % 2 else 3, 7))
+        d = rng.normal(0, 0.2, J.shape[0])
+        Js.append(np.vstack([J, np.zeros((6 - J.shape[0], 7))])); ds.append(np.r_[d, np.zeros(6 - len(d))])
+        xs.append(nullspace_method(J, d, regularization_strength=3e-2))
+    out.update(ns_J=np.array(Js), ns_delta=np.array(ds), ns_rows=np.array([6 if k % 2 else 3 for k in range(40)]), ns_out=np.array(xs))
+    for env_name, tag in (("SawyerAssemblyObstacle-v0", "assembly"), ("SawyerPushObstacle-v0", "push")):
+        env = make_ref_env(env_name, seed=3)
+        env.reset()
+        K = 48
+        nq = env.sim.model.nq
+        q_in, tp, tq, use_q = np.zeros((K, nq)), np.zeros((K, 3)), np.zeros((K, 4)), np.zeros(K, dtype=np.int64)
+        q_out, en, st, su = np.zeros((K, nq)), np.zeros(K), np.zeros(K, dtype=np.int64), np.zeros(K, dtype=np.int64)
+        for k in range(K):
+            env.reset()
+            q = env.sim.data.qpos.copy()
+            q[env.ref_joint_pos_indexes] += rng.normal(0, 0.15, 7)
+            env.set_state(q, env.sim.data.qvel.copy())
+            site = "grip_site"
+            # targets as rl/mopa_rollouts.py:91-99 forms them: current site position + action_range * a, clipped to the world box
+            scale = (0.02, 0.1, 0.5)[k % 3]
+            target_pos = np.clip(env.sim.data.get_site_xpos(site) + scale * rng.uniform(-1, 1, 3), env.min_world_size, env.max_world_size)
+            cur_q = np.zeros(4)
+            refshim.mju_mat2Quat(cur_q, env.sim.data.get_site_xmat(site).ravel())
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+            ang = (0.05, 0.4, 2.5)[(k // 3) % 3] * rng.uniform(0.5, 1.0)
+            dq = np.r_[np.cos(ang / 2), np.sin(ang / 2) * ax]
+            target_quat = np.zeros(4)
+            refshim.mju_mulQuat(target_quat, cur_q, dq)
+            use_q[k] = k % 4 != 0
+            q_in[k], tp[k], tq[k] = q, target_pos, target_quat
+            r = qpos_from_site_pose(env, site, target_pos=target_pos, target_quat=target_quat if use_q[k] else None,
+                                    joint_names=env.robot_joints, max_steps=100, tol=1e-2)
+            q_out[k], en[k], st[k], su[k] = np.array(r.qpos), r.err_norm, r.steps, int(r.success)
+        print(f"  ik[{tag}]: success {int(su.sum())}/{K}  with quat {int(use_q.sum())}  steps max {int(st.max())} mean {st.mean():.1f}")
+        out.update({f"{tag}_qpos": q_in, f"{tag}_target_pos": tp, f"{tag}_target_quat": tq, f"{tag}_use_quat": use_q,
+                    f"{tag}_qpos_out": q_out, f"{tag}_err_norm": en, f"{tag}_steps": st, f"{tag}_success": su})
+    save("ref_py_ik.npz", **out)
+
+
 def gen_rollouts():
     gen_rollout()
     gen_rollout(E=12, T=4, reuse=True)
 
 
-SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts)
+SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik)
 
 
 def main():

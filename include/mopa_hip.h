@@ -190,35 +190,59 @@ int mopa_debug_fk(MopaScene *scene, const double *qpos_host /*[nq]*/, double *ge
 int mopa_debug_pair_dist(MopaScene *scene, const double *qpos_host /*[nq]*/, double *dist_host /*[npair]*/);
 
 /* ======================================================================================================
- *  batched KINEMATIC env.step for the Sawyer push family -- the "env-steps/sec" half
- * of the metric.  Restates what SawyerPushObstacleEnv computes around the physics:
- *   action scaling / desired joint state     env/sawyer/sawyer_push_obstacle.py:162-208
+ * (BASELINE configs 3-5) batched KINEMATIC env.step for the three Sawyer obstacle envs --
+ * the "env-steps/sec" half of the metric.  Restates what the reference envs compute around the physics:
+ *   action scaling / desired joint state     `_step` of env/sawyer/sawyer_{push,lift,assembly}_obstacle.py
+ *                                            (Lift: gripper target = gripper qpos + action[-1], sawyer.py:340-342)
  *   joint-limit clamp + episode bookkeeping  env/base.py:269-314
- *   reward / success                         env/sawyer/sawyer_push_obstacle.py:71-104
- *   observation (40 numbers, dict order)     env/sawyer/sawyer.py:317-338, sawyer_push_obstacle.py:106-119
- * and REPLACES the physics (`_do_simulation`, 75 MuJoCo sub-steps of a position servo) by its kinematic
- * limit: the arm reaches `desired_state` exactly, velocities are zero, nothing else moves (no contact
- * forces: the cube never moves).  NOT dynamics parity -- labelled as such wherever it is reported.
+ *   reward / success                         sawyer_push_obstacle.py:71-104, sawyer_lift_obstacle.py:93-150,
+ *                                            sawyer_assembly_obstacle.py:33-52
+ *   observation (dict order)                 env/sawyer/sawyer.py:317-338 + the env's `_get_obs`
+ * and REPLACES the physics (`_do_simulation`, 75 MuJoCo sub-steps of position servos) by its kinematic
+ * limit: every actuated joint reaches its target clamped to the actuator's ctrlrange, velocities are zero,
+ * nothing else moves (no contact forces: the manipulated object never moves).  NOT dynamics parity -- labelled as
+ * such wherever it is reported.
+ *
+ * Frame / quat slots per kind (positions = world position of a point fixed in a body; quats = body orientations):
+ *   all       frame 0 = site "grip_site";                           quat 0 = body "right_ee_attchment"
+ *   PUSH      frames 1,2 = sites "right_eef","left_eef", 3 = body "cube", 4 = body "target";   quat 1 = "cube"
+ *             obs[40]: common 25 + target_pos, cube_pos, cube_quat(xyzw), gripper_to_cube, cube_to_target
+ *   LIFT      frames 1 = body "cube" (the can), 2 = body "bin1";                                 quat 1 = "cube"
+ *             obs[35]: common 25 + cube_pos, cube_quat(xyzw), gripper_to_cube;  action[8] = 7 arm + gripper
+ *             grasp test (`has_grasp`): touch geoms [can mesh, left-finger boxes..., right-finger boxes...]
+ *   ASSEMBLY  frames 1..4 = sites "hole","hole_bottom","pegHead","pegEnd";                     quat 1 = "peg"
+ *             obs[38]: common 25 + hole, pegHead, pegEnd, peg_quat(wxyz)
+ *   common 25 = joint_pos 7, joint_vel 7 (0), gripper_qpos 2, gripper_qvel 2 (0), eef_pos 3, eef_quat 4 (xyzw)
  * ====================================================================================================== */
-#define MOPA_ENV_OBS_DIM 40
+#define MOPA_ENV_PUSH 0
+#define MOPA_ENV_LIFT 1
+#define MOPA_ENV_ASSEMBLY 2
+#define MOPA_ENV_OBS_DIM 40      /* largest observation (PUSH); see mopa_env_obs_dim */
 
 typedef struct MopaEnvDesc {
-    MopaModel model;                 /* only the body / joint arrays are read */
+    MopaModel model;                 /* body / joint arrays; LIFT also reads the touch geoms and the can's hull */
+    int32_t kind;                    /* MOPA_ENV_* */
     int32_t n_arm;                   /* env.ref_joint_pos_indexes (7) */
     const int32_t *arm_qpos_idx;
     int32_t n_grip;                  /* env.ref_gripper_joint_pos_indexes (2) */
     const int32_t *grip_qpos_idx;
-    /* frames the obs / reward read, each as (body id, offset in the body frame): */
-    int32_t eef_body;     double eef_off[3];       /* site "grip_site"  (sawyer.py:199) */
-    int32_t rfinger_body; double rfinger_off[3];   /* site "right_eef"  (sawyer_push_obstacle.py:76-79) */
-    int32_t lfinger_body; double lfinger_off[3];   /* site "left_eef" */
-    int32_t ee_quat_body;            /* body "right_ee_attchment" (sawyer.py:334) */
-    int32_t cube_body, target_body;  /* sawyer_push_obstacle.py:27-28 */
+    int32_t n_act;                   /* position actuators written by `_do_simulation`, ctrl order: the arm's n_arm, then (LIFT) 2 gripper */
+    const int32_t *act_qpos_idx;     /* [n_act] qpos address of the actuated joint */
+    const double *act_ctrl_lo;       /* [n_act] ctrlrange (-inf / +inf when not ctrllimited) */
+    const double *act_ctrl_hi;
+    int32_t n_frames;                /* 5 (PUSH, ASSEMBLY) or 3 (LIFT), slots as listed above */
+    const int32_t *frame_body;       /* [n_frames] */
+    const double *frame_off;         /* [n_frames,3] offset in the body frame (site position; 0 for a body frame) */
+    int32_t n_quats;                 /* 2 */
+    const int32_t *quat_body;
+    int32_t n_touch;                 /* LIFT: 1 + left + right collidable-geom indices (into model.geom_*), else 0 */
+    const int32_t *touch_geom;
+    int32_t n_touch_left;
     const double  *qpos_min;         /* [nq] per-qpos joint limits: _jnt_minimum[jnt_indices] (env/base.py:62-88) */
     const double  *qpos_max;         /* [nq] */
     const int32_t *qpos_limited;     /* [nq] */
     double ac_scale;                 /* config/sawyer.py (0.05) */
-    double distance_threshold;       /* 0.06 */
+    double distance_threshold;       /* PUSH: 0.06 */
     double success_reward;           /* 150 */
     int32_t max_episode_steps;       /* 250 */
     int32_t device;                  /* HIP device ordinal, -1 = current */
@@ -228,19 +252,23 @@ typedef struct MopaEnv MopaEnv;
 
 int mopa_env_create(const MopaEnvDesc *desc, MopaEnv **out);
 void mopa_env_destroy(MopaEnv *env);
+int mopa_env_obs_dim(const MopaEnv *env);      /* 40 / 35 / 38 */
+int mopa_env_action_dim(const MopaEnv *env);   /* n_arm (+1 for LIFT) */
 
 /* One step of E envs (all pointers device, f64 unless noted).  Per env e:
  *   prev = (is_planner && has_prev[e]) ? prev_state[e] : qpos[e, arm]
- *   desired = prev + clip(is_planner ? action[e] : action[e]*ac_scale, -ac_scale, +ac_scale)
+ *   desired = prev + clip(is_planner ? action[e, :n_arm] : action[e, :n_arm]*ac_scale, -ac_scale, +ac_scale)
+ *   LIFT: gripper targets = qpos[e, gripper] + action[e, n_arm]
  *   move_mask[e] (NULL = 1): bit 1 set -> env e sits this call out entirely (nothing read or written);
- *   bit 0 set -> qpos[e, arm] = desired (kinematic servo); bit 0 clear -> the command is recorded but the arm stays
+ *   bit 0 set -> every actuated joint = its target clamped to ctrlrange (kinematic servo); bit 0 clear -> the command is
+ *   recorded but nothing moves
  *   prev_state[e] = desired, has_prev[e] = 1; limited qpos entries clipped to their range
  *   FK -> reward, success, obs; ep_len[e] += 1; done[e] = success || ep_len[e] == max_episode_steps
  * action == NULL: no step, only FK -> obs (reward/done/success untouched; used after a reset). */
 int mopa_env_step_batch(MopaEnv *env, int64_t E, double *qpos_dev /*[E,nq] in/out*/, double *prev_state_dev /*[E,n_arm] in/out*/,
                         uint8_t *has_prev_dev /*[E] in/out*/, int32_t *ep_len_dev /*[E] in/out*/,
-                        const double *action_dev /*[E,n_arm] or NULL*/, int32_t is_planner,
-                        const uint8_t *move_mask_dev /*[E] or NULL*/, double *obs_dev /*[E,40]*/,
+                        const double *action_dev /*[E,action_dim] or NULL*/, int32_t is_planner,
+                        const uint8_t *move_mask_dev /*[E] or NULL*/, double *obs_dev /*[E,obs_dim]*/,
                         double *reward_dev /*[E]*/, uint8_t *done_dev /*[E]*/, uint8_t *success_dev /*[E]*/, void *stream);
 
 /* Waypoint execution of the rollout runner (rl/mopa_rollouts.py:152-199) for E envs in ONE launch: env e steps through
@@ -248,23 +276,25 @@ int mopa_env_step_batch(MopaEnv *env, int64_t E, double *qpos_dev /*[E,nq] in/ou
  * state, is_planner semantics of mopa_env_step_batch) until its path ends or a step reports done, with
  *   smdp_rew[e] += disc_pow[k] * reward_k   (disc_pow[k] = discount_factor^k, supplied by the caller),
  *   smdp_done[e] = done_k, intra[e] = k for the last step taken.  Envs with path_len[e] == 0 are not touched.
+ * last_extra (LIFT; NULL otherwise): the policy's gripper action, used as the gripper entry of the LAST waypoint's action
+ * (:163-167); earlier waypoints use form_action's gripper difference.
  * rec_* (all four or none): per executed waypoint the obs after the step, the running return and the done flag, and
  * n_exec[e] = steps taken -- the reference's ob_list / meta_rew_list / done_list (input of its reuse_data relabelling).
  * obs / reward / done / success hold the env's last step afterwards, exactly as after that many mopa_env_step_batch calls. */
 int mopa_env_exec_batch(MopaEnv *env, int64_t E, double *qpos_dev /*[E,nq] in/out*/, double *prev_state_dev /*[E,n_arm] in/out*/,
                         uint8_t *has_prev_dev /*[E] in/out*/, int32_t *ep_len_dev /*[E] in/out*/,
                         const double *traj_dev /*[E,L,nq]*/, const int64_t *path_len_dev /*[E]*/, int32_t L,
-                        const double *disc_pow_dev /*[L]*/, double *obs_dev /*[E,40]*/, double *reward_dev /*[E]*/,
+                        const double *disc_pow_dev /*[L]*/, const double *last_extra_dev /*[E] or NULL*/,
+                        double *obs_dev /*[E,obs_dim]*/, double *reward_dev /*[E]*/,
                         uint8_t *done_dev /*[E]*/, uint8_t *success_dev /*[E]*/, double *smdp_rew_dev /*[E] in/out*/,
                         uint8_t *smdp_done_dev /*[E] in/out*/, int64_t *intra_dev /*[E] in/out*/,
-                        double *rec_ob_dev /*[E,L,40] or NULL*/, double *rec_rew_dev /*[E,L] or NULL*/,
+                        double *rec_ob_dev /*[E,L,obs_dim] or NULL*/, double *rec_rew_dev /*[E,L] or NULL*/,
                         uint8_t *rec_done_dev /*[E,L] or NULL*/, int64_t *n_exec_dev /*[E] or NULL*/, void *stream);
 
-/* The limit-clamped arm state the NEXT mopa_env_step_batch call with the same arguments would command
- * (desired_state of sawyer_push_obstacle.py:186), without stepping: input of a collision gate
- * (mopa_is_valid_batch with samples_per_env = 1 -> move_mask). */
+/* The arm state the NEXT mopa_env_step_batch call with the same arguments would reach (desired_state clamped to ctrlrange
+ * and joint limits), without stepping: input of a collision gate (mopa_is_valid_batch with samples_per_env = 1 -> move_mask). */
 int mopa_env_desired_batch(MopaEnv *env, int64_t E, const double *qpos_dev /*[E,nq]*/, const double *prev_state_dev /*[E,n_arm]*/,
-                           const uint8_t *has_prev_dev /*[E]*/, const double *action_dev /*[E,n_arm]*/, int32_t is_planner,
+                           const uint8_t *has_prev_dev /*[E]*/, const double *action_dev /*[E,action_dim]*/, int32_t is_planner,
                            double *desired_dev /*[E,n_arm]*/, void *stream);
 
 /* ======================================================================================================

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "mopa_scene_num_active", "mopa_scene_active_idx", "mopa_scene_num_pairs", "mopa_scene_lds_bytes", "mopa_scene_valid_kernel",
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
-    "mopa_env_create", "mopa_env_destroy", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
+    "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch",
 ]
 
@@ -59,10 +59,11 @@ class MopaSceneDesc(C.Structure):
 
 class MopaEnvDesc(C.Structure):
     _fields_ = [
-        ("model", MopaModel), ("n_arm", C.c_int32), ("arm_qpos_idx", _ip), ("n_grip", C.c_int32), ("grip_qpos_idx", _ip),
-        ("eef_body", C.c_int32), ("eef_off", C.c_double * 3), ("rfinger_body", C.c_int32), ("rfinger_off", C.c_double * 3),
-        ("lfinger_body", C.c_int32), ("lfinger_off", C.c_double * 3), ("ee_quat_body", C.c_int32),
-        ("cube_body", C.c_int32), ("target_body", C.c_int32), ("qpos_min", _dp), ("qpos_max", _dp), ("qpos_limited", _ip),
+        ("model", MopaModel), ("kind", C.c_int32), ("n_arm", C.c_int32), ("arm_qpos_idx", _ip), ("n_grip", C.c_int32), ("grip_qpos_idx", _ip),
+        ("n_act", C.c_int32), ("act_qpos_idx", _ip), ("act_ctrl_lo", _dp), ("act_ctrl_hi", _dp),
+        ("n_frames", C.c_int32), ("frame_body", _ip), ("frame_off", _dp), ("n_quats", C.c_int32), ("quat_body", _ip),
+        ("n_touch", C.c_int32), ("touch_geom", _ip), ("n_touch_left", C.c_int32),
+        ("qpos_min", _dp), ("qpos_max", _dp), ("qpos_limited", _ip),
         ("ac_scale", C.c_double), ("distance_threshold", C.c_double), ("success_reward", C.c_double),
         ("max_episode_steps", C.c_int32), ("device", C.c_int32),
     ]
@@ -123,7 +124,9 @@ def lib() -> C.CDLL:
     L.mopa_env_destroy.argtypes = [vp]
     L.mopa_env_destroy.restype = None
     L.mopa_env_step_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
-    L.mopa_env_exec_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mopa_env_obs_dim.argtypes = [vp]
+    L.mopa_env_action_dim.argtypes = [vp]
+    L.mopa_env_exec_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mopa_env_desired_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp, vp]
     L.mopa_ik_create.argtypes = [C.POINTER(MopaIkDesc), C.POINTER(vp)]
     L.mopa_ik_destroy.argtypes = [vp]

@@ -1,13 +1,17 @@
-"""Batched KINEMATIC SawyerPushObstacle env on libmopa_hip.so.
+"""Batched KINEMATIC Sawyer envs (SURVEY.md 8f row 1 + the Lift / Assembly envs of BASELINE configs 4 and 5) on
+libmopa_hip.so: SawyerPushObstacle-v0, SawyerLiftObstacle-v0, SawyerAssemblyObstacle-v0.
 
-Restates the reference env's arithmetic around the physics -- action scaling and `desired_state`
-(env/sawyer/sawyer_push_obstacle.py:162-208), joint-limit clamp + episode bookkeeping (env/base.py:269-314),
-reward/success (sawyer_push_obstacle.py:71-104), the 40-number observation in dict order (env/sawyer/sawyer.py:317-338,
-sawyer_push_obstacle.py:106-119) and `_reset` (sawyer_push_obstacle.py:36-52) -- and replaces `_do_simulation`
-(75 MuJoCo sub-steps of a position servo) by its kinematic limit: the arm reaches `desired_state`, velocities are
-zero, nothing else moves.  **Not dynamics parity**: no contact forces, the cube never moves, so the push reward can
-only be collected by a policy in the real env.  What it is for: the "env-steps/sec" half of the metric, and the
-planner-side rollouts of MoPA-RL (a planned, collision-checked joint path is executed kinematically by construction).
+Restates the reference envs' arithmetic around the physics -- action scaling and `desired_state` (`_step` of
+env/sawyer/sawyer_{push,lift,assembly}_obstacle.py; Lift adds the gripper command `gripper qpos + action[-1]`,
+sawyer.py:340-342), joint-limit clamp + episode bookkeeping (env/base.py:269-314), reward / success (`compute_reward`),
+the observation in dict order (env/sawyer/sawyer.py:317-338 + the env's `_get_obs`) and `_reset` -- and replaces
+`_do_simulation` (75 MuJoCo sub-steps of position servos) by its kinematic limit: every actuated joint reaches its
+target, clamped to the actuator's ctrlrange; velocities are zero, nothing else moves.  **Not dynamics parity**: no
+contact forces, the manipulated object never moves, so push / lift rewards that need the object to move can only be
+collected by a policy in the real env (the assembly reward -- peg head to hole -- is purely kinematic).  What it is for:
+the "env-steps/sec" half of the metric, and the planner-side rollouts of MoPA-RL (a planned, collision-checked joint
+path is executed kinematically by construction).  Checked against the reference's own env classes run over a
+sim-shaped adapter (tests/golden/ref_py_env_*.npz, tools/gen_ref_py_golden.py) and bit for bit against the CPU oracle.
 
 `block_invalid=True` adds the one piece of contact behaviour a kinematic arm can have: a step whose desired state is
 in collision (K1 validity kernel, same rule as the planner) is not executed -- the arm stays where it is.
@@ -28,79 +32,146 @@ from . import _lib
 from .batch import BatchPlanner, _ptr, _stream_handle, _torch
 from .scene import ENV_SPECS, load_scene, planner_inputs, qpos_joint_arrays
 
+KIND_PUSH, KIND_LIFT, KIND_ASSEMBLY = 0, 1, 2
+ENV_KIND = {"SawyerPushObstacle-v0": KIND_PUSH, "SawyerLiftObstacle-v0": KIND_LIFT, "SawyerAssemblyObstacle-v0": KIND_ASSEMBLY}
+
+# observation layouts == the reference's OrderedDict order (sawyer.py:317-338, then the env's own `_get_obs`)
+_COMMON = [("joint_pos", 7), ("joint_vel", 7), ("gripper_qpos", 2), ("gripper_qvel", 2), ("eef_pos", 3), ("eef_quat", 4)]
+OBS_LAYOUTS = {
+    KIND_PUSH: OrderedDict(_COMMON + [("target_pos", 3), ("cube_pos", 3), ("cube_quat", 4), ("gripper_to_cube", 3), ("cube_to_target", 2)]),
+    KIND_LIFT: OrderedDict(_COMMON + [("cube_pos", 3), ("cube_quat", 4), ("gripper_to_cube", 3)]),
+    KIND_ASSEMBLY: OrderedDict(_COMMON + [("hole", 3), ("pegHead", 3), ("pegEnd", 3), ("peg_quat", 4)]),
+}
+OBS_LAYOUT = OBS_LAYOUTS[KIND_PUSH]
 OBS_DIM = 40
-# observation layout == the reference's OrderedDict order (sawyer.py:317-338 then sawyer_push_obstacle.py:106-119)
-OBS_LAYOUT = OrderedDict([
-    ("joint_pos", 7), ("joint_vel", 7), ("gripper_qpos", 2), ("gripper_qvel", 2), ("eef_pos", 3), ("eef_quat", 4),
-    ("target_pos", 3), ("cube_pos", 3), ("cube_quat", 4), ("gripper_to_cube", 3), ("cube_to_target", 2)])
 
 
 @dataclass
-class PushEnvFacts:
-    """Name -> id resolution of what SawyerPushObstacleEnv._get_reference looks up (sawyer.py:164-199,
-    sawyer_push_obstacle.py:17-30), on a CompiledModel."""
+class EnvFacts:
+    """Name -> id resolution of what the reference env's `_get_reference` / `compute_reward` / `_get_obs` look up, on a
+    CompiledModel.  Frames (world position of a body-fixed point) and quats (world orientation of a body) are listed in
+    the slot order the kernel expects for `kind`:
+      all       frame 0 = site grip_site,  quat 0 = body right_ee_attchment
+      push      frames 1 right_eef, 2 left_eef (sites), 3 cube, 4 target (bodies);  quat 1 = cube
+      lift      frames 1 cube, 2 bin1 (bodies);  quat 1 = cube;  touch geoms = [can, left-finger geoms, right-finger geoms]
+      assembly  frames 1 hole, 2 hole_bottom, 3 pegHead, 4 pegEnd (sites);  quat 1 = peg"""
+    kind: int
     arm_qpos_idx: np.ndarray
     grip_qpos_idx: np.ndarray
-    target_qpos_idx: np.ndarray
-    eef_body: int
-    eef_off: np.ndarray
-    rfinger_body: int
-    rfinger_off: np.ndarray
-    lfinger_body: int
-    lfinger_off: np.ndarray
-    ee_quat_body: int
-    cube_body: int
-    target_body: int
+    act_qpos_idx: np.ndarray
+    act_lo: np.ndarray
+    act_hi: np.ndarray
+    frame_body: np.ndarray
+    frame_off: np.ndarray
+    quat_body: np.ndarray
+    touch_geom: np.ndarray
+    n_touch_left: int
     qpos_min: np.ndarray
     qpos_max: np.ndarray
     qpos_limited: np.ndarray
+    reset_jitter_idx: np.ndarray      # qpos addresses that `_reset` moves by U(-0.01, 0.01) (push: the target sliders)
+
+    @property
+    def action_dim(self) -> int:
+        return len(self.arm_qpos_idx) + (1 if self.kind == KIND_LIFT else 0)
+
+    # named views of the slots (all kinds: eef / ee_quat; push: fingers, cube, target)
+    eef_body = property(lambda self: int(self.frame_body[0]))
+    eef_off = property(lambda self: self.frame_off[0])
+    ee_quat_body = property(lambda self: int(self.quat_body[0]))
+    rfinger_body = property(lambda self: int(self.frame_body[1]))
+    rfinger_off = property(lambda self: self.frame_off[1])
+    lfinger_body = property(lambda self: int(self.frame_body[2]))
+    lfinger_off = property(lambda self: self.frame_off[2])
+    cube_body = property(lambda self: int(self.frame_body[3] if self.kind == KIND_PUSH else self.frame_body[1]))
+    target_body = property(lambda self: int(self.frame_body[4]))
+    target_qpos_idx = property(lambda self: self.reset_jitter_idx)
+
+    @property
+    def obs_dim(self) -> int:
+        return sum(OBS_LAYOUTS[self.kind].values())
 
 
-def push_env_facts(model) -> PushEnvFacts:
+def env_facts(env_name: str, model) -> EnvFacts:
     m = model
-    spec = ENV_SPECS["SawyerPushObstacle-v0"]
+    spec = ENV_SPECS[env_name]
+    kind = ENV_KIND[env_name]
 
     def site(name):
         i = m.site_name2id(name)
         return int(m.site_body[i]), np.asarray(m.site_pos[i], dtype=np.float64).copy()
 
-    eb, eo = site("grip_site")
-    rb, ro = site("right_eef")
-    lb, lo = site("left_eef")
+    def body(name):
+        return m.body_names.index(name), np.zeros(3)
+
+    def cgeom(name):          # index among the collidable geoms
+        return int(np.where(m.geom_mjid == m.geom_name2id(name))[0][0])
+
+    frames = [site("grip_site")]
+    quats = [m.body_names.index("right_ee_attchment")]
+    touch, n_left, jitter = [], 0, []
+    if kind == KIND_PUSH:
+        frames += [site("right_eef"), site("left_eef"), body("cube"), body("target")]
+        quats.append(m.body_names.index("cube"))
+        jitter = [m.get_joint_qpos_addr(j) for j in ("target_x", "target_y")]
+    elif kind == KIND_LIFT:
+        frames += [body("cube"), body("bin1")]
+        quats.append(m.body_names.index("cube"))
+        left = ["l_finger_g0", "l_finger_g1", "l_fingertip_g0"]          # sawyer_lift_obstacle.py:42-48
+        right = ["r_finger_g0", "r_finger_g1", "r_fingertip_g0"]
+        touch = [cgeom("cube")] + [cgeom(g) for g in left] + [cgeom(g) for g in right]
+        n_left = len(left)
+    else:
+        frames += [site("hole"), site("hole_bottom"), site("pegHead"), site("pegEnd")]
+        quats.append(m.body_names.index("peg"))
+    arm = np.array([m.get_joint_qpos_addr(j) for j in spec.robot_joints], dtype=np.int32)
+    # position actuators in ctrl order; the reference writes `desired_state` (+ Lift: the two gripper targets) into ctrl
+    act_adr = np.array([m.jnt_qposadr[j] for j in m.act_joint], dtype=np.int32)
+    n_act = len(arm) + (2 if kind == KIND_LIFT else 0)
+    if len(act_adr) < n_act or list(act_adr[:len(arm)]) != list(arm):
+        raise _lib.MopaError(f"{env_name}: the model's actuators do not start with the arm's position servos")
+    lim = m.act_ctrllimited[:n_act] == 1
     jidx, jlo, jhi, jlim = qpos_joint_arrays(m)
-    return PushEnvFacts(
-        arm_qpos_idx=np.array([m.get_joint_qpos_addr(j) for j in spec.robot_joints], dtype=np.int32),
+    return EnvFacts(
+        kind=kind, arm_qpos_idx=arm,
         grip_qpos_idx=np.array([m.get_joint_qpos_addr(j) for j in ("rc_close", "lc_close")], dtype=np.int32),
-        target_qpos_idx=np.array([m.get_joint_qpos_addr(j) for j in ("target_x", "target_y")], dtype=np.int32),
-        eef_body=eb, eef_off=eo, rfinger_body=rb, rfinger_off=ro, lfinger_body=lb, lfinger_off=lo,
-        ee_quat_body=m.body_names.index("right_ee_attchment"), cube_body=m.body_names.index("cube"),
-        target_body=m.body_names.index("target"),
-        qpos_min=jlo[jidx].astype(np.float64), qpos_max=jhi[jidx].astype(np.float64),
-        qpos_limited=jlim[jidx].astype(np.int32))
+        act_qpos_idx=act_adr[:n_act], act_lo=np.where(lim, m.act_ctrlrange[:n_act, 0], -np.inf),
+        act_hi=np.where(lim, m.act_ctrlrange[:n_act, 1], np.inf),
+        frame_body=np.array([f[0] for f in frames], dtype=np.int32), frame_off=np.array([f[1] for f in frames], dtype=np.float64),
+        quat_body=np.array(quats, dtype=np.int32), touch_geom=np.array(touch, dtype=np.int32), n_touch_left=n_left,
+        qpos_min=jlo[jidx].astype(np.float64), qpos_max=jhi[jidx].astype(np.float64), qpos_limited=jlim[jidx].astype(np.int32),
+        reset_jitter_idx=np.array(jitter, dtype=np.int64))
 
 
-class BatchKinematicPushEnv:
-    """E SawyerPushObstacle envs stepped kinematically on one GPU."""
+def push_env_facts(model) -> EnvFacts:
+    return env_facts("SawyerPushObstacle-v0", model)
 
-    env_name = "SawyerPushObstacle-v0"
 
-    def __init__(self, num_envs: int, device=None, seed: int = 0, max_episode_steps: int = 250,
+class BatchKinematicEnv:
+    """E envs of one of the three Sawyer obstacle tasks, stepped kinematically on one GPU."""
+
+    def __init__(self, env_name: str, num_envs: int, device=None, seed: int = 0, max_episode_steps: int = 250,
                  distance_threshold: float = 0.06, success_reward: float = 150.0, ac_scale: Optional[float] = None,
                  block_invalid: bool = False, model=None):
         torch = _torch()
+        if env_name not in ENV_KIND:
+            raise _lib.MopaError(f"no batched kinematic env for {env_name!r}")
         if not torch.cuda.is_available():
-            raise _lib.MopaError("BatchKinematicPushEnv needs a HIP device (there is no CPU fallback)")
+            raise _lib.MopaError("BatchKinematicEnv needs a HIP device (there is no CPU fallback)")
+        self.env_name = env_name
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
-        self.spec = ENV_SPECS[self.env_name]
+        self.spec = ENV_SPECS[env_name]
         self.model = model if model is not None else load_scene(self.spec.scene)
-        self.facts = push_env_facts(self.model)
+        self.facts = f = env_facts(env_name, self.model)
+        self.kind = f.kind
         self.E = int(num_envs)
         self.nq = self.model.nq
-        self.n_arm = len(self.facts.arm_qpos_idx)
+        self.n_arm = len(f.arm_qpos_idx)
+        self.action_dim, self.obs_dim = f.action_dim, f.obs_dim
+        self.obs_layout = OBS_LAYOUTS[f.kind]
         self.max_episode_steps = int(max_episode_steps)
         self.ac_scale = float(self.spec.ac_scale if ac_scale is None else ac_scale)
         L = _lib.lib()
-        f = self.facts
         keep = []
         desc = _lib.MopaEnvDesc()
         desc.model = _lib.model_struct(self.model, keep)
@@ -111,12 +182,13 @@ class BatchKinematicPushEnv:
         def dp(a):
             a, p = _lib._d(a); keep.append(a); return p
 
+        desc.kind = f.kind
         desc.n_arm, desc.arm_qpos_idx = self.n_arm, ip(f.arm_qpos_idx)
         desc.n_grip, desc.grip_qpos_idx = len(f.grip_qpos_idx), ip(f.grip_qpos_idx)
-        desc.eef_body, desc.eef_off = f.eef_body, (C.c_double * 3)(*f.eef_off)
-        desc.rfinger_body, desc.rfinger_off = f.rfinger_body, (C.c_double * 3)(*f.rfinger_off)
-        desc.lfinger_body, desc.lfinger_off = f.lfinger_body, (C.c_double * 3)(*f.lfinger_off)
-        desc.ee_quat_body, desc.cube_body, desc.target_body = f.ee_quat_body, f.cube_body, f.target_body
+        desc.n_act, desc.act_qpos_idx, desc.act_ctrl_lo, desc.act_ctrl_hi = len(f.act_qpos_idx), ip(f.act_qpos_idx), dp(f.act_lo), dp(f.act_hi)
+        desc.n_frames, desc.frame_body, desc.frame_off = len(f.frame_body), ip(f.frame_body), dp(f.frame_off)
+        desc.n_quats, desc.quat_body = len(f.quat_body), ip(f.quat_body)
+        desc.n_touch, desc.touch_geom, desc.n_touch_left = len(f.touch_geom), ip(f.touch_geom), int(f.n_touch_left)
         desc.qpos_min, desc.qpos_max, desc.qpos_limited = dp(f.qpos_min), dp(f.qpos_max), ip(f.qpos_limited)
         desc.ac_scale = self.ac_scale
         desc.distance_threshold = float(distance_threshold)
@@ -126,13 +198,14 @@ class BatchKinematicPushEnv:
         h = C.c_void_p()
         _lib.check(L.mopa_env_create(C.byref(desc), C.byref(h)))
         self._h = h
+        assert L.mopa_env_obs_dim(h) == self.obs_dim and L.mopa_env_action_dim(h) == self.action_dim
 
         dev, f64 = self.device, torch.float64
         self.qpos = torch.zeros(self.E, self.nq, dtype=f64, device=dev)
         self.prev_state = torch.zeros(self.E, self.n_arm, dtype=f64, device=dev)
         self.has_prev = torch.zeros(self.E, dtype=torch.uint8, device=dev)
         self.ep_len = torch.zeros(self.E, dtype=torch.int32, device=dev)
-        self.obs = torch.zeros(self.E, OBS_DIM, dtype=f64, device=dev)
+        self.obs = torch.zeros(self.E, self.obs_dim, dtype=f64, device=dev)
         self.reward = torch.zeros(self.E, dtype=f64, device=dev)
         self.done = torch.zeros(self.E, dtype=torch.uint8, device=dev)
         self.success = torch.zeros(self.E, dtype=torch.uint8, device=dev)
@@ -141,7 +214,7 @@ class BatchKinematicPushEnv:
         self._qpos0 = torch.tensor(self.model.qpos0, dtype=f64, device=dev)
         self._init_arm = torch.tensor(self.spec.init_qpos, dtype=f64, device=dev)
         self._arm_idx = torch.tensor(f.arm_qpos_idx, dtype=torch.long, device=dev)
-        self._target_idx = torch.tensor(f.target_qpos_idx, dtype=torch.long, device=dev)
+        self._jitter_idx = torch.tensor(f.reset_jitter_idx, dtype=torch.long, device=dev)
         self._planner = None
         self._scene = None
         self._desired = torch.zeros(self.E, self.n_arm, dtype=f64, device=dev)
@@ -173,28 +246,34 @@ class BatchKinematicPushEnv:
             _ptr(move_mask) if move_mask is not None else None, _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
             _ptr(self.success), _stream_handle(stream)))
 
-    def exec_trajectories(self, traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec=None, stream=None):
+    def exec_trajectories(self, traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec=None, last_extra=None, stream=None):
         """Waypoint execution of the rollout (rl/mopa_rollouts.py:152-199) in one launch: env e steps through
         traj[e, :path_len[e]] ([E, L, nq] f64, [E] int64) until its path ends or a step reports done; smdp_rew [E] f64,
-        smdp_done [E] uint8 and intra [E] int64 are updated in place (disc_pow [L] f64 = discount^k).  rec: optional dict
-        with 'ob' [E,L,40] f64, 'meta_rew' [E,L] f64, 'done' [E,L] uint8, 'n_exec' [E] int64 filled per executed waypoint."""
+        smdp_done [E] uint8 and intra [E] int64 are updated in place (disc_pow [L] f64 = discount^k).  last_extra [E] f64
+        (envs with more action entries than arm joints, i.e. Lift): the policy's gripper action, applied at the LAST
+        waypoint of a path (:163-167); the other waypoints carry `form_action`'s gripper difference.  rec: optional dict
+        with 'ob' [E,L,obs_dim] f64, 'meta_rew' [E,L] f64, 'done' [E,L] uint8, 'n_exec' [E] int64 filled per executed waypoint."""
         L = int(traj.shape[1])
         r = rec or {}
         p = lambda k: _ptr(r[k]) if k in r else None
+        if self.action_dim > self.n_arm and last_extra is None:
+            raise _lib.MopaError("this env needs last_extra (the gripper action of the last waypoint)")
         _lib.check(_lib.lib().mopa_env_exec_batch(
             self._h, self.E, _ptr(self.qpos), _ptr(self.prev_state), _ptr(self.has_prev), _ptr(self.ep_len), _ptr(traj),
-            _ptr(path_len), L, _ptr(disc_pow), _ptr(self.obs), _ptr(self.reward), _ptr(self.done), _ptr(self.success),
-            _ptr(smdp_rew), _ptr(smdp_done), _ptr(intra), p("ob"), p("meta_rew"), p("done"), p("n_exec"), _stream_handle(stream)))
+            _ptr(path_len), L, _ptr(disc_pow), _ptr(last_extra) if last_extra is not None else None, _ptr(self.obs), _ptr(self.reward),
+            _ptr(self.done), _ptr(self.success), _ptr(smdp_rew), _ptr(smdp_done), _ptr(intra), p("ob"), p("meta_rew"), p("done"),
+            p("n_exec"), _stream_handle(stream)))
 
     # ------------------------------------------------------------------
     def reset(self, mask=None):
-        """`_reset` of the reference (sawyer_push_obstacle.py:36-52): arm = init_qpos + N(0, 0.02^2), target sliders
-        += U(-0.01, 0.01); everything else qpos0.  `mask` (bool/uint8 [E]) resets only those envs."""
+        """`_reset` of the reference envs: arm = init_qpos + N(0, 0.02^2) (+ push: target sliders += U(-0.01, 0.01),
+        sawyer_push_obstacle.py:36-52); everything else qpos0.  `mask` (bool/uint8 [E]) resets only those envs."""
         torch = _torch()
         E, dev = self.E, self.device
         q = self._qpos0.expand(E, self.nq).clone()
         q[:, self._arm_idx] = self._init_arm + 0.02 * torch.randn(E, self.n_arm, dtype=torch.float64, device=dev, generator=self._gen)
-        q[:, self._target_idx] += (torch.rand(E, 2, dtype=torch.float64, device=dev, generator=self._gen) * 0.02 - 0.01)
+        if len(self._jitter_idx):
+            q[:, self._jitter_idx] += (torch.rand(E, len(self._jitter_idx), dtype=torch.float64, device=dev, generator=self._gen) * 0.02 - 0.01)
         if mask is None:
             self.qpos.copy_(q)
             self.has_prev.zero_()
@@ -216,12 +295,13 @@ class BatchKinematicPushEnv:
         return self.obs
 
     def step(self, action, is_planner: bool = False, stream=None):
-        """`env.step(action, is_planner)` for all E envs.  action: float64 [E, 7] on the GPU.
-        Returns (obs [E,40], reward [E], done [E] uint8, info) -- tensors are the env's own buffers (overwritten by the
-        next step).  info: success [E] uint8, episode_length [E], and `blocked` [E] with block_invalid."""
+        """`env.step(action, is_planner)` for all E envs.  action: float64 [E, action_dim] on the GPU (7 arm entries; Lift:
+        + the gripper entry).  Returns (obs [E, obs_dim], reward [E], done [E] uint8, info) -- tensors are the env's own
+        buffers (overwritten by the next step).  info: success [E] uint8, episode_length [E], and `blocked` [E] with
+        block_invalid."""
         torch = _torch()
-        if action.dtype != torch.float64 or not action.is_cuda or not action.is_contiguous() or tuple(action.shape) != (self.E, self.n_arm):
-            raise _lib.MopaError(f"action must be a contiguous float64 GPU tensor of shape [{self.E}, {self.n_arm}]")
+        if action.dtype != torch.float64 or not action.is_cuda or not action.is_contiguous() or tuple(action.shape) != (self.E, self.action_dim):
+            raise _lib.MopaError(f"action must be a contiguous float64 GPU tensor of shape [{self.E}, {self.action_dim}]")
         info = {}
         move = None
         if self._planner is not None:
@@ -241,29 +321,35 @@ class BatchKinematicPushEnv:
         """The reference's OrderedDict view of an obs tensor (`_get_obs`)."""
         o = self.obs if obs is None else obs
         out, k = OrderedDict(), 0
-        for name, n in OBS_LAYOUT.items():
+        for name, n in self.obs_layout.items():
             out[name] = o[..., k:k + n]
             k += n
         return out
 
 
-def make_env(env_name: str, num_envs: int, **kwargs):
+class BatchKinematicPushEnv(BatchKinematicEnv):
+    """E SawyerPushObstacle envs (the first of the three; kept under its own name)."""
+    env_name = "SawyerPushObstacle-v0"
+
+    def __init__(self, num_envs: int, **kwargs):
+        super().__init__(self.env_name, num_envs, **kwargs)
+
+
+def make_env(env_name: str, num_envs: int, **kwargs) -> BatchKinematicEnv:
     """Batched kinematic env by the reference's gym id (`gym.make(config.env, ...)`, rl/trainer.py:49)."""
-    if env_name == BatchKinematicPushEnv.env_name:
-        return BatchKinematicPushEnv(num_envs, **kwargs)
-    raise _lib.MopaError(f"no batched kinematic env for {env_name!r}")
+    return BatchKinematicEnv(env_name, num_envs, **kwargs)
 
 
-class SawyerPushObstacleKinematicEnv:
+class SawyerKinematicEnv:
     """Single-env facade with the reference call shapes: `reset() -> ob`, `step(action, is_planner=False) ->
     (ob, reward, done, info)` with `ob` an OrderedDict of numpy arrays (env/base.py:229-246)."""
 
-    def __init__(self, **kwargs):
-        self._b = BatchKinematicPushEnv(1, **kwargs)
+    def __init__(self, env_name: str = "SawyerPushObstacle-v0", **kwargs):
+        self._b = BatchKinematicEnv(env_name, 1, **kwargs)
 
     @property
     def dof(self):
-        return 7
+        return self._b.action_dim
 
     @property
     def sim_qpos(self):
@@ -284,3 +370,8 @@ class SawyerPushObstacleKinematicEnv:
         _, r, d, info = self._b.step(a.contiguous(), is_planner)
         return self._ob(), float(r[0]), bool(d[0]), {"episode_success": int(info["success"][0]),
                                                      "episode_length": int(info["episode_length"][0])}
+
+
+class SawyerPushObstacleKinematicEnv(SawyerKinematicEnv):
+    def __init__(self, **kwargs):
+        super().__init__("SawyerPushObstacle-v0", **kwargs)

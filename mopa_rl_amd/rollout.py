@@ -9,8 +9,9 @@ then densification of the planner path) and executed waypoint by waypoint with `
 the SMDP reward `sum_i gamma^i r_i` and `intra_steps` are accumulated (:152-199); a failed plan costs one env step with
 the current reward (:303-334).  Counters `mp / rl / interpolation / mp_fail / approximate / invalid` are kept per env.
 
-Restrictions (each raises): joint-space MoPA-SAC only (`use_ik_target=False`, `discrete_action=False`), Sawyer push
-(no unlimited joints, 7-dof actions).  The `reuse_data` relabelling (:204-300) -- extra transitions between random
+Restrictions (each raises): joint-space MoPA-SAC only (`use_ik_target=False`, `discrete_action=False`), the three Sawyer
+obstacle envs (no unlimited joints; 7 arm entries per action, Lift adds the gripper entry, which a planner step applies at
+the last waypoint of its path, :163-167).  The `reuse_data` relabelling (:204-300) -- extra transitions between random
 pairs of waypoints of an executed path -- is `reuse_transitions()` below, fed by `agent_step(..., record=True)`.
 The env is the KINEMATIC one (kinematic_env.py) -- not dynamics parity.
 
@@ -258,8 +259,8 @@ class BatchMoPARollout:
 
     # ------------------------------------------------------------------
     def agent_step(self, ac, record: bool = False):
-        """One agent step for all E envs.  ac: float64 [E, >=7] GPU tensor (policy output in [-1, 1]).
-        Returns a dict of GPU tensors: ob [E,40] (before), ob_next [E,40], rew [E] (SMDP return of the step), done [E]
+        """One agent step for all E envs.  ac: float64 [E, >= env.action_dim] GPU tensor (policy output in [-1, 1]).
+        Returns a dict of GPU tensors: ob [E,obs_dim] (before), ob_next [E,obs_dim], rew [E] (SMDP return of the step), done [E]
         uint8, intra_steps [E] int64, is_planner [E] bool, success [E] bool (env success flag), plus `path_len`.
         record=True adds `record`: per executed waypoint k the obs after it, the running SMDP return, the done flag and
         the waypoint itself ([E, L, ...]; `n_exec` [E] = waypoints actually executed) -- the `ob_list / meta_rew_list /
@@ -326,7 +327,10 @@ class BatchMoPARollout:
         direct = ~is_pl
         self.counters["rl"][direct] += 1
         # ---- direct execution (:336-356) and failed plans (:303-334: reward of the current state, one env step) in one launch
-        act0 = torch.where(direct[:, None], a / torch.full_like(a, cfg.omega), torch.zeros_like(a)).contiguous()
+        act0 = torch.where(direct[:, None], a / torch.full_like(a, cfg.omega), torch.zeros_like(a))
+        if env.action_dim > n:          # Lift: the gripper entry is passed through unscaled (:340-343)
+            act0 = torch.cat([act0, torch.where(direct[:, None], ac[:, n:env.action_dim], torch.zeros_like(ac[:, n:env.action_dim]))], dim=1)
+        act0 = act0.contiguous()
         flags = torch.where(direct, 1, torch.where(plan_ok, 2, 0)).to(torch.uint8).contiguous()
         env._launch(act0, False, flags)
         rew = torch.where(plan_ok, torch.zeros_like(env.reward), env.reward)
@@ -347,7 +351,8 @@ class BatchMoPARollout:
             disc = torch.tensor([cfg.discount_factor ** k for k in range(L)], dtype=torch.float64, device=dev)
             rew, done = rew.contiguous(), done.to(torch.uint8).contiguous()
             env.exec_trajectories(traj_pad, torch.where(plan_ok, path_len, torch.zeros_like(path_len)).contiguous(), disc,
-                                  rew, done, intra, rec={k: rec[k] for k in ("ob", "meta_rew", "done", "n_exec")} if rec else None)
+                                  rew, done, intra, rec={k: rec[k] for k in ("ob", "meta_rew", "done", "n_exec")} if rec else None,
+                                  last_extra=ac[:, n].contiguous() if env.action_dim > n else None)
         mark("execute")
         env.has_prev.zero_()                                     # env._reset_prev_state()
         self.t += 1

@@ -1424,38 +1424,75 @@ done:
 }
 
 /* ------------------------------------------------------------------ */
-/*  kinematic env.step of SawyerPushObstacleEnv       */
+/*  kinematic env.step of the Sawyer obstacle envs */
 /* ------------------------------------------------------------------ */
-/* Restates the arithmetic AROUND the physics of the reference env:
- *   _step          env/sawyer/sawyer_push_obstacle.py:162-208 (action scaling, desired_state, prev_state)
+/* Restates the arithmetic AROUND the physics of the reference envs (kind 0 = SawyerPushObstacle, 1 = SawyerLiftObstacle,
+ * 2 = SawyerAssemblyObstacle):
+ *   _step          env/sawyer/sawyer_{push,lift,assembly}_obstacle.py `_step` (action scaling, desired_state, prev_state;
+ *                  Lift: gripper target = gripper qpos + action[-1], sawyer.py:340-342)
  *   _after_step    env/base.py:269-314 (joint-limit clamp, episode length, terminal)
- *   compute_reward env/sawyer/sawyer_push_obstacle.py:71-104
- *   _get_obs       env/sawyer/sawyer.py:317-338 + sawyer_push_obstacle.py:106-119 (dict order)
- * with `_do_simulation` (MuJoCo position servo, 75 sub-steps) replaced by its kinematic limit: the arm reaches
- * desired_state, velocities are 0, nothing else moves.  NOT dynamics parity.  One deliberate re-ordering: the
- * joint-limit clamp is applied BEFORE obs/reward (in the reference MuJoCo's limit constraint acts inside the
- * physics, and the explicit clamp of _after_step runs after the obs was taken). */
+ *   compute_reward sawyer_push_obstacle.py:71-104, sawyer_lift_obstacle.py:93-150, sawyer_assembly_obstacle.py:33-52
+ *   _get_obs       env/sawyer/sawyer.py:317-338 + the env's own `_get_obs` (dict order)
+ * with `_do_simulation` (MuJoCo position servos, 75 sub-steps) replaced by its kinematic limit: every actuated joint
+ * reaches its target clamped to the actuator's ctrlrange, velocities are 0, nothing else moves.  NOT dynamics parity.
+ * One deliberate re-ordering: the joint-limit clamp is applied BEFORE obs/reward (in the reference MuJoCo's limit
+ * constraint acts inside the physics, and the explicit clamp of _after_step runs after the obs was taken).
+ * Lift's grasp test (`has_grasp`: a contact between the can and a left-finger geom AND one with a right-finger geom) is
+ * evaluated on the posed geoms: bounding-sphere cull, then the narrow phase; "contact" = the shapes intersect. */
 static inline void frame_pos(double *out, const double *xpos, const double *xmat, int b, const double *off) {
     double v[3];
     mat_vec(v, xmat + 9 * b, off);
     add3(out, xpos + 3 * b, v);
 }
 
+static int env_touch(const OrcScene *s, int g_obj, int g_fin, const double *xpos, const double *xquat, const double *xmat) {
+    /* geoms ordered by type for the narrow phase (MuJoCo orders a contact's geoms by type) */
+    int g1 = g_fin, g2 = g_obj;
+    if (s->geom_type[g1] > s->geom_type[g2]) { g1 = g_obj; g2 = g_fin; }
+    double gp[2][3], gm[2][9], q[4], v[3];
+    const int gs[2] = { g1, g2 };
+    for (int k = 0; k < 2; k++) {
+        const int g = gs[k], b = s->geom_body[g];
+        mat_vec(v, xmat + 9 * b, s->geom_pos + 3 * g);
+        add3(gp[k], xpos + 3 * b, v);
+        quat_mul(q, xquat + 4 * b, s->geom_quat + 4 * g);
+        quat2mat(gm[k], q);
+    }
+    double diff[3];
+    sub3(diff, gp[1], gp[0]);
+    const double rs = s->geom_rbound[g1] + s->geom_rbound[g2];
+    if (dot3(diff, diff) > rs * rs) return 0;
+    Geom A = { s->geom_type[g1], s->geom_size + 3 * g1, gp[0], gm[0], NULL, 0 }, B = { s->geom_type[g2], s->geom_size + 3 * g2, gp[1], gm[1], NULL, 0 };
+    if (s->geom_dataid && s->geom_dataid[g1] >= 0) { A.verts = s->mesh_vert + 3 * s->mesh_vertadr[s->geom_dataid[g1]]; A.nvert = s->mesh_vertnum[s->geom_dataid[g1]]; }
+    if (s->geom_dataid && s->geom_dataid[g2] >= 0) { B.verts = s->mesh_vert + 3 * s->mesh_vertadr[s->geom_dataid[g2]]; B.nvert = s->mesh_vertnum[s->geom_dataid[g2]]; }
+    return geom_dist(&A, &B) < 0.0;
+}
+
+int orc_env_obs_dim(const OrcEnvDesc *d) {
+    const int base = 2 * d->n_arm + 2 * d->n_grip + 7;
+    return base + (d->kind == 0 ? 15 : (d->kind == 1 ? 10 : 13));
+}
+int orc_env_action_dim(const OrcEnvDesc *d) { return d->n_arm + (d->kind == 1 ? 1 : 0); }
+
 void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *prev_state, uint8_t *has_prev,
                   int32_t *ep_len, const double *action, int is_planner, int move, double *obs, double *reward,
                   uint8_t *done, uint8_t *success) {
     const int na = d->n_arm;
-    if (action && (move & 2)) return;   /* flags: bit 0 = arm moves, bit 1 = env sits this step out */
+    if (action && (move & 2)) return;   /* flags: bit 0 = the actuated joints move, bit 1 = env sits this step out */
     move &= 1;
     if (action) {
+        double ctrl[16];
         for (int j = 0; j < na; j++) {
             const int adr = d->arm_qpos_idx[j];
             const double prev = (is_planner && *has_prev) ? prev_state[j] : qpos[adr];
             const double a = is_planner ? action[j] : action[j] * d->ac_scale;
             const double desired = prev + clampd(a, -d->ac_scale, d->ac_scale);
-            if (move) qpos[adr] = desired;
+            ctrl[j] = desired;
             prev_state[j] = desired;
         }
+        for (int k = na; k < d->n_act; k++) ctrl[k] = qpos[d->act_qpos_idx[k]] + action[na];   /* Lift: gripper_state + action[-1] */
+        if (move)
+            for (int k = 0; k < d->n_act; k++) qpos[d->act_qpos_idx[k]] = clampd(ctrl[k], d->act_lo[k], d->act_hi[k]);
         *has_prev = 1;
         for (int i = 0; i < s->nq; i++)
             if (d->qpos_limited[i]) qpos[i] = clampd(qpos[i], d->qpos_min[i], d->qpos_max[i]);
@@ -1463,29 +1500,12 @@ void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *
     double *buf = (double *)malloc(sizeof(double) * 16 * s->nbody);
     double *xpos = buf, *xquat = buf + 3 * s->nbody, *xmat = buf + 7 * s->nbody;
     fk_bodies(s, qpos, xpos, xquat, xmat, 0);
-    double eef[3], rf[3], lf[3], grip[3], g2c[3];
-    frame_pos(eef, xpos, xmat, d->eef_body, d->eef_off);
-    frame_pos(rf, xpos, xmat, d->rfinger_body, d->rfinger_off);
-    frame_pos(lf, xpos, xmat, d->lfinger_body, d->lfinger_off);
-    const double *cube = xpos + 3 * d->cube_body, *target = xpos + 3 * d->target_body;
-    const double *cq = xquat + 4 * d->cube_body, *eq = xquat + 4 * d->ee_quat_body;
-    for (int i = 0; i < 3; i++) grip[i] = (rf[i] + lf[i]) / 2.0;
-    sub3(g2c, cube, grip);
-    const double gripper_to_cube = norm3(g2c);
-    const double c2t0 = cube[0] - target[0], c2t1 = cube[1] - target[1];
-    const double cube_to_target = sqrt(fma(c2t1, c2t1, c2t0 * c2t0));
-    if (action) {
-        double reward_reach = 0.0, reward_push = 0.0;
-        if (gripper_to_cube < 0.1) reward_reach = 0.1 * (1.0 - orc_tanh_pos(10.0 * gripper_to_cube));
-        if (cube_to_target < 0.1) reward_push = 0.5 * (1.0 - orc_tanh_pos(5.0 * cube_to_target));
-        double r = reward_push + reward_reach;
-        int succ = 0;
-        if (cube_to_target < d->distance_threshold) { r += d->success_reward; succ = 1; }
-        *ep_len += 1;
-        *reward = r;
-        *success = (uint8_t)succ;
-        *done = (uint8_t)(succ || *ep_len == d->max_episode_steps);
-    }
+    double P[8][3];
+    for (int f = 0; f < d->n_frames; f++) frame_pos(P[f], xpos, xmat, d->frame_body[f], d->frame_off + 3 * f);
+    const double *eef = P[0];
+    const double *eq = xquat + 4 * d->quat_body[0], *oq = xquat + 4 * d->quat_body[1];
+    double r = 0.0;
+    int succ = 0;
     int o = 0;
     for (int j = 0; j < na; j++) obs[o++] = qpos[d->arm_qpos_idx[j]];          /* joint_pos */
     for (int j = 0; j < na; j++) obs[o++] = 0.0;                               /* joint_vel */
@@ -1493,11 +1513,70 @@ void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *
     for (int j = 0; j < d->n_grip; j++) obs[o++] = 0.0;                        /* gripper_qvel */
     for (int i = 0; i < 3; i++) obs[o++] = eef[i];                             /* eef_pos */
     obs[o++] = eq[1]; obs[o++] = eq[2]; obs[o++] = eq[3]; obs[o++] = eq[0];    /* eef_quat, xyzw */
-    for (int i = 0; i < 3; i++) obs[o++] = target[i];                          /* target_pos */
-    for (int i = 0; i < 3; i++) obs[o++] = cube[i];                            /* cube_pos */
-    obs[o++] = cq[1]; obs[o++] = cq[2]; obs[o++] = cq[3]; obs[o++] = cq[0];    /* cube_quat, xyzw */
-    for (int i = 0; i < 3; i++) obs[o++] = eef[i] - cube[i];                   /* gripper_to_cube */
-    obs[o++] = c2t0; obs[o++] = c2t1;                                          /* cube_to_target */
+    if (d->kind == 0) {
+        /* frames: 1 right_eef, 2 left_eef, 3 cube, 4 target */
+        const double *rf = P[1], *lf = P[2], *cube = P[3], *target = P[4];
+        double grip[3], g2c[3];
+        for (int i = 0; i < 3; i++) grip[i] = (rf[i] + lf[i]) / 2.0;
+        sub3(g2c, cube, grip);
+        const double gripper_to_cube = norm3(g2c);
+        const double c2t0 = cube[0] - target[0], c2t1 = cube[1] - target[1];
+        const double cube_to_target = sqrt(fma(c2t1, c2t1, c2t0 * c2t0));
+        double reward_reach = 0.0, reward_push = 0.0;
+        if (gripper_to_cube < 0.1) reward_reach = 0.1 * (1.0 - orc_tanh_pos(10.0 * gripper_to_cube));
+        if (cube_to_target < 0.1) reward_push = 0.5 * (1.0 - orc_tanh_pos(5.0 * cube_to_target));
+        r = reward_push + reward_reach;
+        if (cube_to_target < d->distance_threshold) { r += d->success_reward; succ = 1; }
+        for (int i = 0; i < 3; i++) obs[o++] = target[i];                          /* target_pos */
+        for (int i = 0; i < 3; i++) obs[o++] = cube[i];                            /* cube_pos */
+        obs[o++] = oq[1]; obs[o++] = oq[2]; obs[o++] = oq[3]; obs[o++] = oq[0];    /* cube_quat, xyzw */
+        for (int i = 0; i < 3; i++) obs[o++] = eef[i] - cube[i];                   /* gripper_to_cube */
+        obs[o++] = c2t0; obs[o++] = c2t1;                                          /* cube_to_target */
+    } else if (d->kind == 1) {
+        /* frames: 1 cube (the can), 2 bin1 */
+        const double *cube = P[1], *bin = P[2];
+        double g2c[3];
+        sub3(g2c, cube, eef);
+        const double reward_reach = (1.0 - orc_tanh_pos(10.0 * norm3(g2c))) * 0.1;
+        int touch_l = 0, touch_r = 0;
+        if (action) {
+            for (int k = 1; k < d->n_touch; k++) {
+                const int hit = env_touch(s, d->touch_geom[0], d->touch_geom[k], xpos, xquat, xmat);
+                if (k <= d->n_touch_left) touch_l |= hit; else touch_r |= hit;
+            }
+        }
+        const double reward_grasp = (touch_l && touch_r) ? 0.35 : 0.0;
+        double reward_lift = 0.0;
+        const double z_target = bin[2] + 0.45;
+        if (reward_grasp > 0.0) {
+            const double z_dist = dmax(z_target - cube[2], 0.0);
+            reward_lift = 0.35 + (1.0 - orc_tanh_pos(15.0 * z_dist)) * (0.5 - 0.35);
+        }
+        r = dmax(dmax(reward_reach, reward_grasp), reward_lift);
+        if (reward_grasp > 0.0 && fabs(cube[2] - z_target) < 0.05) { r += d->success_reward; succ = 1; }
+        for (int i = 0; i < 3; i++) obs[o++] = cube[i];                            /* cube_pos */
+        obs[o++] = oq[1]; obs[o++] = oq[2]; obs[o++] = oq[3]; obs[o++] = oq[0];    /* cube_quat, xyzw */
+        for (int i = 0; i < 3; i++) obs[o++] = eef[i] - cube[i];                   /* gripper_to_cube */
+    } else {
+        /* frames: 1 hole, 2 hole_bottom, 3 pegHead, 4 pegEnd; quat 1 = body "peg" (wxyz, as _get_quat returns it) */
+        const double *hole = P[1], *bottom = P[2], *head = P[3], *end = P[4];
+        double dh[3], db[3];
+        sub3(dh, head, hole);
+        sub3(db, head, bottom);
+        const double dist = norm3(dh), dist_bottom = norm3(db);
+        if (dist < 0.3) r = 0.4 * (1.0 - orc_tanh_pos(15.0 * dist));
+        if (dist_bottom < 0.025) { r += d->success_reward; succ = 1; }
+        for (int i = 0; i < 3; i++) obs[o++] = hole[i];
+        for (int i = 0; i < 3; i++) obs[o++] = head[i];
+        for (int i = 0; i < 3; i++) obs[o++] = end[i];
+        obs[o++] = oq[0]; obs[o++] = oq[1]; obs[o++] = oq[2]; obs[o++] = oq[3];
+    }
+    if (action) {
+        *ep_len += 1;
+        *reward = r;
+        *success = (uint8_t)succ;
+        *done = (uint8_t)(succ || *ep_len == d->max_episode_steps);
+    }
     free(buf);
 }
 
@@ -1505,13 +1584,14 @@ void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *
 void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, double *qpos, double *prev_state, uint8_t *has_prev,
                         int32_t *ep_len, const double *action, int is_planner, const uint8_t *move_mask, double *obs,
                         double *reward, uint8_t *done, uint8_t *success, int nthreads) {
+    const int od = orc_env_obs_dim(d), ad = orc_env_action_dim(d);
 #ifdef _OPENMP
     if (nthreads <= 0) nthreads = omp_get_max_threads();
 #pragma omp parallel for num_threads(nthreads) schedule(static)
 #endif
     for (int64_t e = 0; e < E; e++)
         orc_env_step(s, d, qpos + e * s->nq, prev_state + e * d->n_arm, has_prev + e, ep_len + e,
-                     action ? action + e * d->n_arm : NULL, is_planner, move_mask ? move_mask[e] : 1, obs + e * 40,
+                     action ? action + e * ad : NULL, is_planner, move_mask ? move_mask[e] : 1, obs + e * od,
                      reward + e, done + e, success + e);
 }
 

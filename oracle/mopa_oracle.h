@@ -97,23 +97,26 @@ int orc_plan(const OrcScene *s, const double *start /*[nq]*/, const double *goal
 double orc_exp(double x);
 double orc_tanh_pos(double x);
 
-/* (SURVEY 8f row 1) kinematic env.step restated -- see the comment on orc_env_step in mopa_oracle.c.
+/* (SURVEY 8f row 1 / N1) kinematic env.step restated -- see the comment on orc_env_step in mopa_oracle.c.
  * Same fields as MopaEnvDesc (include/mopa_hip.h) without the model. */
 typedef struct OrcEnvDesc {
+    int32_t kind;                                   /* 0 push, 1 lift, 2 assembly */
     int32_t n_arm; const int32_t *arm_qpos_idx;
     int32_t n_grip; const int32_t *grip_qpos_idx;
-    int32_t eef_body; double eef_off[3];
-    int32_t rfinger_body; double rfinger_off[3];
-    int32_t lfinger_body; double lfinger_off[3];
-    int32_t ee_quat_body, cube_body, target_body;
+    int32_t n_act; const int32_t *act_qpos_idx; const double *act_lo, *act_hi;   /* position actuators, ctrl order (arm first) */
+    int32_t n_frames; const int32_t *frame_body; const double *frame_off;        /* [n_frames], [n_frames,3] */
+    int32_t n_quats; const int32_t *quat_body;
+    int32_t n_touch; const int32_t *touch_geom; int32_t n_touch_left;            /* lift: [object, left-finger geoms..., right-finger geoms...] */
     const double *qpos_min, *qpos_max; const int32_t *qpos_limited;
     double ac_scale, distance_threshold, success_reward;
     int32_t max_episode_steps;
 } OrcEnvDesc;
+int orc_env_obs_dim(const OrcEnvDesc *d);
+int orc_env_action_dim(const OrcEnvDesc *d);
 /* one env, in place; action == NULL: obs only */
 void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos /*[nq]*/, double *prev_state /*[n_arm]*/,
-                  uint8_t *has_prev, int32_t *ep_len, const double *action /*[n_arm] or NULL*/, int is_planner, int move,
-                  double *obs /*[40]*/, double *reward, uint8_t *done, uint8_t *success);
+                  uint8_t *has_prev, int32_t *ep_len, const double *action /*[action_dim] or NULL*/, int is_planner, int move,
+                  double *obs /*[obs_dim]*/, double *reward, uint8_t *done, uint8_t *success);
 void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, double *qpos, double *prev_state, uint8_t *has_prev,
                         int32_t *ep_len, const double *action, int is_planner, const uint8_t *move_mask, double *obs,
                         double *reward, uint8_t *done, uint8_t *success, int nthreads);

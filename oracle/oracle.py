@@ -77,6 +77,10 @@ def lib():
         L.orc_env_step.restype = None
         L.orc_env_step.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), _dp, _dp, _u8p, _ip, _dp, C.c_int, C.c_int, _dp, _dp,
                                    _u8p, _u8p]
+        L.orc_env_obs_dim.restype = C.c_int
+        L.orc_env_obs_dim.argtypes = [C.POINTER(OrcEnvDesc)]
+        L.orc_env_action_dim.restype = C.c_int
+        L.orc_env_action_dim.argtypes = [C.POINTER(OrcEnvDesc)]
         L.orc_ik_solve.restype = None
         L.orc_ik_solve.argtypes = [C.c_void_p, C.c_int, _ip, C.c_int, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_int, C.c_double,
                                    C.c_double, C.c_double, C.c_double, _dp, _ip, _u8p]
@@ -101,10 +105,11 @@ def _i(a):
 
 class OrcEnvDesc(C.Structure):
     _fields_ = [
-        ("n_arm", C.c_int32), ("arm_qpos_idx", _ip), ("n_grip", C.c_int32), ("grip_qpos_idx", _ip),
-        ("eef_body", C.c_int32), ("eef_off", C.c_double * 3), ("rfinger_body", C.c_int32), ("rfinger_off", C.c_double * 3),
-        ("lfinger_body", C.c_int32), ("lfinger_off", C.c_double * 3), ("ee_quat_body", C.c_int32),
-        ("cube_body", C.c_int32), ("target_body", C.c_int32), ("qpos_min", _dp), ("qpos_max", _dp), ("qpos_limited", _ip),
+        ("kind", C.c_int32), ("n_arm", C.c_int32), ("arm_qpos_idx", _ip), ("n_grip", C.c_int32), ("grip_qpos_idx", _ip),
+        ("n_act", C.c_int32), ("act_qpos_idx", _ip), ("act_lo", _dp), ("act_hi", _dp),
+        ("n_frames", C.c_int32), ("frame_body", _ip), ("frame_off", _dp), ("n_quats", C.c_int32), ("quat_body", _ip),
+        ("n_touch", C.c_int32), ("touch_geom", _ip), ("n_touch_left", C.c_int32),
+        ("qpos_min", _dp), ("qpos_max", _dp), ("qpos_limited", _ip),
         ("ac_scale", C.c_double), ("distance_threshold", C.c_double), ("success_reward", C.c_double),
         ("max_episode_steps", C.c_int32),
     ]
@@ -122,9 +127,9 @@ def tanh_pos(x: float) -> float:
     return lib().orc_tanh_pos(float(x))
 
 
-class OraclePushEnv:
-    """E kinematic SawyerPushObstacle envs stepped one by one through orc_env_step (the checker of K4).
-    `facts` is mopa_rl_amd.kinematic_env.PushEnvFacts (plain name->id data, no product code runs here)."""
+class OracleEnv:
+    """E kinematic Sawyer envs (push / lift / assembly) stepped through orc_env_step (the checker of K4).
+    `facts` is mopa_rl_amd.kinematic_env.EnvFacts (plain name->id data, no product code runs here)."""
 
     def __init__(self, scene: "OracleScene", facts, E: int, ac_scale=0.05, distance_threshold=0.06, success_reward=150.0,
                  max_episode_steps=250):
@@ -138,22 +143,24 @@ class OraclePushEnv:
         def dp(a):
             a, p = _d(a); self._keep.append(a); return p
 
+        d.kind = int(facts.kind)
         d.n_arm, d.arm_qpos_idx = len(facts.arm_qpos_idx), ip(facts.arm_qpos_idx)
         d.n_grip, d.grip_qpos_idx = len(facts.grip_qpos_idx), ip(facts.grip_qpos_idx)
-        d.eef_body, d.eef_off = facts.eef_body, (C.c_double * 3)(*facts.eef_off)
-        d.rfinger_body, d.rfinger_off = facts.rfinger_body, (C.c_double * 3)(*facts.rfinger_off)
-        d.lfinger_body, d.lfinger_off = facts.lfinger_body, (C.c_double * 3)(*facts.lfinger_off)
-        d.ee_quat_body, d.cube_body, d.target_body = facts.ee_quat_body, facts.cube_body, facts.target_body
+        d.n_act, d.act_qpos_idx, d.act_lo, d.act_hi = len(facts.act_qpos_idx), ip(facts.act_qpos_idx), dp(facts.act_lo), dp(facts.act_hi)
+        d.n_frames, d.frame_body, d.frame_off = len(facts.frame_body), ip(facts.frame_body), dp(facts.frame_off)
+        d.n_quats, d.quat_body = len(facts.quat_body), ip(facts.quat_body)
+        d.n_touch, d.touch_geom, d.n_touch_left = len(facts.touch_geom), ip(facts.touch_geom), int(facts.n_touch_left)
         d.qpos_min, d.qpos_max, d.qpos_limited = dp(facts.qpos_min), dp(facts.qpos_max), ip(facts.qpos_limited)
         d.ac_scale, d.distance_threshold, d.success_reward = ac_scale, distance_threshold, success_reward
         d.max_episode_steps = max_episode_steps
         self.desc = d
         self.n_arm = d.n_arm
+        self.obs_dim, self.action_dim = lib().orc_env_obs_dim(C.byref(d)), lib().orc_env_action_dim(C.byref(d))
         self.qpos = np.zeros((self.E, self.nq))
         self.prev_state = np.zeros((self.E, self.n_arm))
         self.has_prev = np.zeros(self.E, dtype=np.uint8)
         self.ep_len = np.zeros(self.E, dtype=np.int32)
-        self.obs = np.zeros((self.E, 40))
+        self.obs = np.zeros((self.E, self.obs_dim))
         self.reward = np.zeros(self.E)
         self.done = np.zeros(self.E, dtype=np.uint8)
         self.success = np.zeros(self.E, dtype=np.uint8)
@@ -179,6 +186,7 @@ class OraclePushEnv:
 
     def step(self, action, is_planner=False, move_mask=None, nthreads: int = 1):
         action = np.ascontiguousarray(action, dtype=np.float64)
+        assert action.shape == (self.E, self.action_dim)
         mm = None if move_mask is None else np.ascontiguousarray(move_mask, dtype=np.uint8)
         lib().orc_env_step_batch(
             self.scene._h, C.byref(self.desc), self.E, self.qpos.ctypes.data_as(_dp), self.prev_state.ctypes.data_as(_dp),
@@ -186,6 +194,9 @@ class OraclePushEnv:
             mm.ctypes.data_as(_u8p) if mm is not None else None, self.obs.ctypes.data_as(_dp),
             self.reward.ctypes.data_as(_dp), self.done.ctypes.data_as(_u8p), self.success.ctypes.data_as(_u8p), int(nthreads))
         return self.obs, self.reward, self.done, self.success
+
+
+OraclePushEnv = OracleEnv      # earlier name
 
 
 def sincos(x: float) -> Tuple[float, float]:

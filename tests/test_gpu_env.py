@@ -82,6 +82,48 @@ def test_rollout_bit_identical_to_oracle(setup, oracle_mod, torch_mod, E):
         assert n_succ > 0 and (ref.reward > 0).any() and ref.done.any()      # the interesting branches were exercised
 
 
+@pytest.mark.parametrize("env_name,tag", [("SawyerLiftObstacle-v0", "lift"), ("SawyerAssemblyObstacle-v0", "assembly")])
+def test_lift_and_assembly_bit_identical_to_oracle(env_name, tag, oracle_mod, torch_mod):
+    """the other two env kinds (BASELINE configs 4 and 5): gripper command and grasp test of Lift, peg / hole frames of
+    Assembly, ctrlrange clamps -- obs, reward, flags and carried state equal the oracle's bit for bit; start states are random
+    arm poses plus the near-goal states of the reference-generated fixture (where the reward terms are live)"""
+    import os
+    from mopa_rl_amd.kinematic_env import env_facts, make_env
+    from mopa_rl_amd.scene import default_qpos, planner_inputs
+    torch = torch_mod
+    pi = planner_inputs(env_name)
+    f = env_facts(env_name, pi.model)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", f"ref_py_env_{tag}.npz"))
+    rng = np.random.default_rng(3)
+    E = 320
+    q = np.tile(default_qpos(env_name, pi.model), (E, 1))
+    q[:, f.arm_qpos_idx] = np.clip(q[:, f.arm_qpos_idx] + rng.normal(0, 0.3, size=(E, 7)), pi.jnt_minimum, pi.jnt_maximum)
+    near = np.concatenate([G["qpos0"], G["qpos_after"][np.arange(len(G["qpos0"])), G["n_steps"] // 2]])
+    q[: 8 * len(near)] = np.tile(near, (8, 1))
+    q[: 8 * len(near), :7] += rng.normal(0, 0.004, size=(8 * len(near), 7))
+    env = make_env(env_name, E, max_episode_steps=5)
+    ref = oracle_mod.OracleEnv(orc, f, E, ac_scale=pi.spec.ac_scale, max_episode_steps=5)
+    assert env.obs_dim == ref.obs_dim and env.action_dim == ref.action_dim == G["action"].shape[2]
+    env.set_state(torch.tensor(q, device=env.device))
+    ref.set_state(q)
+    _compare(env, ref, "after set_state")
+    live = n_done = 0
+    for t in range(7):
+        is_planner = bool(t % 3 == 1)
+        a = rng.uniform(-0.12, 0.12, size=(E, env.action_dim)) if is_planner else rng.uniform(-1.5, 1.5, size=(E, env.action_dim))
+        if env.action_dim == 8:
+            a[:, 7] = rng.choice([-1.0, 1.0, 0.003, -0.002], size=E)
+        obs, rew, done, info = env.step(torch.tensor(a, device=env.device), is_planner=is_planner)
+        ref.step(a, is_planner=is_planner)
+        _compare(env, ref, f"step {t}")
+        assert np.array_equal(_bits(rew.cpu().numpy()), _bits(ref.reward)), f"step {t}: reward"
+        assert np.array_equal(done.cpu().numpy(), ref.done) and np.array_equal(info["success"].cpu().numpy(), ref.success)
+        live += int((ref.reward > (0.3 if tag == "lift" else 0.0)).sum())
+        n_done += int(ref.done.sum())
+    assert live > 0 and n_done > 0          # grasp (lift) / reach (assembly) rewards occurred
+
+
 def test_move_mask_and_block_invalid(setup, oracle_mod, torch_mod):
     """block_invalid = K1 verdict of the desired state decides whether the arm moves; the result must equal the oracle
     env stepped with the oracle's own validity verdicts as move mask."""
@@ -100,7 +142,7 @@ def test_move_mask_and_block_invalid(setup, oracle_mod, torch_mod):
         a = rng.uniform(-1.0, 1.0, size=(E, 7))
         s = pi.spec.ac_scale
         desired = ref.qpos[:, f.arm_qpos_idx] + np.clip(a * s, -s, s)
-        desired = np.clip(desired, pi.jnt_minimum, pi.jnt_maximum)
+        desired = np.clip(np.clip(desired, f.act_lo[:7], f.act_hi[:7]), pi.jnt_minimum, pi.jnt_maximum)   # servo ctrlrange, then joint limits
         want_move, _ = orc.is_valid_batch(desired, ref.qpos, samples_per_env=1)
         _, _, _, info = env.step(torch.tensor(a, device=env.device))
         ref.step(a, move_mask=want_move)

@@ -469,12 +469,79 @@ def gen_ik():
     save("ref_py_ik.npz", **out)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# section "env": the reference env classes' step / _step / compute_reward / _get_obs / _after_step over FakeSim (f1, N1)
+# ------------------------------------------------------------------------------------------------------------------
+def gen_env():
+    from env.inverse_kinematics import qpos_from_site_pose
+    for env_name, tag in (("SawyerPushObstacle-v0", "push"), ("SawyerLiftObstacle-v0", "lift"), ("SawyerAssemblyObstacle-v0", "assembly")):
+        rng = np.random.default_rng(hash(tag) % 1000)
+        E, T, MAXS = 10, 24, 24
+        env0 = make_ref_env(env_name, seed=0)
+        nq, adim = env0.sim.model.nq, env0.dof
+        q0 = np.zeros((E, nq))
+        act = np.zeros((E, T, adim)); is_pl = np.zeros((E, T), dtype=np.int64); fresh = np.zeros((E, T), dtype=np.int64)
+        n_steps = np.zeros(E, dtype=np.int64)
+        obs = None
+        rew = np.zeros((E, T)); done = np.zeros((E, T), dtype=np.int64); succ = np.zeros((E, T), dtype=np.int64)
+        q_after = np.zeros((E, T, nq)); obs0 = None
+        for e in range(E):
+            env = make_ref_env(env_name, seed=50 + e, max_episode_steps=MAXS)
+            ob = env.reset()
+            if e % 2 == 1:
+                # start near the task's goal region so that the reward terms are exercised: the reference's own IK moves the
+                # gripper to the object (push: above the cube; lift: around the can; assembly: peg head over the hole)
+                d = env.sim.data
+                if tag == "push":
+                    tgt = d.body_xpos[env.cube_body_id] + np.array([-0.04, 0.0, 0.03]) + rng.normal(0, 0.01, 3)
+                elif tag == "lift":
+                    tgt = d.body_xpos[env.cube_body_id] + np.array([0.0, 0.0, 0.0 if e % 4 == 1 else 0.04]) + rng.normal(0, 0.004, 3)
+                else:
+                    tgt = d.get_site_xpos("grip_site") + (d.get_site_xpos("hole_bottom") - d.get_site_xpos("pegHead")) + rng.normal(0, 0.01, 3)
+                for _ in range(6):      # a few restarts: the solver stops at tol 1e-3 or when it stalls
+                    if tag == "assembly":   # the peg swings with the wrist: re-aim at the remaining head-to-hole offset
+                        tgt = d.get_site_xpos("grip_site") + (d.get_site_xpos("hole_bottom") - d.get_site_xpos("pegHead")) + (e % 4 == 3) * rng.normal(0, 0.01, 3)
+                    qpos_from_site_pose(env, "grip_site", target_pos=tgt, joint_names=env.robot_joints, max_steps=100, tol=1e-3)
+                if tag == "lift":       # fingers wide open before closing in on the can
+                    q = env.sim.data.qpos.copy()
+                    q[env.ref_gripper_joint_pos_indexes] = [-0.0115, -0.0115] if e % 4 == 1 else [0.0208, 0.0208]
+                    env.set_state(q, env.sim.data.qvel.copy())
+                ob = env._get_obs()
+            q0[e] = env.sim.data.qpos
+            fo = flat_ob(ob)
+            if obs is None:
+                obs, obs0 = np.zeros((E, T, len(fo))), np.zeros((E, len(fo)))
+            obs0[e] = fo
+            for t in range(T):
+                pl = int(rng.random() < 0.5)
+                if pl:
+                    a = rng.uniform(-0.07, 0.07, adim)          # a planner waypoint difference, sometimes beyond +-ac_scale
+                else:
+                    a = rng.uniform(-1.3, 1.3, adim)
+                if adim == 8:
+                    a[7] = rng.choice([-1.0, 1.0, rng.uniform(-0.01, 0.01)])      # gripper: bang-bang or a nudge
+                if t % 5 == 0:
+                    env._reset_prev_state()
+                    fresh[e, t] = 1
+                ob, r, dn, info = env.step(OrderedDict(default=a.copy()), is_planner=bool(pl))
+                act[e, t], is_pl[e, t] = a, pl
+                obs[e, t], rew[e, t], done[e, t], succ[e, t] = flat_ob(ob), r, int(dn), int(env._success)
+                q_after[e, t] = env.sim.data.qpos
+                n_steps[e] = t + 1
+                if dn:
+                    break
+        print(f"  env[{tag}]: steps {int(n_steps.sum())} nonzero rewards {int((rew != 0).sum())} max reward {rew.max():.3f} "
+              f"success {int(succ.sum())} done {int(done.sum())} obs_dim {obs.shape[2]}")
+        save(f"ref_py_env_{tag}.npz", qpos0=q0, obs0=obs0, action=act, is_planner=is_pl, fresh_prev=fresh, n_steps=n_steps, obs=obs,
+             reward=rew, done=done, success=succ, qpos_after=q_after, max_episode_steps=np.array(MAXS))
+
+
 def gen_rollouts():
     gen_rollout()
     gen_rollout(E=12, T=4, reuse=True)
 
 
-SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik)
+SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env)
 
 
 def main():

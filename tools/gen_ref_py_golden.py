@@ -366,6 +366,13 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
             np.random.seed(1000 * e + t)                    # the reuse_data relabelling draws from the global numpy RNG
             out["qpos_start"][e, t] = env.sim.data.qpos
             out["ep_len_start"][e, t] = env._episode_length
+            # the observation the policy sees, copied NOW: the Assembly env's obs dict holds views into the sim's site
+            # arrays (`di["pegHead"] = self.sim.data.get_site_xpos(...)`, no copy -- as with mujoco-py), so the dict the runner
+            # keeps as `prev_ob` shows the peg where the step took it by the time the transition is read
+            fo = flat_ob(ob)
+            if out["ob"] is None:
+                out["ob"], out["ob_next"] = np.zeros((E, T, len(fo))), np.zeros((E, T, len(fo)))
+            out["ob"][e, t] = fo
             a = OrderedDict(default=AC[e, t].copy())
             if agent.is_planner_ac(a):      # will the runner's back-off move this step's target?  (it divides by np.linalg.norm,
                 n = len(env.ref_joint_pos_indexes)    # a BLAS dot whose summation order is build-dependent: such steps are compared to round-off)
@@ -394,11 +401,9 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
                 break
             t = state["t"]
             ob0, ob1 = flat_ob(batch["ob"][0]), flat_ob(batch["ob"][-1])
-            if out["ob"] is None:
-                out["ob"], out["ob_next"] = np.zeros((E, T, len(ob0))), np.zeros((E, T, len(ob0)))
             if t != t_done:                                 # first yield after an act(): the step's own transition
                 t_done = t
-                out["ob"][e, t], out["ob_next"][e, t] = ob0, ob1
+                out["ob_next"][e, t] = ob1
                 out["rew"][e, t], out["done"][e, t], out["intra"][e, t] = batch["rew"][0], int(batch["done"][0]), batch["intra_steps"][0]
                 out["qpos_end"][e, t] = env.sim.data.qpos
                 c = dict(gen.gi_frame.f_locals["counter"])
@@ -539,6 +544,8 @@ def gen_env():
 def gen_rollouts():
     gen_rollout()
     gen_rollout(E=12, T=4, reuse=True)
+    gen_rollout("SawyerLiftObstacle-v0", "lift", E=24, T=5)
+    gen_rollout("SawyerAssemblyObstacle-v0", "assembly", E=24, T=5)
 
 
 SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env)

@@ -333,6 +333,11 @@ int mopa_ik_solve_batch(MopaIk *ik, int64_t E, double *qpos_dev /*[E,nq] in/out*
                         double max_update_norm, double progress_thresh, double regularization_strength,
                         double *err_norm_dev /*[E]*/, int32_t *steps_dev /*[E]*/, uint8_t *success_dev /*[E]*/, void *stream);
 
+/* World pose of the IK site for E states: site_pos [E,3], site_mat [E,9] row-major -- what the MoPA+IK rollouts read before
+ * they pose the problem (env.sim.data.get_site_xpos / get_site_xmat(config.ik_target), rl/mopa_rollouts.py:91-99,692). */
+int mopa_ik_site_pose_batch(MopaIk *ik, int64_t E, const double *qpos_dev /*[E,nq]*/, double *site_pos_dev /*[E,3]*/,
+                            double *site_mat_dev /*[E,9]*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
-    "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch",
+    "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch",
 ]
 
 
@@ -133,6 +133,7 @@ def lib() -> C.CDLL:
     L.mopa_ik_destroy.restype = None
     L.mopa_ik_solve_batch.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                                       vp, vp, vp, vp]
+    L.mopa_ik_site_pose_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
     L.mopa_scene_valid_kernel.argtypes = [vp, C.c_int64, C.c_char_p, C.c_int32]
     _lib = L
     return L

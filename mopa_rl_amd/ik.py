@@ -55,6 +55,15 @@ class BatchIK:
         except Exception:
             pass
 
+    def site_pose(self, qpos, stream=None):
+        """World pose of the site for E states: (pos [E,3], mat [E,3,3]) -- `get_site_xpos / get_site_xmat(ik_target)`."""
+        torch = _torch()
+        E = qpos.shape[0]
+        pos = torch.empty(E, 3, dtype=torch.float64, device=qpos.device)
+        mat = torch.empty(E, 3, 3, dtype=torch.float64, device=qpos.device)
+        _lib.check(_lib.lib().mopa_ik_site_pose_batch(self._h, E, _ptr(qpos), _ptr(pos), _ptr(mat), _stream_handle(stream)))
+        return pos, mat
+
     def solve(self, qpos, target_pos, target_quat=None, max_steps: int = 100, rot_weight: float = 1.0, tol: float = 1e-14,
               max_update_norm: float = 2.0, progress_thresh: float = 20.0, regularization_strength: float = 3e-2, stream=None) -> IKResult:
         """qpos [E, nq] (updated in place), target_pos [E, 3], target_quat [E, 4] wxyz or None: contiguous float64 GPU tensors.

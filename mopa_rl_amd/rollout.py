@@ -9,7 +9,9 @@ then densification of the planner path) and executed waypoint by waypoint with `
 the SMDP reward `sum_i gamma^i r_i` and `intra_steps` are accumulated (:152-199); a failed plan costs one env step with
 the current reward (:303-334).  Counters `mp / rl / interpolation / mp_fail / approximate / invalid` are kept per env.
 
-Restrictions (each raises): joint-space MoPA-SAC only (`use_ik_target=False`, `discrete_action=False`), the three Sawyer
+Action spaces: joint-space MoPA-SAC, and MoPA + IK (`use_ik_target`: Cartesian displacement + rotation quaternion of the
+ik_target site, turned into a joint displacement by the batched damped-LS IK -- BASELINE config 5); `discrete_action` is not
+offered.  Envs: the three Sawyer
 obstacle envs (no unlimited joints; 7 arm entries per action, Lift adds the gripper entry, which a planner step applies at
 the last waypoint of its path, :163-167).  The `reuse_data` relabelling (:204-300) -- extra transitions between random
 pairs of waypoints of an executed path -- is `reuse_transitions()` below, fed by `agent_step(..., record=True)`.
@@ -61,6 +63,12 @@ class RolloutConfig:
     max_nodes: int = 1024
     max_path: int = 256
     seed: int = 1234
+    # MoPA + IK action space (config/__init__.py --use_ik_target / --ik_target; rl/trainer.py:93-125): the policy outputs a
+    # Cartesian displacement of the ik_target site (3) + a rotation quaternion (4) [+ the gripper entry]
+    use_ik_target: bool = False
+    ik_target: str = "grip_site"
+    min_world_size: tuple = (-1.2, -1.2, 0.0)        # env/sawyer/sawyer.py:52-53
+    max_world_size: tuple = (1.2, 1.2, 2.0)
 
 
 def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30):
@@ -128,7 +136,17 @@ class BatchMoPARollout:
         self.t = 0     # agent steps taken (part of the RNG stream of the planner queries)
         self.main_iters = max(1, int(round(self.cfg.timelimit * ITERS_PER_SECOND)))
         self.simple_iters = max(1, int(round(self.cfg.simple_planner_timelimit * ITERS_PER_SECOND)))
-        del spec
+        self.ik = None
+        if self.cfg.use_ik_target:
+            from .ik import BatchIK
+            self.ik = BatchIK(env.model, self.cfg.ik_target, spec.robot_joints, device=dev_index)
+            self._world_lo = torch.tensor(self.cfg.min_world_size, dtype=f64, device=dev)
+            self._world_hi = torch.tensor(self.cfg.max_world_size, dtype=f64, device=dev)
+            # `_cart2dispalcement` clips the IK result against env._jnt_minimum/_jnt_maximum[jnt_indices] (float64; unlimited
+            # joints carry +-3.14 there, env/base.py:85-86) -- only the arm entries are read back
+            self._ik_lo = torch.tensor(f.qpos_min[self.arm], dtype=f64, device=dev)
+            self._ik_hi = torch.tensor(f.qpos_max[self.arm], dtype=f64, device=dev)
+        self.ac_dim = (7 if self.cfg.use_ik_target else self.n) + (env.action_dim - self.n)
 
     # ------------------------------------------------------------------
     def close(self):
@@ -138,6 +156,43 @@ class BatchMoPARollout:
     def clip_qpos(self, q):
         """`SACAgent.clip_qpos` (rl/sac_agent.py:237-260) per row, with the float32 limits the agents hold."""
         return self.limits.clip_state(q)
+
+    def ik_displacement(self, ac, cur):
+        """`MoPARolloutRunner._cart2dispalcement` (rl/mopa_rollouts.py:87-99,681-728) for E envs: the policy's Cartesian action
+        -> joint displacement of the arm through the damped-LS IK (K5).
+            target_cart = clip(site_xpos + action_range * ac[:3], world box)
+            target_quat = mulQuat(q_site[(w, x, y, y)], ac[3:7] / |ac[3:7]|)      # the reference indexes [3, 0, 1, 1] (sic)
+            qpos_from_site_pose(ik_env, ik_target, target_cart, target_quat, robot_joints, max_steps=100, tol=1e-2)
+            displacement = clip(result, joint limits)[arm] - curr[arm]
+        q_site is the site's orientation as `util.env.mat2quat` returns it: from the float32-rounded rotation matrix, sign
+        w >= 0.  (The reference takes the dominant eigenvector of the 4 x 4 K-matrix; for a rotation matrix that is the
+        closed-form quaternion used here, to the float32 rounding of the matrix -- a 1e-7 effect on the target.)"""
+        torch = _torch()
+        cfg = self.cfg
+        site_pos, site_mat = self.ik.site_pose(cur.contiguous())
+        target_cart = torch.minimum(torch.maximum(site_pos + cfg.action_range * ac[:, :3], self._world_lo), self._world_hi).contiguous()
+        m = site_mat.to(torch.float32).to(torch.float64)                      # np.array(rmat, dtype=np.float32)
+        m00, m01, m02, m10, m11, m12, m20, m21, m22 = (m[:, i, j] for i in range(3) for j in range(3))
+        tr = m00 + m11 + m22
+        # closed-form quaternion, branch on the largest of (trace, m00, m11, m22) for conditioning
+        qw = torch.stack([1.0 + tr, m21 - m12, m02 - m20, m10 - m01], dim=1)
+        qx = torch.stack([m21 - m12, 1.0 + m00 - m11 - m22, m01 + m10, m02 + m20], dim=1)
+        qy = torch.stack([m02 - m20, m01 + m10, 1.0 - m00 + m11 - m22, m12 + m21], dim=1)
+        qz = torch.stack([m10 - m01, m02 + m20, m12 + m21, 1.0 - m00 - m11 + m22], dim=1)
+        pick = torch.stack([tr, m00, m11, m22], dim=1).argmax(dim=1)
+        q = torch.stack([qw, qx, qy, qz], dim=1)[torch.arange(len(m), device=m.device), pick]      # (w, x, y, z), unnormalised
+        q = q / q.norm(dim=1, keepdim=True)
+        q = torch.where(q[:, :1] < 0, -q, q)
+        tq = torch.stack([q[:, 0], q[:, 1], q[:, 2], q[:, 2]], dim=1)                               # [[3, 0, 1, 1]] of (x, y, z, w)
+        aq = ac[:, 3:7] / ac[:, 3:7].norm(dim=1, keepdim=True)
+        aw, ax, ay, az = tq.unbind(1)
+        bw, bx, by, bz = aq.unbind(1)
+        target_quat = torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                                   aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], dim=1).contiguous()
+        q_ik = cur.clone()
+        self.ik.solve(q_ik, target_cart, target_quat, max_steps=100, tol=1e-2)
+        arm_t = torch.minimum(torch.maximum(q_ik[:, :self.n], self._ik_lo), self._ik_hi)
+        return arm_t - cur[:, :self.n]
 
     def _valid(self, q):
         return self.bp.is_valid(q[:, self.arm].contiguous(), q.contiguous(), samples_per_env=1).bool()
@@ -282,21 +337,32 @@ class BatchMoPARollout:
         else:
             def mark(name):
                 pass
-        a = ac[:, :n].contiguous()
         prev_ob = env.obs.clone()
         cur = env.qpos.clone()
         ar = torch.arange(E, device=dev)
+        if cfg.use_ik_target:
+            # MoPA + IK: the action is Cartesian; its joint displacement decides planner / direct and IS the direct action
+            a = self.ik_displacement(ac, cur)
+            extra_ac = ac[:, 7:7 + (env.action_dim - n)]
+            mark("ik")
+        else:
+            a = ac[:, :n].contiguous()
+            extra_ac = ac[:, n:env.action_dim]
         is_pl = is_planner_action(a, cfg.omega)
         plan_ok = torch.zeros(E, dtype=torch.bool, device=dev)
         path_len = torch.zeros(E, dtype=torch.int64, device=dev)
         traj_pad = None
         pl_idx = torch.nonzero(is_pl).flatten()
         if len(pl_idx):
-            disp = action_to_displacement(a[pl_idx], cfg.ac_scale, cfg.omega, cfg.action_range, cfg.ac_space_type)
             target = cur[pl_idx].clone()
-            target[:, :n] += disp
-            # np.clip to the joint limits, unlimited entries restored (:121-131)
-            target = self.limits.clip_target(target)
+            if not cfg.use_ik_target:
+                disp = action_to_displacement(a[pl_idx], cfg.ac_scale, cfg.omega, cfg.action_range, cfg.ac_space_type)
+                target[:, :n] += disp
+                # np.clip to the joint limits, unlimited entries restored (:121-131)
+                target = self.limits.clip_target(target)
+            # (with use_ik_target the reference never moves target_qpos off curr_qpos -- :113-131 is skipped and
+            # `_cart2dispalcement` keeps its result local --, so a planner step plans from the current state to itself: two
+            # zero-motion env steps.  Reproduced as is.)
             if cfg.invalid_target_handling:
                 target, _, tv = self.bp.pullback(cur[pl_idx].contiguous(), target.contiguous(), cfg.step_size, cfg.num_trials)
                 tv = tv.bool()
@@ -329,7 +395,7 @@ class BatchMoPARollout:
         # ---- direct execution (:336-356) and failed plans (:303-334: reward of the current state, one env step) in one launch
         act0 = torch.where(direct[:, None], a / torch.full_like(a, cfg.omega), torch.zeros_like(a))
         if env.action_dim > n:          # Lift: the gripper entry is passed through unscaled (:340-343)
-            act0 = torch.cat([act0, torch.where(direct[:, None], ac[:, n:env.action_dim], torch.zeros_like(ac[:, n:env.action_dim]))], dim=1)
+            act0 = torch.cat([act0, torch.where(direct[:, None], extra_ac, torch.zeros_like(extra_ac))], dim=1)
         act0 = act0.contiguous()
         flags = torch.where(direct, 1, torch.where(plan_ok, 2, 0)).to(torch.uint8).contiguous()
         env._launch(act0, False, flags)
@@ -352,7 +418,7 @@ class BatchMoPARollout:
             rew, done = rew.contiguous(), done.to(torch.uint8).contiguous()
             env.exec_trajectories(traj_pad, torch.where(plan_ok, path_len, torch.zeros_like(path_len)).contiguous(), disc,
                                   rew, done, intra, rec={k: rec[k] for k in ("ob", "meta_rew", "done", "n_exec")} if rec else None,
-                                  last_extra=ac[:, n].contiguous() if env.action_dim > n else None)
+                                  last_extra=extra_ac[:, 0].contiguous() if env.action_dim > n else None)
         mark("execute")
         env.has_prev.zero_()                                     # env._reset_prev_state()
         self.t += 1

@@ -79,6 +79,36 @@ def test_batched_rollout_equals_reference_rollout_runner(env_name, tag):
     assert G["done"].sum() > 0 and G["intra"].max() >= 8
 
 
+def test_ik_action_space_rollout_equals_reference_runner():
+    """BASELINE config 5's action space (MoPA + IK, `use_ik_target`): Cartesian displacement + rotation quaternion of the grip site
+    -> joint displacement through the batched damped-LS IK (K5, position + orientation target) -> planner / direct decision ->
+    env steps, against the reference runner on SawyerAssemblyObstacle (tests/golden/ref_py_rollout_assembly_ik.npz).
+    The reference forms the IK's orientation target from a float32 rotation matrix through an eigen-decomposition
+    (util/env.py:232-288); the batched form uses the closed-form quaternion of the same float32 matrix, so joint states agree
+    to ~1e-7 rather than bit for bit; flags and counters are identical."""
+    import torch
+    from mopa_rl_amd.rollout import COUNTERS
+    env_name = "SawyerAssemblyObstacle-v0"
+    G = np.load(os.path.join(GOLD, "ref_py_rollout_assembly_ik.npz"))
+    E, T = G["ac"].shape[:2]
+    env, ro = _make(G, E, env_name, use_ik_target=True)
+    assert ro.ac_dim == 7
+    for t in range(T):
+        _load_state(env, G["qpos_start"][:, t], G["ep_len_start"][:, t])
+        before = {k: ro.counters[k].clone() for k in COUNTERS}
+        ro.t = t
+        out = ro.agent_step(torch.tensor(G["ac"][:, t], device=env.device))
+        np.testing.assert_allclose(env.qpos.cpu().numpy(), G["qpos_end"][:, t], rtol=0, atol=2e-6, err_msg=f"step {t}: qpos")
+        assert np.array_equal(out["done"].cpu().numpy().astype(np.int64), G["done"][:, t]), f"step {t}: done"
+        assert np.array_equal(out["intra_steps"].cpu().numpy(), G["intra"][:, t]), f"step {t}: intra_steps"
+        got_c = np.stack([(ro.counters[k] - before[k]).cpu().numpy() for k in COUNTERS], axis=1)
+        assert np.array_equal(got_c, G["counters"][:, t]), f"step {t}: counters"
+        np.testing.assert_allclose(out["rew"].cpu().numpy(), G["rew"][:, t], rtol=1e-5, atol=1e-6, err_msg=f"step {t}: reward")
+        np.testing.assert_allclose(out["ob_next"].cpu().numpy(), G["ob_next"][:, t], rtol=0, atol=1e-5, err_msg=f"step {t}: ob_next")
+    tot = dict(zip(COUNTERS, G["counters"].sum(axis=(0, 1))))
+    assert tot["rl"] > 0 and tot["interpolation"] > 0, tot
+
+
 def test_reuse_data_relabelling_equals_reference():
     """`reuse_transitions` against the relabelled sub-trajectory transitions the reference's runner emitted (reuse_data=True,
     rl/mopa_rollouts.py:204-300) on the same steps with the same random draws."""

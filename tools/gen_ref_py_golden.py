@@ -340,15 +340,24 @@ def rollout_actions(E, T, n_ac, rng):
     return ac
 
 
-def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=False):
+def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=False, ik=False):
+    import util.env as ref_util_env
     from rl.mopa_rollouts import MoPARolloutRunner
+    ref_util_env.np = refshim.NumpyCompat()
     P = ROLLOUT_PARAMS
-    cfg = make_config(env_name, timelimit=P["timelimit"], reuse_data=reuse, num_trials=P["num_trials"])
+    cfg = make_config(env_name, timelimit=P["timelimit"], reuse_data=reuse, num_trials=P["num_trials"], use_ik_target=ik)
     n_ac = 8 if env_name == "SawyerLiftObstacle-v0" else 7
     agent, pi = make_agent(env_name, cfg, ac_dim=n_ac)
     st = Streams(agent, E, P["seed"], P["max_nodes"], P["max_path"])
     rng = np.random.default_rng(11)
-    AC = rollout_actions(E, T, n_ac, rng)
+    if ik:
+        # MoPA + IK action space (rl/trainer.py:93-125): Cartesian displacement (3) + rotation quaternion (4) in [-1, 1]
+        AC = rng.uniform(-1, 1, size=(E, T, 7))
+        AC[:, :, :3] *= rng.choice([0.05, 0.3, 1.0], size=(E, T, 1))           # small steps (direct) and long reaches (planner)
+        AC[:, :, 3] = np.abs(AC[:, :, 3]) + 0.5                                 # mostly small rotations ...
+        AC[: E // 4, :, 3:] = rng.uniform(-1, 1, size=(E // 4, T, 4))            # ... and some arbitrary ones
+    else:
+        AC = rollout_actions(E, T, n_ac, rng)
     nq = pi.model.nq
     out = dict(ac=AC, qpos_start=np.zeros((E, T, nq)), ep_len_start=np.zeros((E, T), dtype=np.int64), qpos_end=np.zeros((E, T, nq)),
                rew=np.zeros((E, T)), done=np.zeros((E, T), dtype=np.int64), intra=np.zeros((E, T), dtype=np.int64),
@@ -373,6 +382,8 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
             if out["ob"] is None:
                 out["ob"], out["ob_next"] = np.zeros((E, T, len(fo))), np.zeros((E, T, len(fo)))
             out["ob"][e, t] = fo
+            if ik:
+                return OrderedDict([("default", AC[e, t, :3].copy()), ("quat", AC[e, t, 3:].copy())]), None, None
             a = OrderedDict(default=AC[e, t].copy())
             if agent.is_planner_ac(a):      # will the runner's back-off move this step's target?  (it divides by np.linalg.norm,
                 n = len(env.ref_joint_pos_indexes)    # a BLAS dot whose summation order is build-dependent: such steps are compared to round-off)
@@ -384,7 +395,8 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
 
         agent.act = act
         runner = object.__new__(MoPARolloutRunner)
-        runner._config, runner._env, runner._env_eval, runner._ik_env, runner._pi = cfg, env, None, None, agent
+        runner._config, runner._env, runner._env_eval, runner._pi = cfg, env, None, agent
+        runner._ik_env = make_ref_env(env_name, seed=900 + e, max_episode_steps=P["max_episode_steps"]) if ik else None
         gen = runner.run(every_steps=1)
         prev_c = {k: 0 for k in COUNTERS}
         t_done = -1
@@ -421,7 +433,7 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
         out.update(x_env=np.array([x[0] for x in extra]), x_t=np.array([x[1] for x in extra]), x_ob=np.array([x[2] for x in extra]),
                    x_ac=np.array([x[3] for x in extra]), x_rew=np.array([x[4] for x in extra]), x_done=np.array([x[5] for x in extra]),
                    x_intra=np.array([x[6] for x in extra]), x_ob_next=np.array([x[7] for x in extra]))
-    save(f"ref_py_rollout_{tag}{'_reuse' if reuse else ''}.npz",
+    save(f"ref_py_rollout_{tag}{'_reuse' if reuse else ''}{'_ik' if ik else ''}.npz",
          params=np.array([P["timelimit"], P["max_nodes"], P["max_path"], P["seed"], P["max_episode_steps"], P["num_trials"]]), **out)
 
 
@@ -546,6 +558,7 @@ def gen_rollouts():
     gen_rollout(E=12, T=4, reuse=True)
     gen_rollout("SawyerLiftObstacle-v0", "lift", E=24, T=5)
     gen_rollout("SawyerAssemblyObstacle-v0", "assembly", E=24, T=5)
+    gen_rollout("SawyerAssemblyObstacle-v0", "assembly", E=24, T=5, ik=True)
 
 
 SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env)

@@ -183,93 +183,135 @@ def motion_section(torch, bp, pi, qa, rows, S, device):
     return out
 
 
-def env_step_section(torch, pi, E, device, steps, with_cpu):
-    """The "env-steps/sec" half of BASELINE.json's metric: E kinematic SawyerPushObstacle envs (K4 `k_env_step`),
+def env_step_section(torch, E, device, steps, with_cpu):
+    """The "env-steps/sec" half of BASELINE.json's metric: E kinematic Sawyer envs per task (K4 `k_env_step`),
     KINEMATIC -- the physics of the reference env.step is replaced by its kinematic limit (mopa_rl_amd/kinematic_env.py),
-    so this is NOT dynamics parity.  Two rates: the bare step, and the step gated by the planner's validity rule on the
-    desired state (block_invalid: one K1 launch + one K4 launch + torch glue per step)."""
-    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
-    out = {"config": f"{ENV} kinematic env.step, {E} envs, uniform policy actions in [-1,1]^7 (ac_scale {pi.spec.ac_scale})",
-           "label": "kinematic limit of the position servo; NOT dynamics parity (no contact forces, cube never moves)"}
+    so this is NOT dynamics parity.  Push (the headline env): the bare step, the step gated by the planner's validity rule on
+    the desired state (block_invalid: one K1 launch + one K4 launch + torch glue per step), parity + CPU baseline against the
+    oracle.  Lift (grasp test: finger boxes vs the can's hull) and Assembly: the bare step."""
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.scene import planner_inputs
+    out = {"label": "kinematic limit of the position servos; NOT dynamics parity (no contact forces, the manipulated object never moves)"}
     g = torch.Generator(device=device)
     g.manual_seed(5)
-    acts = (torch.rand(steps + 2, E, 7, generator=g, dtype=torch.float64, device=device) * 2 - 1).contiguous()
-    for key, block in (("steps_per_s", False), ("steps_per_s_collision_gated", True)):
-        env = BatchKinematicPushEnv(E, device=device, seed=11, block_invalid=block, max_episode_steps=1 << 30)
-        env.reset()
-        q_init = env.qpos.clone()
-        env.step(acts[0]); env.step(acts[1])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for t in range(steps):
-            env.step(acts[2 + t])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[key] = E * steps / dt
-        out[key.replace("steps_per_s", "us_per_batch")] = dt / steps * 1e6
-        if not block and with_cpu:
-            # parity + CPU baseline: replay the same rollout through the CPU checker from the same reset state
-            from oracle import oracle as O
-            orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
-            ref = O.OraclePushEnv(orc, env.facts, E, ac_scale=env.ac_scale, max_episode_steps=1 << 30)
-            ref.set_state(q_init.cpu().numpy())
-            a_host = acts.cpu().numpy()
-            cores = host_cores()
+    for env_name, tag in (("SawyerPushObstacle-v0", "push"), ("SawyerLiftObstacle-v0", "lift"), ("SawyerAssemblyObstacle-v0", "assembly")):
+        pi = planner_inputs(env_name)
+        blk = {"config": f"{env_name} kinematic env.step, {E} envs, uniform policy actions in [-1,1] (ac_scale {pi.spec.ac_scale})"}
+        for key, block in (("steps_per_s", False), ("steps_per_s_collision_gated", True)):
+            if block and tag != "push":
+                continue
+            env = make_env(env_name, E, device=device, seed=11, block_invalid=block, max_episode_steps=1 << 30)
+            acts = (torch.rand(steps + 2, E, env.action_dim, generator=g, dtype=torch.float64, device=device) * 2 - 1).contiguous()
+            env.reset()
+            q_init = env.qpos.clone()
+            env.step(acts[0]); env.step(acts[1])
+            torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for t in range(steps + 2):
-                ref.step(a_host[t], nthreads=cores)
-            dt_cpu = time.perf_counter() - t0
-            out["parity_mismatches_vs_oracle"] = int((env.obs.cpu().numpy().view(np.uint64) != ref.obs.view(np.uint64)).sum()
-                                                     + (env.reward.cpu().numpy().view(np.uint64) != ref.reward.view(np.uint64)).sum())
-            t0 = time.perf_counter()
-            ref.step(a_host[0], nthreads=1)
-            dt_1 = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": E * (steps + 2) / dt_cpu, "unit": "env-steps/s", "cores": cores, "kind": "port",
-                                   "single_thread_value": E / dt_1,
-                                   "sample": f"the same {steps + 2} x {E} steps through the oracle's orc_env_step_batch "
-                                             "(OpenMP over envs); our C restatement, not MuJoCo"}
+            for t in range(steps):
+                env.step(acts[2 + t])
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            blk[key] = E * steps / dt
+            blk[key.replace("steps_per_s", "us_per_batch")] = dt / steps * 1e6
+            if not block and with_cpu and tag == "push":
+                # parity + CPU baseline: replay the same rollout through the CPU checker from the same reset state
+                from oracle import oracle as O
+                orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+                ref = O.OracleEnv(orc, env.facts, E, ac_scale=env.ac_scale, max_episode_steps=1 << 30)
+                ref.set_state(q_init.cpu().numpy())
+                a_host = acts.cpu().numpy()
+                cores = host_cores()
+                t0 = time.perf_counter()
+                for t in range(steps + 2):
+                    ref.step(a_host[t], nthreads=cores)
+                dt_cpu = time.perf_counter() - t0
+                blk["parity_mismatches_vs_oracle"] = int((env.obs.cpu().numpy().view(np.uint64) != ref.obs.view(np.uint64)).sum()
+                                                         + (env.reward.cpu().numpy().view(np.uint64) != ref.reward.view(np.uint64)).sum())
+                t0 = time.perf_counter()
+                ref.step(a_host[0], nthreads=1)
+                dt_1 = time.perf_counter() - t0
+                blk["cpu_baseline"] = {"value": E * (steps + 2) / dt_cpu, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                                       "single_thread_value": E / dt_1,
+                                       "sample": f"the same {steps + 2} x {E} steps through the oracle's orc_env_step_batch "
+                                                 "(OpenMP over envs); our C restatement, not MuJoCo"}
+        out[tag] = blk
+    out["steps_per_s"] = out["push"]["steps_per_s"]
     return out
 
 
-def rollout_section(torch, pi, E, device, agent_steps):
-    """End-to-end MoPA rollout step (mopa_rl_amd/rollout.py), SURVEY 8d config 3: a SAC actor (stock PyTorch, random-init
-    40-256-256-256-(7+7) MLP, f32; a = tanh(mu + sigma * eps)) samples the action from the obs inside the timed loop,
+SAC_GRAD_FLOATS = 145678 + 2 * 78337       # actor + two critics for obs 40 / ac 7 (SURVEY section 2: the payload of sync_grads)
+
+
+def rollout_section(torch, env_name, E, device, agent_steps, world=1):
+    """End-to-end MoPA rollout step (mopa_rl_amd/rollout.py), SURVEY 8d configs 3 / 4: a SAC actor (stock PyTorch, random-init
+    obs-256-256-256-(2 x ac) MLP, f32; a = tanh(mu + sigma * eps)) samples the action from the obs inside the timed loop,
     then per env either a direct env step or target / pull-back / straight-line pre-check / RRT-Connect / densification /
-    waypoint execution on the kinematic env.  Host-orchestrated; every check / plan / env step a batched launch."""
-    from mopa_rl_amd.kinematic_env import BatchKinematicPushEnv
+    waypoint execution on the kinematic env.  Host-orchestrated; every check / plan / env step a batched launch.
+    Every agent step ends with the exchanges a data-parallel run needs (no-ops at world 1): the asynchronous RCCL all-gather
+    of the step's transition records (dist.TransitionExchange, overlapped with the next step) and an all-reduce of a
+    gradient-sized f32 buffer (what `sync_grads` moves per SAC update, reference util/pytorch.py:153-159)."""
+    import torch.distributed as dist
+    from mopa_rl_amd.dist import TransitionExchange, all_reduce_mean_
+    from mopa_rl_amd.kinematic_env import make_env
     from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
-    env = BatchKinematicPushEnv(E, device=device, seed=21, max_episode_steps=250)
+    env = make_env(env_name, E, device=device, seed=21 + int(os.environ.get("RANK", "0")), max_episode_steps=250)
     env.reset()
     ro = BatchMoPARollout(env, RolloutConfig())
     torch.manual_seed(8)
     nn = torch.nn
+    ad = env.action_dim
     actor = nn.Sequential(nn.Linear(env.obs.shape[1], 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
-                          nn.Linear(256, 14)).to(device)
+                          nn.Linear(256, 2 * ad)).to(device)
     g = torch.Generator(device=device)
     g.manual_seed(8)
+    tx = TransitionExchange(E, env.obs_dim, ad, device)
+    grads = torch.zeros(SAC_GRAD_FLOATS, dtype=torch.float32, device=device)
 
     def act():
         with torch.no_grad():
             mu, log_std = actor(env.obs.float()).chunk(2, dim=1)
-            eps = torch.randn(E, 7, generator=g, dtype=torch.float32, device=device)
+            eps = torch.randn(E, ad, generator=g, dtype=torch.float32, device=device)
             return torch.tanh(mu + torch.exp(log_std.clamp(-10.0, 2.0)) * eps).double()
-    out = ro.agent_step(act())
+
+    def one(k):
+        a = act()
+        out = ro.agent_step(a)
+        tx.pack(k, out["ob"], a, out["rew"], out["done"], out["intra_steps"], out["ob_next"])
+        tx.launch(k)
+        all_reduce_mean_(grads)
+        return out
+    out = one(0)
     env.reset(out["done"].bool())
+    tx.drain()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     n_env_steps = 0
     t0 = time.perf_counter()
     for t in range(agent_steps):
-        out = ro.agent_step(act())
+        out = one(t + 1)
         n_env_steps += int((out["intra_steps"] + 1).sum().item())
         if bool(out["done"].any().item()):
             env.reset(out["done"].bool())
+    gathered = tx.result(agent_steps)
+    tx.drain()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c = {k: int(v.sum().item()) for k, v in ro.counters.items()}
-    return {"config": f"{ENV}, {E} envs, {agent_steps} agent steps; actions sampled by a random-init SAC actor (40-256-256-256-14 MLP, "
-                      "f32, tanh-Gaussian) from the obs (omega 0.7), kinematic env",
-            "agent_steps_per_s": E * agent_steps / dt, "env_steps_per_s": n_env_steps / dt, "s_per_agent_step_batch": dt / agent_steps,
-            "counters": c}
+    if world > 1:
+        t = torch.tensor([dt, float(n_env_steps)] + [float(c[k]) for k in sorted(c)], dtype=torch.float64, device=device)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, n_env_steps = float(tmax[0].item()), int(t[1].item())
+        c = {k: int(t[2 + i].item()) for i, k in enumerate(sorted(c))}
+    return {"config": f"{env_name}, {E} envs per GPU x {world} GPU(s), {agent_steps} agent steps; actions sampled by a random-init SAC actor "
+                      f"({env.obs.shape[1]}-256-256-256-{2 * ad} MLP, f32, tanh-Gaussian) from the obs (omega 0.7), kinematic env",
+            "agent_steps_per_s": world * E * agent_steps / dt, "env_steps_per_s": n_env_steps / dt, "s_per_agent_step_batch": dt / agent_steps,
+            "counters": c,
+            "exchange": {"transition_record_bytes": tx.width * 4, "all_gather_bytes_per_rank_per_step": tx.bytes_per_step,
+                         "gathered_rows": int(gathered["rew"].shape[0]), "grad_all_reduce_bytes": SAC_GRAD_FLOATS * 4,
+                         "collectives": "RCCL all_gather_into_tensor (async, double-buffered) + all_reduce(SUM)/world" if world > 1 else "none (1 rank)"}}
 
 
 def ik_section(torch, device, E=8192):
@@ -324,6 +366,53 @@ def ik_section(torch, device, E=8192):
     return out
 
 
+def scenes_section(torch, device, E, S, steps=5):
+    """K1 on the other reference scenes at the same batch shape (4096 x 256 mixed states): which kernel the library picks and
+    its rate -- Lift runs the gated mesh pass, Assembly and Lift read the FP32 centres from the pose slab."""
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import planner_inputs
+    out = {}
+    for env in ("SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0", "PusherObstacle-v0"):
+        pi = planner_inputs(env)
+        sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range,
+                        device=device.index if device.index is not None else -1)
+        bp = BatchPlanner(sc)
+        qa, rows = make_inputs(torch, pi, E, S, 1234, device)
+        v = torch.empty(E * S, dtype=torch.uint8, device=device)
+        for _ in range(2):
+            bp.is_valid(qa, rows, samples_per_env=S, out=v)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        for a, b in ev:
+            a.record(); bp.is_valid(qa, rows, samples_per_env=S, out=v); b.record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        out[env] = {"checks_per_s": E * S / (ms * 1e-3), "ms_per_launch": ms, "kernel": sc.valid_kernel(E * S),
+                    "pairs_checked_per_state": sc.npair_checked, "valid_fraction": float(v.float().mean().item())}
+        sc.close()
+    return out
+
+
+def lib_sha256():
+    import hashlib
+    from mopa_rl_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+
+
+def committed_traffic(kernel, n_states):
+    """HBM-side traffic / VALU counts of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile.sh ->
+    tools/make_traffic_json.py -> profiles/rNN/k_is_valid_traffic.json); they cannot be collected from inside this process.
+    A file is used only if it was measured on THIS build of libmopa_hip.so (sha256 stamp), for this kernel and batch size."""
+    import glob
+    sha = lib_sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "k_is_valid_traffic.json")), reverse=True):
+        t = json.load(open(f))
+        if t.get("lib_sha256") == sha and t.get("states_per_launch") == n_states and t.get("kernel", "").startswith(kernel):
+            t["source"] = os.path.relpath(f, ROOT)
+            return t
+    return None
+
+
 def cpu_baseline(pi, qa_host, rows_host, S, budget_states):
     """Oracle (oracle/mopa_oracle.c, kind="port") on the host cores, on the first `budget_states` states."""
     from oracle import oracle as O
@@ -355,7 +444,8 @@ def main():
     ap.add_argument("--no-plan", action="store_true", help="skip the RRT-Connect section (config 3)")
     ap.add_argument("--plan-envs", type=int, default=4096)
     ap.add_argument("--no-env", action="store_true", help="skip the kinematic env.step section")
-    ap.add_argument("--no-rollout", action="store_true", help="skip the end-to-end rollout section")
+    ap.add_argument("--no-rollout", action="store_true", help="skip the end-to-end rollout sections (Push at 1 GPU; Lift with the "
+                    "transition all-gather + gradient all-reduce at any rank count)")
     args = ap.parse_args()
 
     import torch
@@ -448,15 +538,15 @@ def main():
             "valid_fraction": n_valid / N,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "k_is_valid_v5<false, true, false>", "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
+                         "kernel": scene.valid_kernel(N), "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
                          "note": "path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see DESIGN.md"},
         }
-        # HBM-side traffic of the same launch, from the committed rocprofv3 PMC passes (tools/profile.sh ->
-        # profiles/r01/k_is_valid_v5_traffic.json); it cannot be collected from inside this process.
-        tj = os.path.join(ROOT, "profiles", "r01", "k_is_valid_v5_traffic.json")
-        if os.path.exists(tj) and E * S == 1 << 20:
-            t = json.load(open(tj))
+        t = committed_traffic(scene.valid_kernel(N), N)
+        if t is None:
+            out["roofline"]["traffic_source"] = None      # no PMC pass committed for this build of the library
+        else:
             out["roofline"]["traffic"] = t["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = f"{t['source']} (lib sha256 {t['lib_sha256'][:12]})"
             out["roofline"]["traffic_note"] = t["note"]
             if "valu_insts_per_launch" in t:
                 # FP64 issue roof: a wave64 FP64 op holds a 16-lane SIMD for 4 cycles -> CUs*4*clk/4 wave-instr/s
@@ -469,11 +559,9 @@ def main():
             out["motion"] = motion_section(torch, bp, pi, qa, rows, S, device)
             out["planner"] = plan_section(torch, bp, pi, args.plan_envs, device, not args.no_cpu)
         if not args.no_env and world == 1:
-            out["env_step"] = env_step_section(torch, pi, args.envs, device, 50, not args.no_cpu)
-        if not args.no_env and world == 1:
+            out["scenes"] = scenes_section(torch, device, E, S)
+            out["env_step"] = env_step_section(torch, args.envs, device, 50, not args.no_cpu)
             out["ik"] = ik_section(torch, device)
-        if not args.no_rollout and world == 1:
-            out["rollout"] = rollout_section(torch, pi, args.envs, device, 3)
         if not args.no_cpu and world == 1:
             cb = cpu_baseline(pi, qa.cpu().numpy(), rows.cpu().numpy(), S, args.cpu_states)
             mism = int((cb["verdicts"] != valid[: cb["n"]].cpu().numpy()).sum())
@@ -483,6 +571,15 @@ def main():
                           "oracle/mopa_oracle.c = this repo's C restatement, NOT MuJoCo/OMPL (unavailable)",
                 "single_thread_value": cb["single"]}
             out["parity_mismatches_vs_oracle"] = mism
+    # the rollout sections run on EVERY rank (their exchanges are collectives): config 3 (Push) at one GPU, config 4
+    # (Lift: env shard + all-gather of the rollout transitions + gradient all-reduce) at any rank count
+    ro = {}
+    if not args.no_rollout:
+        if world == 1:
+            ro["rollout"] = rollout_section(torch, ENV, args.envs, device, 3)
+        ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 3, world)
+    if rank == 0:
+        out.update(ro)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

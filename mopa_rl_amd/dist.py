@@ -113,3 +113,61 @@ class OverlappedGather:
     def drain(self):
         for b in range(self.depth):
             self._wait(b)
+
+
+class TransitionExchange:
+    """All-gather of the transition records of one agent step (every rank fills the same replay
+    buffer; the reference keeps one buffer per MPI rank and never exchanges transitions, rl/dataset.py).  A record is one
+    float32 row per env:  ob | ac | rew | done | intra_steps | ob_next  (Lift: 35 + 8 + 3 + 35 = 81 floats = 324 B).
+    `pack(k, ...)` fills the local buffer of step k on the current stream, `launch(k)` starts the asynchronous all-gather on
+    the backend's stream (so it overlaps whatever the current stream does next -- the next agent step's validity / planner
+    launches), `result(k)` waits for it and returns the fields as views of the gathered [world * E, W] tensor.  Buffers are
+    reused round-robin (`depth`); a buffer is handed out again only after the collective reading it has completed.
+    With one rank nothing is communicated."""
+
+    def __init__(self, n_envs: int, obs_dim: int, ac_dim: int, device, depth: int = 2):
+        import torch
+        self.world, self.rank = world_info()
+        self.E, self.obs_dim, self.ac_dim, self.depth = int(n_envs), int(obs_dim), int(ac_dim), int(depth)
+        self.width = 2 * self.obs_dim + self.ac_dim + 3
+        self.local = [torch.zeros(self.E, self.width, dtype=torch.float32, device=device) for _ in range(depth)]
+        self.gathered = ([torch.zeros(self.world * self.E, self.width, dtype=torch.float32, device=device) for _ in range(depth)]
+                         if self.world > 1 else None)
+        self.pending = [None] * depth
+
+    @property
+    def bytes_per_step(self) -> int:
+        return self.E * self.width * 4
+
+    def _wait(self, b: int):
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+
+    def pack(self, k: int, ob, ac, rew, done, intra_steps, ob_next):
+        b = k % self.depth
+        self._wait(b)
+        buf, o, a = self.local[b], self.obs_dim, self.ac_dim
+        buf[:, :o] = ob
+        buf[:, o:o + a] = ac[:, :a]
+        buf[:, o + a] = rew
+        buf[:, o + a + 1] = done
+        buf[:, o + a + 2] = intra_steps
+        buf[:, o + a + 3:] = ob_next
+        return buf
+
+    def launch(self, k: int):
+        if self.world > 1:
+            b = k % self.depth
+            self.pending[b] = _dist().all_gather_into_tensor(self.gathered[b], self.local[b], async_op=True)
+
+    def result(self, k: int):
+        b = k % self.depth
+        self._wait(b)
+        g, o, a = (self.gathered[b] if self.world > 1 else self.local[b]), self.obs_dim, self.ac_dim
+        return {"ob": g[:, :o], "ac": g[:, o:o + a], "rew": g[:, o + a], "done": g[:, o + a + 1], "intra_steps": g[:, o + a + 2],
+                "ob_next": g[:, o + a + 3:]}
+
+    def drain(self):
+        for b in range(self.depth):
+            self._wait(b)

@@ -131,3 +131,75 @@ def test_overlapped_gather_double_buffering():
     for k in range(steps):
         for r in range(world):
             assert (got[k, r * n:(r + 1) * n] == (17 * k + 3 * r) % 251).all(), (k, r)
+
+
+def _tx_rollout(oracle_mod, env_name, lo, hi, E, T):
+    """T direct kinematic env steps of envs [lo, hi) of an E-env job on the CPU oracle; states and actions are keyed by the
+    GLOBAL env id, so a shard computes exactly the rows it owns of the unsharded job"""
+    from mopa_rl_amd.kinematic_env import env_facts
+    from mopa_rl_amd.scene import default_qpos, planner_inputs
+    pi = planner_inputs(env_name)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    f = env_facts(env_name, pi.model)
+    n = hi - lo
+    env = oracle_mod.OracleEnv(orc, f, n, ac_scale=pi.spec.ac_scale, max_episode_steps=3)
+    q = np.tile(default_qpos(env_name, pi.model), (n, 1))
+    for i, e in enumerate(range(lo, hi)):
+        q[i, :7] += np.random.default_rng(1000 + e).normal(0, 0.02, 7)
+    env.set_state(q)
+    steps = []
+    for t in range(T):
+        ob = env.obs.copy()
+        ac = np.stack([np.random.default_rng(7919 * t + e).uniform(-1, 1, env.action_dim) for e in range(lo, hi)])
+        env.step(ac)
+        steps.append(dict(ob=ob, ac=ac, rew=env.reward.copy(), done=env.done.copy(), intra_steps=np.zeros(n), ob_next=env.obs.copy()))
+    return steps, env.obs_dim, env.action_dim
+
+
+def _tx_worker(rank, world, port, E, T, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from mopa_rl_amd.dist import TransitionExchange, shard_range
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = shard_range(E, world, rank)
+    steps, od, ad = _tx_rollout(O, "SawyerLiftObstacle-v0", lo, hi, E, T)
+    tx = TransitionExchange(hi - lo, od, ad, torch.device("cpu"))
+    got = []
+    for k, s in enumerate(steps):
+        tx.pack(k, *(torch.from_numpy(np.asarray(s[f], dtype=np.float64)) for f in ("ob", "ac", "rew", "done", "intra_steps", "ob_next")))
+        tx.launch(k)
+        if k >= 1:
+            got.append({f: v.clone().numpy() for f, v in tx.result(k - 1).items()})   # consume step k-1 while step k is in flight
+    got.append({f: v.clone().numpy() for f, v in tx.result(T - 1).items()})
+    tx.drain()
+    if rank == 0:
+        q.put((got, tx.bytes_per_step))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_transition_all_gather_equals_unsharded(oracle_mod):
+    """BASELINE config 4's exchange (env shard + all-gather of rollout transitions) on 2 gloo ranks: the gathered records of
+    every step equal the unsharded job's, field by field (float32 records), with double-buffered asynchronous collectives"""
+    import torch.multiprocessing as mp
+    world, E, T = 2, 8, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tx_worker, args=(r, world, port, E, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, nbytes = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want, od, ad = _tx_rollout(oracle_mod, "SawyerLiftObstacle-v0", 0, E, E, T)
+    assert nbytes == (E // world) * (2 * od + ad + 3) * 4 and (od, ad) == (35, 8)
+    for k in range(T):
+        for f in ("ob", "ac", "rew", "done", "intra_steps", "ob_next"):
+            assert np.array_equal(got[k][f], np.asarray(want[k][f], dtype=np.float32)), (k, f)
+    assert sum(int(w["done"].sum()) for w in want) > 0

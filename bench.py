@@ -242,7 +242,7 @@ def env_step_section(torch, E, device, steps, with_cpu):
 SAC_GRAD_FLOATS = 145678 + 2 * 78337       # actor + two critics for obs 40 / ac 7 (the payload of sync_grads)
 
 
-def rollout_section(torch, env_name, E, device, agent_steps, world=1):
+def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_planner=False):
     """End-to-end MoPA rollout step (mopa_rl_amd/rollout.py), SURVEY 8d configs 3 / 4: a SAC actor (stock PyTorch, random-init
     obs-256-256-256-(2 x ac) MLP, f32; a = tanh(mu + sigma * eps)) samples the action from the obs inside the timed loop,
     then per env either a direct env step or target / pull-back / straight-line pre-check / RRT-Connect / densification /
@@ -256,7 +256,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1):
     from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
     env = make_env(env_name, E, device=device, seed=21 + int(os.environ.get("RANK", "0")), max_episode_steps=250)
     env.reset()
-    ro = BatchMoPARollout(env, RolloutConfig())
+    ro = BatchMoPARollout(env, RolloutConfig(async_planner=async_planner))
     torch.manual_seed(8)
     nn = torch.nn
     ad = env.action_dim
@@ -286,29 +286,34 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    n_env_steps = 0
+    n_env_steps = n_agent_steps = 0
     t0 = time.perf_counter()
     for t in range(agent_steps):
         out = one(t + 1)
-        n_env_steps += int((out["intra_steps"] + 1).sum().item())
-        if bool(out["done"].any().item()):
-            env.reset(out["done"].bool())
+        st = out["stepped"]
+        n_agent_steps += int(st.sum().item())
+        n_env_steps += int(((out["intra_steps"] + 1) * st).sum().item())
+        d = out["done"].bool() & st
+        if bool(d.any().item()):
+            env.reset(d)
     gathered = tx.result(agent_steps)
     tx.drain()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c = {k: int(v.sum().item()) for k, v in ro.counters.items()}
     if world > 1:
-        t = torch.tensor([dt, float(n_env_steps)] + [float(c[k]) for k in sorted(c)], dtype=torch.float64, device=device)
+        t = torch.tensor([dt, float(n_env_steps), float(n_agent_steps)] + [float(c[k]) for k in sorted(c)], dtype=torch.float64, device=device)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, n_env_steps = float(tmax[0].item()), int(t[1].item())
-        c = {k: int(t[2 + i].item()) for i, k in enumerate(sorted(c))}
-    return {"config": f"{env_name}, {E} envs per GPU x {world} GPU(s), {agent_steps} agent steps; actions sampled by a random-init SAC actor "
-                      f"({env.obs.shape[1]}-256-256-256-{2 * ad} MLP, f32, tanh-Gaussian) from the obs (omega 0.7), kinematic env",
-            "agent_steps_per_s": world * E * agent_steps / dt, "env_steps_per_s": n_env_steps / dt, "s_per_agent_step_batch": dt / agent_steps,
-            "counters": c,
+        dt, n_env_steps, n_agent_steps = float(tmax[0].item()), int(t[1].item()), int(t[2].item())
+        c = {k: int(t[3 + i].item()) for i, k in enumerate(sorted(c))}
+    mode = ("async_planner: RRT-Connect on side streams, envs waiting for a query sit out (each env's transitions are those of the "
+            "lock-step run)") if async_planner else "lock-step: every call waits for its slowest RRT-Connect query"
+    return {"config": f"{env_name}, {E} envs per GPU x {world} GPU(s), {agent_steps} calls of agent_step; actions sampled by a random-init SAC actor "
+                      f"({env.obs.shape[1]}-256-256-256-{2 * ad} MLP, f32, tanh-Gaussian) from the obs (omega 0.7), kinematic env; {mode}",
+            "agent_steps_per_s": n_agent_steps / dt, "env_steps_per_s": n_env_steps / dt, "s_per_agent_step_batch": dt / agent_steps,
+            "envs_stepping_per_call": n_agent_steps / (world * agent_steps), "counters": c,
             "exchange": {"transition_record_bytes": tx.width * 4, "all_gather_bytes_per_rank_per_step": tx.bytes_per_step,
                          "gathered_rows": int(gathered["rew"].shape[0]), "grad_all_reduce_bytes": SAC_GRAD_FLOATS * 4,
                          "collectives": "RCCL all_gather_into_tensor (async, double-buffered) + all_reduce(SUM)/world" if world > 1 else "none (1 rank)"}}
@@ -577,7 +582,8 @@ def main():
     if not args.no_rollout:
         if world == 1:
             ro["rollout"] = rollout_section(torch, ENV, args.envs, device, 3)
-        ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 3, world)
+            ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 20, async_planner=True)
+        ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 20, world, async_planner=True)
     if rank == 0:
         out.update(ro)
         print(json.dumps(out))

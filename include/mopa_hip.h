@@ -125,6 +125,8 @@ typedef struct MopaPlanParams {
     uint64_t env_id_base;
     const uint64_t *env_ids_dev;   /* mopa_plan_batch only, nullable: explicit stream id per query (device pointer, [E]) --
                                       lets a caller plan for a compacted subset of its envs with the streams of the full set */
+    const uint64_t *seeds_dev;     /* mopa_plan_batch only, nullable: explicit seed per query (device pointer, [E]) instead of
+                                      `seed` -- queries of envs that are at different steps of their own rollouts in one launch */
 } MopaPlanParams;
 
 const char *mopa_last_error(void);

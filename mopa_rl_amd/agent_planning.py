@@ -99,11 +99,10 @@ class JointLimits:
 
 
     def clip_state_np(self, q):
-        """`clip_state` for one host-side row (numpy)."""
+        """`clip_state` on host rows (numpy, [nq] or [S, nq])."""
         lo, hi, lo_s, hi_s = self._np
-        if np.any(q < lo) or np.any(q > hi):
-            return np.minimum(np.maximum(q, lo_s), hi_s)
-        return q
+        beyond = ((q < lo) | (q > hi)).any(axis=-1, keepdims=True)
+        return np.where(beyond, np.minimum(np.maximum(q, lo_s), hi_s), q)
 
 
 def interpolation_steps(diff, ac_scale: float, ac_low: float = -1.0, ac_high: float = 1.0):

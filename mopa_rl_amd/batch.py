@@ -71,9 +71,10 @@ class BatchPlanner:
         return valid
 
     def plan(self, start, goal, max_iters: int = 2000, max_nodes: int = 1024, max_path: int = 256, seed: int = 0,
-             env_id_base: int = 0, stream=None, env_ids=None) -> Tuple["object", "object", "object", "object"]:
+             env_id_base: int = 0, stream=None, env_ids=None, seeds=None) -> Tuple["object", "object", "object", "object"]:
         """E independent RRT-Connect queries.  Returns (path[E,max_path,nq], path_len[E], status[E], n_checks[E]).
-        env_ids (int64 [E] GPU tensor, optional): the sample-stream id of every query (default env_id_base + index)."""
+        env_ids (int64 [E] GPU tensor, optional): the sample-stream id of every query (default env_id_base + index).
+        seeds (int64 [E] GPU tensor, optional): a seed per query instead of `seed`."""
         torch = _torch()
         _check_f64(start, "start", self.nq)
         _check_f64(goal, "goal", self.nq)
@@ -86,8 +87,11 @@ class BatchPlanner:
         if env_ids is not None and (env_ids.dtype != torch.int64 or not env_ids.is_cuda or not env_ids.is_contiguous()
                                     or tuple(env_ids.shape) != (E,)):
             raise _lib.MopaError("env_ids must be a contiguous int64 GPU tensor of shape [E]")
+        if seeds is not None and (seeds.dtype != torch.int64 or not seeds.is_cuda or not seeds.is_contiguous() or tuple(seeds.shape) != (E,)):
+            raise _lib.MopaError("seeds must be a contiguous int64 GPU tensor of shape [E]")
         prm = _lib.MopaPlanParams(int(max_iters), int(max_nodes), int(max_path), int(seed) & 0xFFFFFFFFFFFFFFFF,
-                                  int(env_id_base), _ptr(env_ids) if env_ids is not None else None)
+                                  int(env_id_base), _ptr(env_ids) if env_ids is not None else None,
+                                  _ptr(seeds) if seeds is not None else None)
         _lib.check(_lib.lib().mopa_plan_batch(self.scene.handle, _ptr(start), _ptr(goal), E, C.byref(prm), _ptr(path),
                                               _ptr(plen), _ptr(status), _ptr(nchk), _stream_handle(stream)))
         return path, plen, status, nchk

@@ -65,6 +65,8 @@ class RolloutConfig:
     seed: int = 1234
     # MoPA + IK action space (config/__init__.py --use_ik_target / --ik_target; rl/trainer.py:93-125): the policy outputs a
     # Cartesian displacement of the ik_target site (3) + a rotation quaternion (4) [+ the gripper entry]
+    async_planner: bool = False       # RRT-Connect on side streams; envs waiting for a query sit out (see agent_step)
+    planner_streams: int = 4
     use_ik_target: bool = False
     ik_target: str = "grip_site"
     min_world_size: tuple = (-1.2, -1.2, 0.0)        # env/sawyer/sawyer.py:52-53
@@ -125,7 +127,7 @@ class BatchMoPARollout:
         mk = lambda r: _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, self.cfg.contact_threshold, range_=r,
                                   seed=self.cfg.seed, device=dev_index)
         self.scene, self.simple_scene = mk(self.cfg.range), mk(self.cfg.simple_planner_range)
-        self.bp = BatchPlanner(self.scene)
+        self.bp, self._bp_simple = BatchPlanner(self.scene), BatchPlanner(self.simple_scene)
         self.E, self.nq, self.n = env.E, env.nq, env.n_arm
         self.arm = list(int(i) for i in env.facts.arm_qpos_idx)
         assert self.arm == list(range(self.n)), "the reference slices qpos[:n] (rl/sac_agent.py:275-278)"
@@ -133,7 +135,12 @@ class BatchMoPARollout:
         dev, f64 = env.device, torch.float64
         self.limits = JointLimits(f.qpos_min, f.qpos_max, f.qpos_limited, self.cfg.joint_margin, device=dev)
         self.counters: Dict[str, "object"] = {k: torch.zeros(self.E, dtype=torch.int64, device=dev) for k in COUNTERS}
-        self.t = 0     # agent steps taken (part of the RNG stream of the planner queries)
+        self.t_env = torch.zeros(self.E, dtype=torch.int64, device=dev)     # agent steps every env has completed
+        self._t = 0
+        self.busy = torch.zeros(self.E, dtype=torch.bool, device=dev)        # env waits for an RRT-Connect query (async_planner)
+        self._jobs = []
+        self._streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, self.cfg.planner_streams))] if self.cfg.async_planner else []
+        self._next_stream = 0
         self.main_iters = max(1, int(round(self.cfg.timelimit * ITERS_PER_SECOND)))
         self.simple_iters = max(1, int(round(self.cfg.simple_planner_timelimit * ITERS_PER_SECOND)))
         self.ik = None
@@ -147,6 +154,8 @@ class BatchMoPARollout:
             self._ik_lo = torch.tensor(f.qpos_min[self.arm], dtype=f64, device=dev)
             self._ik_hi = torch.tensor(f.qpos_max[self.arm], dtype=f64, device=dev)
         self.ac_dim = (7 if self.cfg.use_ik_target else self.n) + (env.action_dim - self.n)
+        self._pend_ob = torch.zeros(self.E, env.obs_dim, dtype=f64, device=dev)      # ob / ac of the step a busy env is in
+        self._pend_ac = torch.zeros(self.E, self.ac_dim, dtype=f64, device=dev)
 
     # ------------------------------------------------------------------
     def close(self):
@@ -198,13 +207,183 @@ class BatchMoPARollout:
         return self.bp.is_valid(q[:, self.arm].contiguous(), q.contiguous(), samples_per_env=1).bool()
 
     # ------------------------------------------------------------------
-    def plan(self, cur, target, env_ids):
-        """`SACAgent.plan` (rl/sac_agent.py:198-235) for M envs.  Returns (traj [M, L, nq] device tensor, length [M] device
-        int64 -- 0 where the plan failed --, and the boolean numpy arrays success, interpolation, valid, exact).  Straight
-        lines that validate never leave the GPU; only the envs that needed RRT-Connect are post-processed on the host
-        (ragged paths: successive differences, densification) and uploaded into their rows."""
+    @property
+    def t(self) -> int:
+        """agent steps taken (lock-step count); part of the planner's sample-stream key.  Assigning it puts every env at that
+        step (tests replay recorded steps)."""
+        return self._t
+
+    @t.setter
+    def t(self, value: int):
+        self._t = int(value)
+        self.t_env.fill_(int(value))
+
+    def _rrt_launch(self, cur_f, target_f, ids, stream=None):
+        """RRT-Connect (K3) for the envs `ids` whose straight line is blocked (:205-209): asynchronous, optionally on a side
+        stream.  The sample stream of a query is keyed by (cfg.seed + the env's own step count, env id), so an env's plans do
+        not depend on which other envs are planned with it or when."""
+        torch = _torch()
+        cfg = self.cfg
+        seeds = (self.t_env[ids] + cfg.seed).contiguous()
+        job = {"ids": ids, "cur": cur_f, "target": target_f, "steps": self.t_env[ids].clone(), "event": None, "stage": "rrt", "stream": stream}
+        if stream is None:
+            job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=self.main_iters, max_nodes=cfg.max_nodes,
+                                                                      max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=self.main_iters, max_nodes=cfg.max_nodes,
+                                                                          max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds,
+                                                                          stream=stream)
+                for t in (cur_f, target_f, ids, seeds):
+                    t.record_stream(stream)
+                job["event"] = torch.cuda.Event()
+                job["event"].record(stream)
+        return job
+
+    def _rrt_advance(self, job, wait: bool):
+        """Drive a planner job through its stages; returns True when it is finished (job["result"] = (trajs: row -> [L, nq]
+        numpy for the successful rows; success, valid, exact as numpy bool arrays over the job's rows)).
+          stage "rrt"     results of the main RRT-Connect launch: sentinel decoding, the un-wrapped trajectory of
+                          `SamplingBasedPlanner.plan` / `PlannerAgent.plan`, densification (rl/sac_agent.py:216-233): a path
+                          segment longer than ac_scale in some joint is cut by the straight-line rule from its clipped start; all
+                          interior states of all segments are validated in ONE launch
+          stage "simple"  the (rare) segments with an invalid interior state: simple planner, one batched launch (:300-303)
+          stage "main"    those it could not connect: main planner, one batched launch (:304-306); else the segment stays [end]
+        With `wait` every stage is waited for (lock-step); otherwise a stage whose launch has not finished returns False."""
         torch = _torch()
         cfg, n = self.cfg, self.n
+        while True:
+            if job["event"] is not None:
+                if wait:
+                    job["event"].synchronize()
+                elif not job["event"].query():
+                    return False
+            plen_h, st_h = job["plen"].cpu().numpy(), job["status"].cpu().numpy()
+            path_h = job["path"][:, :max(1, int(plen_h.max()))].cpu().numpy()      # the [max_path] tail of every row is unused
+            if job["stage"] == "rrt":
+                cur_h = job["cur"].cpu().numpy()
+                job["ids_h"], job["steps_h"] = job["ids"].cpu().numpy(), job["steps"].cpu().numpy()
+                M = len(job["ids_h"])
+                bad = st_h != 0        # sentinel rows (sampling_based_planner.py:64-69): -5 goal invalid, -4 no exact solution
+                valid, exact = np.ones(M, dtype=bool), np.ones(M, dtype=bool)
+                valid[bad] = st_h[bad] != _lib.PLAN_INVALID_GOAL
+                exact[bad] = st_h[bad] != _lib.PLAN_NO_EXACT
+                good = np.where(~bad)[0]
+                job.update(flags=(~bad, valid, exact), good=good, replacement={}, fb=[], seg_r=np.zeros(0, dtype=np.int64),
+                           seg_i=np.zeros(0, dtype=np.int64), T=None, nrow=np.zeros(0, dtype=np.int64))
+                if len(good):
+                    # SamplingBasedPlanner.plan rebuilds the trajectory from successive differences (:71-99) and PlannerAgent
+                    # drops row 0: tr[k] = tr[k-1] + (states[k] - states[k-1]), tr[0] = cur.  np.add.accumulate is that same
+                    # strictly sequential sum, for all paths at once (rows past a path's length hold garbage and are cut off).
+                    P = path_h[good]
+                    A = np.concatenate([cur_h[good][:, None, :], P[:, 1:] - P[:, :-1]], axis=1)
+                    T = np.add.accumulate(A, axis=1)
+                    nrow = plen_h[good] - 1
+                    job["T"], job["nrow"] = T, nrow
+                    if cfg.interpolation and T.shape[1] > 1:
+                        step = T[:, 1:, :n] - T[:, :-1, :n]                      # waypoint i minus its predecessor (cur for i = 0)
+                        far = ((step < -cfg.ac_scale) | (step > cfg.ac_scale)).any(axis=2)
+                        far &= np.arange(far.shape[1])[None, :] < nrow[:, None]
+                        job["seg_r"], job["seg_i"] = np.nonzero(far)             # segment k: waypoint seg_i[k] of path seg_r[k]
+                if len(job["seg_r"]):
+                    self._densify_cut(job)
+                if not job["fb"]:
+                    return self._rrt_done(job)
+                self._fallback_launch(job, "simple")
+                continue
+            # a fallback stage came back: rows = job["fb"] (indices into seg_jobs)
+            left = []
+            for r, k in enumerate(job["fb"]):
+                if st_h[r] == 0:
+                    p = path_h[r, :plen_h[r]]
+                    # SamplingBasedPlanner.plan: start + running sum of successive differences; PlannerAgent drops row 0
+                    job["replacement"][k] = np.add.accumulate(np.vstack([job["starts"][k][None], p[1:] - p[:-1]]), axis=0)[1:]
+                elif job["stage"] == "simple":
+                    left.append(k)
+                else:
+                    job["replacement"][k] = job["ends"][k][None]
+            job["fb"] = left
+            if not left:
+                return self._rrt_done(job)
+            self._fallback_launch(job, "main")
+
+    def _fallback_launch(self, job, stage):
+        torch = _torch()
+        cfg = self.cfg
+        dev = self.env.device
+        ks = job["fb"]
+        scene_bp, iters, base = ((self._bp_simple, self.simple_iters, 1) if stage == "simple" else (self.bp, self.main_iters, 2))
+        starts = torch.tensor(job["starts"][ks], device=dev)
+        ends = torch.tensor(job["ends"][ks], device=dev)
+        rows = job["good"][job["seg_r"][ks]]
+        ids = torch.tensor(self.E * base + job["ids_h"][rows], dtype=torch.int64, device=dev)
+        seeds = torch.tensor(cfg.seed + job["steps_h"][rows], dtype=torch.int64, device=dev)
+        stream = job["stream"]
+        job["stage"] = stage
+        if stream is None:
+            job["path"], job["plen"], job["status"], _ = scene_bp.plan(starts, ends, max_iters=iters, max_nodes=cfg.max_nodes,
+                                                                       max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                job["path"], job["plen"], job["status"], _ = scene_bp.plan(starts, ends, max_iters=iters, max_nodes=cfg.max_nodes,
+                                                                           max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds,
+                                                                           stream=stream)
+                job["keep"] = (starts, ends, ids, seeds)
+                job["event"] = torch.cuda.Event()
+                job["event"].record(stream)
+
+    def _rrt_done(self, job):
+        """assemble the final trajectories: [M, L, nq] padded + lengths (0 for the failed rows).  Waypoint i of path r becomes
+        `pieces[r, i]` rows: itself, or -- densified -- its cut (count interior states + the waypoint), or a fallback path."""
+        M, nq = len(job["ids_h"]), self.nq
+        good, T, nrow = job["good"], job["T"], job["nrow"]
+        if not len(good):
+            job["result"] = (np.zeros((M, 1, nq)), np.zeros(M, dtype=np.int64)) + job["flags"]
+            return True
+        R, W = T.shape[0], T.shape[1] - 1
+        seg_r, seg_i = job["seg_r"], job["seg_i"]
+        pieces = (np.arange(W)[None, :] < nrow[:, None]).astype(np.int64)
+        seg_len = np.zeros(len(seg_r), dtype=np.int64)
+        if len(seg_r):
+            seg_len[:] = job["count"] + 1
+            for k, rep in job["replacement"].items():
+                seg_len[k] = len(rep)
+            pieces[seg_r, seg_i] = seg_len
+        off = np.cumsum(pieces, axis=1) - pieces                       # first output row of waypoint i
+        length = pieces.sum(axis=1)
+        out = np.zeros((R, max(1, int(length.max())), nq))
+        r_idx, i_idx = np.nonzero(np.arange(W)[None, :] < nrow[:, None])
+        out[r_idx, off[r_idx, i_idx] + pieces[r_idx, i_idx] - 1] = T[r_idx, i_idx + 1]      # every piece ends in its waypoint
+        if len(seg_r):
+            plain = np.array([k not in job["replacement"] for k in range(len(seg_r))])
+            kk = np.nonzero(plain)[0]
+            if len(kk):
+                cnt = job["count"][kk]
+                kr = np.repeat(kk, cnt)                                                      # (segment, interior state c) pairs
+                c = np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+                out[seg_r[kr], off[seg_r[kr], seg_i[kr]] + c] = job["walk"][kr, c]
+            for k, rep in job["replacement"].items():
+                o = off[seg_r[k], seg_i[k]]
+                out[seg_r[k], o:o + len(rep)] = rep
+        traj = np.zeros((M, out.shape[1], nq))
+        ln = np.zeros(M, dtype=np.int64)
+        traj[good], ln[good] = out, length
+        job["result"] = (traj, ln) + job["flags"]
+        return True
+
+    def _rrt_finish(self, job):
+        self._rrt_advance(job, wait=True)
+        return job["result"]
+
+    def plan(self, cur, target, env_ids):
+        """`SACAgent.plan` (rl/sac_agent.py:198-235) for M envs, synchronously.  Returns (traj [M, L, nq] device tensor, length
+        [M] device int64 -- 0 where the plan failed --, and the boolean numpy arrays success, interpolation, valid, exact).
+        Straight lines that validate never leave the GPU; only the envs that needed RRT-Connect are post-processed on the
+        host (ragged paths: successive differences, densification) and uploaded into their rows."""
+        torch = _torch()
+        cfg = self.cfg
         M = cur.shape[0]
         cur = self.clip_qpos(cur)
         traj_t, tlen, succ, _ = simple_interpolate_batch(self.bp, cur, target, cfg.ac_scale, self.arm)
@@ -215,69 +394,37 @@ class BatchMoPARollout:
         fail = np.where(~succ_h)[0]
         if len(fail) == 0:
             return traj_t, lens, success, interpolation, valid, exact
-        # ---- main planner for the envs whose straight line is blocked (:205-209)
         fi = torch.as_tensor(fail, device=cur.device)
-        ids = env_ids[fi].contiguous()
-        cur_f = cur[fi].contiguous()
-        path, plen, status, _ = self.bp.plan(cur_f, target[fi].contiguous(), max_iters=self.main_iters,
-                                             max_nodes=cfg.max_nodes, max_path=cfg.max_path, seed=cfg.seed + self.t, env_ids=ids)
-        plen_h, st_h = plen.cpu().numpy(), status.cpu().numpy()
-        path_h = path[:, :max(1, int(plen_h.max()))].cpu().numpy()      # the [max_path] tail of every row is unused
-        cur_h, ids_h = cur_f.cpu().numpy(), ids.cpu().numpy()
+        job = self._rrt_launch(cur[fi].contiguous(), target[fi].contiguous(), env_ids[fi].contiguous())
+        tr_j, ln_j, s_j, v_j, e_j = self._rrt_finish(job)
         interpolation[fail] = False
-        trajs = {}             # j (index into `fail`) -> [L_j, nq] numpy
-        seg_jobs = []          # (j, i, start, end) of planner-path segments that need densification
-        bad = st_h != 0        # sentinel rows (sampling_based_planner.py:64-69): -5 goal invalid, -4 no exact solution
-        valid[fail[bad]] = st_h[bad] != _lib.PLAN_INVALID_GOAL
-        exact[fail[bad]] = st_h[bad] != _lib.PLAN_NO_EXACT
-        success[fail[bad]] = False
-        good = np.where(~bad)[0]
-        if len(good):
-            success[fail[good]] = valid[fail[good]] = exact[fail[good]] = True
-            # SamplingBasedPlanner.plan rebuilds the trajectory from successive differences (:71-99) and PlannerAgent
-            # drops row 0: tr[k] = tr[k-1] + (states[k] - states[k-1]), tr[0] = cur.  np.add.accumulate is that same
-            # strictly sequential sum, for all paths at once (rows past a path's length hold garbage and are cut off).
-            P = path_h[good]
-            A = np.concatenate([cur_h[good][:, None, :], P[:, 1:] - P[:, :-1]], axis=1)
-            T = np.add.accumulate(A, axis=1)
-            nrow = plen_h[good] - 1
-            if cfg.interpolation:
-                step = T[:, 1:, :n] - T[:, :-1, :n]                      # waypoint i minus its predecessor (cur for i = 0)
-                far = ((step < -cfg.ac_scale) | (step > cfg.ac_scale)).any(axis=2)
-                far &= np.arange(far.shape[1])[None, :] < nrow[:, None]
-            for r, j in enumerate(good):
-                trajs[j] = T[r, 1:nrow[r] + 1].copy()
-                if cfg.interpolation:
-                    for i in np.nonzero(far[r])[0]:
-                        seg_jobs.append((j, int(i), T[r, i].copy(), trajs[j][i]))
-        if seg_jobs:
-            self._densify(trajs, seg_jobs, cur_h, ids_h)
-        if trajs:
-            L = max(traj_t.shape[1], max(len(tr) for tr in trajs.values()))
-            if L > traj_t.shape[1]:
-                traj_t = torch.cat([traj_t, torch.zeros(M, L - traj_t.shape[1], self.nq, dtype=traj_t.dtype, device=traj_t.device)], dim=1)
-            js = sorted(trajs)
-            pad = np.zeros((len(js), L, self.nq))
-            ln = np.zeros(len(js), dtype=np.int64)
-            for r, j in enumerate(js):
-                pad[r, :len(trajs[j])] = trajs[j]
-                ln[r] = len(trajs[j])
-            rows = torch.as_tensor(fail[js], device=cur.device)
-            traj_t[rows] = torch.as_tensor(pad, device=cur.device)
-            lens[rows] = torch.as_tensor(ln, device=cur.device)
+        success[fail], valid[fail], exact[fail] = s_j, v_j, e_j
+        traj_t, lens = self._merge_paths(traj_t, lens, tr_j, ln_j, fi)
         return traj_t, lens, success, interpolation, valid, exact
 
-    def _densify(self, trajs, seg_jobs, cur_h, ids_h):
-        """rl/sac_agent.py:216-233 -- a planner-path segment longer than ac_scale in some joint is replaced by the
-        straight-line rule (steps <= 0.8 ac_scale from the segment's clipped start, then the segment's end).  All segments
-        of all envs are cut at once and all their interior states validated in ONE launch; the (rare) segments with an
-        invalid interior state fall back to the single-query planners: simple planner, main planner, else [end]
-        (:300-313)."""
+    def _merge_paths(self, traj_t, lens, tr_j, ln_j, rows):
+        """write a job's padded host-side trajectories (tr_j [M, L, nq], ln_j [M]; 0 = no path) into rows `rows` (device index
+        tensor) of traj_t / lens"""
         torch = _torch()
-        cfg, n, nq = self.cfg, self.n, self.nq
-        S = len(seg_jobs)
-        starts = np.stack([self.limits.clip_state_np(j[2]) for j in seg_jobs])      # :266 clip_qpos on every segment start
-        ends = np.stack([j[3] for j in seg_jobs])
+        if not ln_j.any():
+            return traj_t, lens
+        L = int(ln_j.max())
+        if L > traj_t.shape[1]:
+            traj_t = torch.cat([traj_t, torch.zeros(traj_t.shape[0], L - traj_t.shape[1], self.nq, dtype=traj_t.dtype, device=traj_t.device)], dim=1)
+        traj_t[rows, :L] = torch.as_tensor(tr_j[:, :L], device=traj_t.device)
+        lens[rows] = torch.as_tensor(ln_j, device=traj_t.device)
+        return traj_t, lens
+
+    def _densify_cut(self, job):
+        """cut every long segment of a job by the straight-line rule (steps <= 0.8 ac_scale from the segment's clipped start,
+        then the segment's end), validate all interior states in one launch; segments whose interior states are all valid are
+        done, the others are listed in job["fb"] for the fallback planners.  All segments at once (array operations)."""
+        torch = _torch()
+        cfg, n = self.cfg, self.n
+        T, seg_r, seg_i = job["T"], job["seg_r"], job["seg_i"]
+        starts = self.limits.clip_state_np(T[seg_r, seg_i])                         # :266 clip_qpos on every segment start
+        ends = T[seg_r, seg_i + 1]
+        S = len(seg_r)
         bound = cfg.ac_scale * 0.8
         diff = ends[:, :n] - starts[:, :n]
         ratio = np.maximum(np.where(diff > bound, diff / bound, 0.0), np.where(diff < -bound, diff / -bound, 0.0))
@@ -293,33 +440,24 @@ class BatchMoPARollout:
         live = np.arange(K)[None, :] < count[:, None]
         verdict = np.ones((S, K), dtype=bool)
         verdict[live] = self._valid(torch.tensor(walk[live], device=self.env.device)).cpu().numpy()
-        clear = verdict.all(axis=1)
-        replacement = {}
-        for k, (m, i, _, end) in enumerate(seg_jobs):
-            if clear[k]:
-                replacement[(m, i)] = list(walk[k, :count[k]]) + [end]
-                continue
-            e = int(ids_h[m])
-            found = None
-            for scene, iters, base in ((self.simple_scene, self.simple_iters, 1), (self.scene, self.main_iters, 2)):
-                st, p, _ = scene.plan(starts[k], end, max_iters=iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path,
-                                      seed=cfg.seed + self.t, env_id=self.E * base + e)
-                if st == 0:
-                    # SamplingBasedPlanner.plan: start + running sum of successive differences; PlannerAgent drops row 0
-                    found = list(np.add.accumulate(np.vstack([starts[k][None], p[1:] - p[:-1]]), axis=0)[1:])
-                    break
-            replacement[(m, i)] = found if found is not None else [end]
-        for m in sorted({j[0] for j in seg_jobs}):
-            trajs[m] = np.array([row for i in range(len(trajs[m])) for row in replacement.get((m, i), [trajs[m][i]])])
+        job.update(starts=starts, ends=ends, count=count, walk=walk, fb=list(np.nonzero(~verdict.all(axis=1))[0]))
 
     # ------------------------------------------------------------------
     def agent_step(self, ac, record: bool = False):
-        """One agent step for all E envs.  ac: float64 [E, >= env.action_dim] GPU tensor (policy output in [-1, 1]).
-        Returns a dict of GPU tensors: ob [E,obs_dim] (before), ob_next [E,obs_dim], rew [E] (SMDP return of the step), done [E]
-        uint8, intra_steps [E] int64, is_planner [E] bool, success [E] bool (env success flag), plus `path_len`.
+        """One agent step for all E envs.  ac: float64 [E, >= self.ac_dim] GPU tensor (policy output in [-1, 1]).
+        Returns a dict of GPU tensors: ob [E,obs_dim] (before), ac (the action each transition belongs to), ob_next
+        [E,obs_dim], rew [E] (SMDP return of the step), done [E] uint8, intra_steps [E] int64, is_planner [E] bool, success [E]
+        (env success flag), `path_len`, `plan_ok`, and `stepped` [E] bool: the envs that completed an agent step in this call.
         record=True adds `record`: per executed waypoint k the obs after it, the running SMDP return, the done flag and
         the waypoint itself ([E, L, ...]; `n_exec` [E] = waypoints actually executed) -- the `ob_list / meta_rew_list /
-        done_list / traj` of the reference, input of `reuse_transitions`."""
+        done_list / traj` of the reference, input of `reuse_transitions`.
+
+        Lock-step (default): every env steps in every call; the call returns when the slowest RRT-Connect query of the step is
+        done.  `cfg.async_planner`: the RRT-Connect queries of a call run on side streams while the call returns; their envs
+        are `busy` -- they sit out the following calls (their rows of `ac` are ignored) -- until their query has finished, and
+        complete their step (path execution or the failed-plan step) in the first call after that.  Envs are independent and a
+        query's sample stream is keyed by the env's own step count, so each env goes through the same sequence of transitions
+        either way; only their interleaving differs.  Rows of the outputs are meaningful where `stepped`."""
         torch = _torch()
         env, cfg, E, n = self.env, self.cfg, self.E, self.n
         dev = env.device
@@ -337,21 +475,23 @@ class BatchMoPARollout:
         else:
             def mark(name):
                 pass
-        prev_ob = env.obs.clone()
+        busy0 = self.busy.clone()
+        active = ~busy0
+        prev_ob = torch.where(busy0[:, None], self._pend_ob, env.obs)
+        ac_tr = torch.where(busy0[:, None], self._pend_ac, ac[:, :self.ac_dim])
         cur = env.qpos.clone()
-        ar = torch.arange(E, device=dev)
         if cfg.use_ik_target:
             # MoPA + IK: the action is Cartesian; its joint displacement decides planner / direct and IS the direct action
             a = self.ik_displacement(ac, cur)
-            extra_ac = ac[:, 7:7 + (env.action_dim - n)]
+            extra_ac = ac_tr[:, 7:7 + (env.action_dim - n)]
             mark("ik")
         else:
             a = ac[:, :n].contiguous()
-            extra_ac = ac[:, n:env.action_dim]
-        is_pl = is_planner_action(a, cfg.omega)
+            extra_ac = ac_tr[:, n:env.action_dim]
+        is_pl = is_planner_action(a, cfg.omega) & active
         plan_ok = torch.zeros(E, dtype=torch.bool, device=dev)
         path_len = torch.zeros(E, dtype=torch.int64, device=dev)
-        traj_pad = None
+        traj_pad = torch.zeros(E, 1, self.nq, dtype=torch.float64, device=dev)
         pl_idx = torch.nonzero(is_pl).flatten()
         if len(pl_idx):
             target = cur[pl_idx].clone()
@@ -369,51 +509,79 @@ class BatchMoPARollout:
             else:
                 tv = self._valid(target)
             mark("target")
-            v_idx = torch.nonzero(tv).flatten()
             self.counters["mp_fail"][pl_idx[~tv]] += 1          # invalid target: success, valid, exact = False, False, True
             self.counters["invalid"][pl_idx[~tv]] += 1
+            v_idx = torch.nonzero(tv).flatten()
             if len(v_idx):
+                # ---- SACAgent.plan: straight-line pre-check for all of them in one launch (:198-204) ----
                 ids = pl_idx[v_idx].contiguous()
-                traj_dev, lens_dev, success, interpolation, valid, exact = self.plan(cur[ids].contiguous(), target[v_idx].contiguous(), ids)
-                mark("plan")
-                t = lambda x: torch.as_tensor(x, device=dev)
-                s_t = t(success)
-                plan_ok[ids] = s_t
-                self.counters["interpolation"][ids[s_t & t(interpolation)]] += 1
-                self.counters["mp"][ids[s_t & ~t(interpolation)]] += 1
-                self.counters["mp_fail"][ids[~s_t]] += 1
-                self.counters["approximate"][ids[~s_t & ~t(exact)]] += 1
-                self.counters["invalid"][ids[~s_t & ~t(valid)]] += 1
-                L = int(lens_dev.max().item())
-                if L:
-                    traj_pad = torch.zeros(E, L, self.nq, dtype=torch.float64, device=dev)
-                    traj_pad[ids] = traj_dev[:, :L]
-                    path_len[ids] = lens_dev
-        mark("pad")
-        direct = ~is_pl
+                cur_v = self.clip_qpos(cur[ids].contiguous())
+                tgt_v = target[v_idx].contiguous()
+                traj_i, tlen, succ, _ = simple_interpolate_batch(self.bp, cur_v, tgt_v, cfg.ac_scale, self.arm)
+                ok_ids = ids[succ]
+                plan_ok[ok_ids] = True
+                self.counters["interpolation"][ok_ids] += 1
+                traj_pad = torch.zeros(E, traj_i.shape[1], self.nq, dtype=torch.float64, device=dev)
+                traj_pad[ok_ids] = traj_i[succ]
+                path_len[ok_ids] = tlen[succ].to(torch.int64)
+                mark("interpolate")
+                blocked = torch.nonzero(~succ).flatten()
+                if len(blocked):
+                    # ---- the blocked ones go to RRT-Connect; lock-step waits for it below, async_planner does not ----
+                    side = None
+                    if cfg.async_planner:
+                        side = self._streams[self._next_stream % len(self._streams)]
+                        self._next_stream += 1
+                    bid = ids[blocked].contiguous()
+                    self._jobs.append(self._rrt_launch(cur_v[blocked].contiguous(), tgt_v[blocked].contiguous(), bid, side))
+                    self.busy[bid] = True
+                    self._pend_ob[bid] = prev_ob[bid]
+                    self._pend_ac[bid] = ac_tr[bid]
+        # ---- RRT-Connect jobs that are done (lock-step: all of them) ----
+        finished = torch.zeros(E, dtype=torch.bool, device=dev)
+        still = []
+        for job in self._jobs:
+            if not self._rrt_advance(job, wait=not cfg.async_planner):
+                still.append(job)
+                continue
+            tr_j, ln_j, s_j, v_j, e_j = job["result"]
+            jid = job["ids"]
+            t = lambda x: torch.as_tensor(x, device=dev)
+            s_t = t(s_j)
+            finished[jid] = True
+            plan_ok[jid] = s_t
+            self.counters["mp"][jid[s_t]] += 1
+            self.counters["mp_fail"][jid[~s_t]] += 1
+            self.counters["approximate"][jid[~s_t & ~t(e_j)]] += 1
+            self.counters["invalid"][jid[~s_t & ~t(v_j)]] += 1
+            traj_pad, path_len = self._merge_paths(traj_pad, path_len, tr_j, ln_j, jid)
+            self.busy[jid] = False
+        self._jobs = still
+        mark("plan")
+        direct = active & ~is_pl
         self.counters["rl"][direct] += 1
+        sitting = self.busy & ~finished            # still waiting for their query: nothing of theirs is touched
+        stepped = ~sitting
         # ---- direct execution (:336-356) and failed plans (:303-334: reward of the current state, one env step) in one launch
         act0 = torch.where(direct[:, None], a / torch.full_like(a, cfg.omega), torch.zeros_like(a))
         if env.action_dim > n:          # Lift: the gripper entry is passed through unscaled (:340-343)
             act0 = torch.cat([act0, torch.where(direct[:, None], extra_ac, torch.zeros_like(extra_ac))], dim=1)
         act0 = act0.contiguous()
-        flags = torch.where(direct, 1, torch.where(plan_ok, 2, 0)).to(torch.uint8).contiguous()
+        flags = torch.where(direct, 1, torch.where(plan_ok | sitting, 2, 0)).to(torch.uint8).contiguous()
         env._launch(act0, False, flags)
         rew = torch.where(plan_ok, torch.zeros_like(env.reward), env.reward)
         done = torch.where(plan_ok, torch.zeros_like(env.done), env.done)
         intra = torch.zeros(E, dtype=torch.int64, device=dev)
         # ---- waypoint execution (:152-199)
         rec = None
+        L = traj_pad.shape[1]
         if record:
-            Lr = traj_pad.shape[1] if traj_pad is not None else 0
-            rec = {"ob": torch.zeros(E, Lr, env.obs.shape[1], dtype=torch.float64, device=dev),
-                   "meta_rew": torch.zeros(E, Lr, dtype=torch.float64, device=dev),
-                   "done": torch.zeros(E, Lr, dtype=torch.uint8, device=dev),
-                   "waypoint": traj_pad if traj_pad is not None else torch.zeros(E, 0, self.nq, dtype=torch.float64, device=dev),
-                   "n_exec": torch.zeros(E, dtype=torch.int64, device=dev)}
-        if traj_pad is not None:
+            rec = {"ob": torch.zeros(E, L, env.obs.shape[1], dtype=torch.float64, device=dev),
+                   "meta_rew": torch.zeros(E, L, dtype=torch.float64, device=dev),
+                   "done": torch.zeros(E, L, dtype=torch.uint8, device=dev),
+                   "waypoint": traj_pad, "n_exec": torch.zeros(E, dtype=torch.int64, device=dev)}
+        if bool(plan_ok.any()):
             # one launch: every env walks its own waypoints until its path ends or a step reports done
-            L = traj_pad.shape[1]
             disc = torch.tensor([cfg.discount_factor ** k for k in range(L)], dtype=torch.float64, device=dev)
             rew, done = rew.contiguous(), done.to(torch.uint8).contiguous()
             env.exec_trajectories(traj_pad, torch.where(plan_ok, path_len, torch.zeros_like(path_len)).contiguous(), disc,
@@ -421,10 +589,16 @@ class BatchMoPARollout:
                                   last_extra=extra_ac[:, 0].contiguous() if env.action_dim > n else None)
         mark("execute")
         env.has_prev.zero_()                                     # env._reset_prev_state()
-        self.t += 1
-        del ar
-        res = {"ob": prev_ob, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra, "is_planner": is_pl,
-               "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok}
+        self.t_env[stepped] += 1
+        self._t += 1
+        res = {"ob": prev_ob, "ac": ac_tr, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra,
+               "is_planner": is_pl | finished, "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok, "stepped": stepped}
         if rec is not None:
             res["record"] = rec
         return res
+
+    def drain(self):
+        """wait for every RRT-Connect query in flight (async_planner); their envs complete their step in the next agent_step"""
+        for job in self._jobs:
+            if job["event"] is not None:
+                job["event"].synchronize()

@@ -140,6 +140,46 @@ def test_reuse_data_relabelling_equals_reference():
     assert n_checked == len(G["x_env"]) and n_checked > 30
 
 
+def test_async_planner_gives_every_env_the_same_transitions():
+    """`async_planner`: RRT-Connect queries run on side streams while the other envs go on stepping; the envs waiting for a
+    query sit out.  Every env must still go through exactly the transitions of the lock-step run (its plans are keyed by its own
+    step count), only later in wall-clock order."""
+    import torch
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    E, T = 192, 5
+    rng = np.random.default_rng(4)
+    AC = rng.uniform(-1, 1, size=(E, T, 7)) * rng.choice([0.6, 0.9, 1.0], size=(E, T, 1))
+    AC[: E // 2, 1, 1], AC[: E // 2, 1, 3] = 1.0, -1.0           # blocked straight lines: RRT-Connect queries
+    AC[E // 4: 3 * E // 4, 3, 1], AC[E // 4: 3 * E // 4, 3, 3] = 1.0, -1.0
+    ACt = torch.tensor(AC, device="cuda")
+    runs = {}
+    for mode in ("lockstep", "async"):
+        env = make_env(ENV, E, seed=12, max_episode_steps=1000)
+        env.reset()
+        ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.15, max_nodes=512, max_path=128, num_trials=10, async_planner=(mode == "async")))
+        seq = [[] for _ in range(E)]
+        calls = n_sitting = 0
+        while min(len(q) for q in seq) < T:
+            te = ro.t_env.clamp(max=T - 1)
+            ac = ACt[torch.arange(E, device="cuda"), te].contiguous()
+            out = ro.agent_step(ac)
+            st = out["stepped"].cpu().numpy()
+            rows = np.concatenate([out["rew"].cpu().numpy()[:, None], out["done"].cpu().numpy()[:, None].astype(np.float64),
+                                   out["intra_steps"].cpu().numpy()[:, None].astype(np.float64), env.qpos.cpu().numpy()[:, :9],
+                                   out["ac"].cpu().numpy()], axis=1)
+            for e in np.where(st)[0]:
+                seq[e].append(rows[e])
+            n_sitting += int((~st).sum())
+            calls += 1
+            assert calls < 200
+        runs[mode] = (np.array([np.array(q[:T]) for q in seq]), calls, n_sitting, {k: v.clone() for k, v in ro.counters.items()})
+    a, b = runs["lockstep"], runs["async"]
+    assert a[2] == 0 and a[1] == T
+    assert np.array_equal(_bits(a[0]), _bits(b[0]))
+    assert int(a[3]["mp"].sum()) > 0 and int(a[3]["mp_fail"].sum()) > 0      # RRT-Connect was exercised, both outcomes
+
+
 def test_pullback_kernel_equals_host_form(oracle_mod):
     """`mopa_pullback_batch` (one launch) against `handle_invalid_target_batch` (torch ops + one validity launch per
     trial, itself the batched form of rl/mopa_rollouts.py:133-143): same targets, trial counts and verdicts, bit for bit."""

@@ -17,7 +17,7 @@ def wrap(obj, name):
     setattr(obj, name, g)
 for n in ("_densify",): wrap(ro, n)
 ro.timing = T
-wrap(ro.bp, "plan"); wrap(R, "simple_interpolate_batch"); wrap(R, "handle_invalid_target_batch")
+wrap(ro.bp, "plan"); wrap(R, "simple_interpolate_batch")
 wrap(ro.main if hasattr(ro, "main") else ro, "plan") if False else None
 gen = torch.Generator(device=env.device); gen.manual_seed(1)
 for t in range(4):

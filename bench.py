@@ -289,7 +289,11 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     n_env_steps = n_agent_steps = 0
     t0 = time.perf_counter()
     for t in range(agent_steps):
+        _c0 = time.perf_counter()
         out = one(t + 1)
+        if os.environ.get("MOPA_BENCH_TRACE"):
+            torch.cuda.current_stream().synchronize()
+            print(f"[rollout {env_name} async={async_planner}] call {t}: {(time.perf_counter() - _c0) * 1e3:.1f} ms, jobs in flight {len(ro._jobs)}", file=sys.stderr)
         st = out["stepped"]
         n_agent_steps += int(st.sum().item())
         n_env_steps += int(((out["intra_steps"] + 1) * st).sum().item())
@@ -582,8 +586,8 @@ def main():
     if not args.no_rollout:
         if world == 1:
             ro["rollout"] = rollout_section(torch, ENV, args.envs, device, 3)
-            ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 20, async_planner=True)
-        ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 20, world, async_planner=True)
+            ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 40, async_planner=True)
+        ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 40, world, async_planner=True)
     if rank == 0:
         out.update(ro)
         print(json.dumps(out))

@@ -66,7 +66,7 @@ class RolloutConfig:
     # MoPA + IK action space (config/__init__.py --use_ik_target / --ik_target; rl/trainer.py:93-125): the policy outputs a
     # Cartesian displacement of the ik_target site (3) + a rotation quaternion (4) [+ the gripper entry]
     async_planner: bool = False       # RRT-Connect on side streams; envs waiting for a query sit out (see agent_step)
-    planner_streams: int = 4
+    planner_streams: int = 2          # RRT-Connect jobs in flight at most (async_planner)
     use_ik_target: bool = False
     ik_target: str = "grip_site"
     min_world_size: tuple = (-1.2, -1.2, 0.0)        # env/sawyer/sawyer.py:52-53
@@ -139,6 +139,7 @@ class BatchMoPARollout:
         self._t = 0
         self.busy = torch.zeros(self.E, dtype=torch.bool, device=dev)        # env waits for an RRT-Connect query (async_planner)
         self._jobs = []
+        self._pool = []           # (cur, target, env ids) of blocked envs waiting for the next RRT-Connect launch
         self._streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, self.cfg.planner_streams))] if self.cfg.async_planner else []
         self._next_stream = 0
         self.main_iters = max(1, int(round(self.cfg.timelimit * ITERS_PER_SECOND)))
@@ -528,15 +529,23 @@ class BatchMoPARollout:
                 blocked = torch.nonzero(~succ).flatten()
                 if len(blocked):
                     # ---- the blocked ones go to RRT-Connect; lock-step waits for it below, async_planner does not ----
-                    side = None
-                    if cfg.async_planner:
-                        side = self._streams[self._next_stream % len(self._streams)]
-                        self._next_stream += 1
                     bid = ids[blocked].contiguous()
-                    self._jobs.append(self._rrt_launch(cur_v[blocked].contiguous(), tgt_v[blocked].contiguous(), bid, side))
+                    self._pool.append((cur_v[blocked].contiguous(), tgt_v[blocked].contiguous(), bid))
                     self.busy[bid] = True
                     self._pend_ob[bid] = prev_ob[bid]
                     self._pend_ac[bid] = ac_tr[bid]
+        if self._pool:
+            # One K3 launch takes about as long for 40 queries as for 4000 (its time is the latency of the slowest query), so the
+            # waiting envs of several calls share a launch: a job starts only when a side stream has no job in flight.
+            side = None
+            if cfg.async_planner:
+                used = {j["stream"] for j in self._jobs}
+                free = [st for st in self._streams if st not in used]
+                side = free[0] if free else None
+            if side is not None or not cfg.async_planner:
+                cu, tg, bi = (torch.cat([p[k] for p in self._pool]).contiguous() for k in range(3))
+                self._pool = []
+                self._jobs.append(self._rrt_launch(cu, tg, bi, side))
         # ---- RRT-Connect jobs that are done (lock-step: all of them) ----
         finished = torch.zeros(E, dtype=torch.bool, device=dev)
         still = []
@@ -598,7 +607,7 @@ class BatchMoPARollout:
         return res
 
     def drain(self):
-        """wait for every RRT-Connect query in flight (async_planner); their envs complete their step in the next agent_step"""
+        """wait for every RRT-Connect launch in flight (async_planner); their envs complete their step in a following agent_step"""
         for job in self._jobs:
             if job["event"] is not None:
                 job["event"].synchronize()

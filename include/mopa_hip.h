@@ -127,6 +127,9 @@ typedef struct MopaPlanParams {
                                       lets a caller plan for a compacted subset of its envs with the streams of the full set */
     const uint64_t *seeds_dev;     /* mopa_plan_batch only, nullable: explicit seed per query (device pointer, [E]) instead of
                                       `seed` -- queries of envs that are at different steps of their own rollouts in one launch */
+    int32_t max_workgroups;        /* mopa_plan_batch only: cap on the persistent workgroups of the launch (0 = as many as the chip
+                                      holds).  A planner workgroup keeps ~70 KB of LDS for as long as queries are left; a launch that
+                                      shares the GPU with other streams' kernels (asynchronous rollouts) leaves them room this way */
 } MopaPlanParams;
 
 const char *mopa_last_error(void);

@@ -66,7 +66,9 @@ class RolloutConfig:
     # MoPA + IK action space (config/__init__.py --use_ik_target / --ik_target; rl/trainer.py:93-125): the policy outputs a
     # Cartesian displacement of the ik_target site (3) + a rotation quaternion (4) [+ the gripper entry]
     async_planner: bool = False       # RRT-Connect on side streams; envs waiting for a query sit out (see agent_step)
-    planner_streams: int = 2          # RRT-Connect jobs in flight at most (async_planner)
+    planner_streams: int = 3          # RRT-Connect launches in flight at most (async_planner)
+    planner_job_cap: int = 2048       # queries per asynchronous launch at most (the rest waits for the next free stream)
+    planner_workgroups: int = 256     # persistent workgroups of an asynchronous launch (leaves LDS to the other streams' kernels)
     use_ik_target: bool = False
     ik_target: str = "grip_site"
     min_world_size: tuple = (-1.2, -1.2, 0.0)        # env/sawyer/sawyer.py:52-53
@@ -235,7 +237,7 @@ class BatchMoPARollout:
             with torch.cuda.stream(stream):
                 job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=self.main_iters, max_nodes=cfg.max_nodes,
                                                                           max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds,
-                                                                          stream=stream)
+                                                                          stream=stream, max_workgroups=cfg.planner_workgroups)
                 for t in (cur_f, target_f, ids, seeds):
                     t.record_stream(stream)
                 job["event"] = torch.cuda.Event()
@@ -254,6 +256,8 @@ class BatchMoPARollout:
         With `wait` every stage is waited for (lock-step); otherwise a stage whose launch has not finished returns False."""
         torch = _torch()
         cfg, n = self.cfg, self.n
+        if job["stage"] == "split":
+            return self._rrt_join(job, wait)
         while True:
             if job["event"] is not None:
                 if wait:
@@ -261,7 +265,10 @@ class BatchMoPARollout:
                 elif not job["event"].query():
                     return False
             plen_h, st_h = job["plen"].cpu().numpy(), job["status"].cpu().numpy()
+            if job["stage"] == "rrt" and len(plen_h) > 64 and "bucketed" not in job:
+                return self._rrt_split(job, plen_h)
             path_h = job["path"][:, :max(1, int(plen_h.max()))].cpu().numpy()      # the [max_path] tail of every row is unused
+            path_h[np.arange(path_h.shape[1])[None, :] >= plen_h[:, None]] = 0.0   # ... and holds whatever the allocator left
             if job["stage"] == "rrt":
                 cur_h = job["cur"].cpu().numpy()
                 job["ids_h"], job["steps_h"] = job["ids"].cpu().numpy(), job["steps"].cpu().numpy()
@@ -309,6 +316,45 @@ class BatchMoPARollout:
                 return self._rrt_done(job)
             self._fallback_launch(job, "main")
 
+    _BUCKETS = (6, 12, 24, 48)
+
+    def _rrt_split(self, job, plen_h):
+        """A finished launch's paths are post-processed as padded [rows, longest path, nq] arrays; a few long paths among many
+        short ones would make that mostly padding.  Split the job's rows by path length into sub-jobs (each padded to its own
+        longest path) and advance those; job["result"] is put together from theirs."""
+        torch = _torch()
+        edges = np.searchsorted(np.array(self._BUCKETS), plen_h, side="left")
+        subs, result_rows = [], []
+        for b in np.unique(edges):
+            rows = np.nonzero(edges == b)[0]
+            rt = torch.as_tensor(rows, device=job["path"].device)
+            L = max(1, int(plen_h[rows].max()))
+            sub = {k: job[k][rt] for k in ("ids", "cur", "target", "steps", "plen", "status")}
+            sub.update(path=job["path"][rt, :L], event=None, stage="rrt", stream=job["stream"], bucketed=True)
+            subs.append(sub)
+            result_rows.append(rows)
+        job["subs"], job["sub_rows"], job["stage"] = subs, result_rows, "split"
+        return self._rrt_join(job, wait=job["event"] is None)
+
+    def _rrt_join(self, job, wait):
+        done = True
+        for sub in job["subs"]:
+            if "result" not in sub:
+                done &= bool(self._rrt_advance(sub, wait))
+        if not done:
+            return False
+        M, nq = len(job["plen"]), self.nq
+        L = max(s["result"][0].shape[1] for s in job["subs"])
+        traj, ln = np.zeros((M, L, nq)), np.zeros(M, dtype=np.int64)
+        flags = [np.zeros(M, dtype=bool) for _ in range(3)]
+        for sub, rows in zip(job["subs"], job["sub_rows"]):
+            tr, l, *fl = sub["result"]
+            traj[rows, :tr.shape[1]], ln[rows] = tr, l
+            for f, g in zip(flags, fl):
+                f[rows] = g
+        job["result"] = (traj, ln) + tuple(flags)
+        return True
+
     def _fallback_launch(self, job, stage):
         torch = _torch()
         cfg = self.cfg
@@ -330,7 +376,7 @@ class BatchMoPARollout:
             with torch.cuda.stream(stream):
                 job["path"], job["plen"], job["status"], _ = scene_bp.plan(starts, ends, max_iters=iters, max_nodes=cfg.max_nodes,
                                                                            max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds,
-                                                                           stream=stream)
+                                                                           stream=stream, max_workgroups=cfg.planner_workgroups)
                 job["keep"] = (starts, ends, ids, seeds)
                 job["event"] = torch.cuda.Event()
                 job["event"].record(stream)
@@ -545,6 +591,10 @@ class BatchMoPARollout:
             if side is not None or not cfg.async_planner:
                 cu, tg, bi = (torch.cat([p[k] for p in self._pool]).contiguous() for k in range(3))
                 self._pool = []
+                if cfg.async_planner and len(bi) > cfg.planner_job_cap:
+                    c = cfg.planner_job_cap
+                    self._pool = [(cu[c:].contiguous(), tg[c:].contiguous(), bi[c:].contiguous())]
+                    cu, tg, bi = cu[:c].contiguous(), tg[:c].contiguous(), bi[:c].contiguous()
                 self._jobs.append(self._rrt_launch(cu, tg, bi, side))
         # ---- RRT-Connect jobs that are done (lock-step: all of them) ----
         finished = torch.zeros(E, dtype=torch.bool, device=dev)

@@ -13,7 +13,7 @@ def wrap(obj, name):
     def g(*a, **k):
         t0 = time.perf_counter(); r = f(*a, **k); T[name] = T.get(name, 0) + time.perf_counter() - t0; return r
     setattr(obj, name, g)
-for n in ("_rrt_advance", "_rrt_launch", "_densify_cut", "_fallback_launch", "_merge_paths"): wrap(ro, n)
+for n in ("_rrt_advance", "_rrt_finish", "plan", "ik_displacement", "_rrt_launch", "_densify_cut", "_fallback_launch", "_merge_paths"): wrap(ro, n)
 _v = ro._valid
 def _valid_t(q):
     t0 = time.perf_counter(); r = _v(q); t1 = time.perf_counter(); r2 = r.cpu(); t2 = time.perf_counter()

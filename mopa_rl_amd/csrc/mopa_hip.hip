@@ -90,6 +90,7 @@ struct SceneHdr {
     // double-blob offsets
     int o_mb_pos, o_mb_quat, o_sf_pos, o_sf_quat, o_sf_mat, o_mj_axis, o_mj_pos, o_mj_ref;
     int o_g_lpos, o_g_lquat, o_g_rbound, o_g_rec, o_act_lo, o_act_hi, o_act_ext;
+    int o_act_ref, o_act_hinge;   // per active joint value slot: the joint's reference value (doubles), 1 = hinge (ints)
     int o_g_aabb;   // [ng][3] world-AABB half extents of static geoms (second-stage cull), zeros for moving geoms
     // int-blob offsets
     int o_mb_parent, o_mb_jntadr, o_mb_jntnum, o_mj_type, o_mj_qsrc, o_g_type, o_g_slot, o_g_mb;
@@ -839,8 +840,9 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     if (!gp_word_mesh.empty()) build_lists(2, t5_padr, t5_pnum, t5_word);
 
     // v5: FP32 broad-phase table, one 32-byte entry per (owner geom, partner) pair:
-    //   [0..2] partner centre (static partners) / a point of the plane, [3] partner bounding radius,
-    //   [4..6] world-AABB half extents of a static partner / the plane normal,
+    //   [0..2] partner centre (static partners) / a point of the plane,
+    //   [3] (owner radius + eps + partner radius)^2 / for a plane: owner radius + eps,
+    //   [4..6] world-AABB half extents of a static partner + owner radius + eps / the plane normal,
     //   [7] flags: bits 0..13 = low bits of gp_word (partner gid, code, cur_is_g2, pmov), 14..21 partner slot, 30 plane
     // Within a geom's range the entries are ordered [moving partners | static non-plane partners | planes] (the kernel
     // runs one branch-free loop per group); the group sizes follow the table: tab[8 n_gp + slot] = nmov | nstat<<8 | nplane<<16.
@@ -866,18 +868,24 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
                     const int w = t5_word[p];
                     const int pg = w & 0xff, pmov = (w >> 13) & 1;
                     int32_t *te = &gp_tab[8 * dst++];
-                    te[3] = f2i(g_rbound[pg]);
+                    // the owner's inflated radius is folded into the entry (an entry belongs to one owner geom): FP32
+                    // arithmetic here = what the kernel would do per pair and state
+                    const float rg = (float)g_rbound[mg_geom[mslot]] + kCullEps;
+                    auto ff2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
+                    const float rs = rg + (float)g_rbound[pg];
+                    te[3] = ff2i(rs * rs);
                     int flags = w & 0x3fffff;    // gp_word already carries the slot in bits 14..21
                     if (!pmov) {
                         const double *rec = &g_rec[(size_t)kGeomStride * pg];
                         te[0] = f2i(rec[GO_POS]); te[1] = f2i(rec[GO_POS + 1]); te[2] = f2i(rec[GO_POS + 2]);
                         if (m.geom_type[pg] == G_PLANE) {
                             te[4] = f2i(rec[GO_MAT + 2]); te[5] = f2i(rec[GO_MAT + 5]); te[6] = f2i(rec[GO_MAT + 8]);
+                            te[3] = ff2i(rg);
                             flags |= 1 << 30;
                         } else {
                             double H[3];
                             static_aabb_half(m.geom_type[pg], rec, g_rbound[pg], H);
-                            te[4] = f2i(H[0]); te[5] = f2i(H[1]); te[6] = f2i(H[2]);
+                            te[4] = ff2i((float)H[0] + rg); te[5] = ff2i((float)H[1] + rg); te[6] = ff2i((float)H[2] + rg);
                         }
                     }
                     te[7] = flags;
@@ -958,6 +966,17 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.o_mg_geom = B.add_i(mg_geom); h.o_chain_adr = B.add_i(chain_adr); h.o_chain_len = B.add_i(chain_len);
     h.o_chain_items = B.add_i(chain_items); h.o_pairs = B.add_i(pk); h.o_pq_adr = B.add_i(pq_adr);
     h.o_act_adr = B.add_i(act_adr); h.o_act_so2 = B.add_i(act_so2);
+    {
+        std::vector<double> act_ref(8, 0.0);
+        std::vector<int32_t> act_hinge(8, 0);
+        for (int j = 0; j < nmj; j++)
+            if (mj_qsrc[j] >= 0 && mj_qsrc[j] < na && mj_qsrc[j] < 8) {
+                act_ref[mj_qsrc[j]] = mj_ref[j];
+                act_hinge[mj_qsrc[j]] = mj_type[j] == J_HINGE;
+            }
+        h.o_act_ref = B.add_d(act_ref);
+        h.o_act_hinge = B.add_i(act_hinge);
+    }
     h.n_save = n_save; h.n_gp = (int)t5_word.size();
     h.o_mb_load = B.add_i(mb_load); h.o_mb_save = B.add_i(mb_save); h.o_mb_mgadr = B.add_i(mb_mgadr); h.o_mb_mgnum = B.add_i(mb_mgnum);
     h.o_mg_padr = B.add_i(mg_padr); h.o_mg_pnum = B.add_i(mg_pnum); h.o_mg_store = B.add_i(mg_store); h.o_gp_word = B.add_i(gp_word);

@@ -66,9 +66,11 @@ class RolloutConfig:
     # MoPA + IK action space (config/__init__.py --use_ik_target / --ik_target; rl/trainer.py:93-125): the policy outputs a
     # Cartesian displacement of the ik_target site (3) + a rotation quaternion (4) [+ the gripper entry]
     async_planner: bool = False       # RRT-Connect on side streams; envs waiting for a query sit out (see agent_step)
-    planner_streams: int = 3          # RRT-Connect launches in flight at most (async_planner)
+    planner_streams: int = 2          # RRT-Connect launches in flight at most (async_planner)
     planner_job_cap: int = 2048       # queries per asynchronous launch at most (the rest waits for the next free stream)
-    planner_workgroups: int = 256     # persistent workgroups of an asynchronous launch (leaves LDS to the other streams' kernels)
+    planner_workgroups: int = 64      # persistent workgroups of an asynchronous launch: a planner wave holds ~370 registers, no
+                                      # validity wave (226) fits next to it on a SIMD, so launches that took every CU would stall
+                                      # the main stream's kernels for their whole bulk phase
     use_ik_target: bool = False
     ik_target: str = "grip_site"
     min_world_size: tuple = (-1.2, -1.2, 0.0)        # env/sawyer/sawyer.py:52-53
@@ -113,6 +115,20 @@ def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30):
     return extra
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_streams(dev, n):
+    """The planner's side streams, shared by every rollout object of the process: the GPU runs only a few hardware queues
+    side by side (4 by default), streams beyond that share a queue with another stream and a 48 ms planner launch then sits
+    in front of the main stream's kernels -- so streams are created once per device and handed out again."""
+    torch = _torch()
+    pool = _SIDE_STREAMS.setdefault(str(dev), [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=dev))
+    return pool[:n]
+
+
 class BatchMoPARollout:
     def __init__(self, env, cfg: Optional[RolloutConfig] = None):
         torch = _torch()
@@ -142,7 +158,7 @@ class BatchMoPARollout:
         self.busy = torch.zeros(self.E, dtype=torch.bool, device=dev)        # env waits for an RRT-Connect query (async_planner)
         self._jobs = []
         self._pool = []           # (cur, target, env ids) of blocked envs waiting for the next RRT-Connect launch
-        self._streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, self.cfg.planner_streams))] if self.cfg.async_planner else []
+        self._streams = _side_streams(dev, max(1, self.cfg.planner_streams)) if self.cfg.async_planner else []
         self._next_stream = 0
         self.main_iters = max(1, int(round(self.cfg.timelimit * ITERS_PER_SECOND)))
         self.simple_iters = max(1, int(round(self.cfg.simple_planner_timelimit * ITERS_PER_SECOND)))
@@ -266,7 +282,7 @@ class BatchMoPARollout:
                     return False
             plen_h, st_h = job["plen"].cpu().numpy(), job["status"].cpu().numpy()
             if job["stage"] == "rrt" and len(plen_h) > 64 and "bucketed" not in job:
-                return self._rrt_split(job, plen_h)
+                return self._rrt_split(job, plen_h, wait)
             path_h = job["path"][:, :max(1, int(plen_h.max()))].cpu().numpy()      # the [max_path] tail of every row is unused
             path_h[np.arange(path_h.shape[1])[None, :] >= plen_h[:, None]] = 0.0   # ... and holds whatever the allocator left
             if job["stage"] == "rrt":
@@ -318,7 +334,7 @@ class BatchMoPARollout:
 
     _BUCKETS = (6, 12, 24, 48)
 
-    def _rrt_split(self, job, plen_h):
+    def _rrt_split(self, job, plen_h, wait):
         """A finished launch's paths are post-processed as padded [rows, longest path, nq] arrays; a few long paths among many
         short ones would make that mostly padding.  Split the job's rows by path length into sub-jobs (each padded to its own
         longest path) and advance those; job["result"] is put together from theirs."""
@@ -334,7 +350,7 @@ class BatchMoPARollout:
             subs.append(sub)
             result_rows.append(rows)
         job["subs"], job["sub_rows"], job["stage"] = subs, result_rows, "split"
-        return self._rrt_join(job, wait=job["event"] is None)
+        return self._rrt_join(job, wait)
 
     def _rrt_join(self, job, wait):
         done = True
@@ -511,11 +527,11 @@ class BatchMoPARollout:
         tm = getattr(self, "timing", None)     # optional dict: phase -> seconds (each mark synchronises; profiling only)
         if tm is not None:
             import time as _time
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
             _t = [_time.perf_counter()]
 
             def mark(name):
-                torch.cuda.synchronize()
+                torch.cuda.current_stream().synchronize()    # the main stream only: planner launches on side streams go on
                 now = _time.perf_counter()
                 tm[name] = tm.get(name, 0.0) + now - _t[0]
                 _t[0] = now
@@ -600,7 +616,9 @@ class BatchMoPARollout:
         finished = torch.zeros(E, dtype=torch.bool, device=dev)
         still = []
         for job in self._jobs:
-            if not self._rrt_advance(job, wait=not cfg.async_planner):
+            if not cfg.async_planner:
+                self._rrt_advance(job, wait=True)
+            elif not self._rrt_advance(job, wait=False):
                 still.append(job)
                 continue
             tr_j, ln_j, s_j, v_j, e_j = job["result"]
@@ -661,3 +679,4 @@ class BatchMoPARollout:
         for job in self._jobs:
             if job["event"] is not None:
                 job["event"].synchronize()
+

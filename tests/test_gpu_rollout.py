@@ -201,11 +201,19 @@ def test_pullback_kernel_equals_host_form(oracle_mod):
     tgt[:, :7] = np.clip(tgt[:, :7], pi.jnt_minimum, pi.jnt_maximum)
     tgt[0] = cur[0]                                   # degenerate: target == current state
     c, t = torch.tensor(cur, device="cuda"), torch.tensor(tgt, device="cuda")
-    for num_trials in (100, 3):
+    import os
+    for num_trials in (100, 3, 0):
         want_t, want_n, want_v = handle_invalid_target_batch(bp, c, t, 0.02, num_trials)
-        got_t, got_n, got_v = bp.pullback(c, t, 0.02, num_trials)
-        assert np.array_equal(got_v.cpu().numpy().astype(bool), want_v.cpu().numpy())
-        assert np.array_equal(got_n.cpu().numpy().astype(np.int64), want_n.cpu().numpy())
-        assert np.array_equal(_bits(got_t.cpu().numpy()), _bits(want_t.cpu().numpy()))
+        # both device forms: one wave per env walking its own trials / all candidate rows of all envs through K1 at once
+        for form in ("wave", "batch"):
+            os.environ["MOPA_PULLBACK"] = form
+            try:
+                got_t, got_n, got_v = bp.pullback(c, t, 0.02, num_trials)
+            finally:
+                del os.environ["MOPA_PULLBACK"]
+            assert np.array_equal(got_v.cpu().numpy().astype(bool), want_v.cpu().numpy()), form
+            assert np.array_equal(got_n.cpu().numpy().astype(np.int64), want_n.cpu().numpy()), form
+            assert np.array_equal(_bits(got_t.cpu().numpy()), _bits(want_t.cpu().numpy())), form
+    want_t, want_n, want_v = handle_invalid_target_batch(bp, c, t, 0.02, 3)
     n = want_n.cpu().numpy()
     assert (n > 0).sum() > 30 and (~want_v.cpu().numpy()).sum() >= 0 and n.max() == 3

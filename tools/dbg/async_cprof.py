@@ -1,0 +1,20 @@
+import sys, time, cProfile, pstats; sys.path.insert(0, ".")
+import torch, numpy as np
+from mopa_rl_amd.kinematic_env import make_env
+from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+E = 4096
+env = make_env("SawyerPushObstacle-v0", E, seed=5); env.reset()
+ro = BatchMoPARollout(env, RolloutConfig(async_planner=True))
+gen = torch.Generator(device=env.device); gen.manual_seed(1)
+pr = cProfile.Profile()
+adv = ro._rrt_advance
+def wrapped(job, wait):
+    if job["event"] is not None and not job["event"].query(): return False
+    pr.enable(); r = adv(job, wait); pr.disable(); return r
+ro._rrt_advance = wrapped
+for t in range(80):
+    ac = torch.rand(E, 7, generator=gen, dtype=torch.float64, device=env.device) * 2 - 1
+    out = ro.agent_step(ac)
+    d = out["done"].bool() & out["stepped"]
+    if bool(d.any()): env.reset(d)
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)

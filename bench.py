@@ -256,7 +256,8 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
     env = make_env(env_name, E, device=device, seed=21 + int(os.environ.get("RANK", "0")), max_episode_steps=250)
     env.reset()
-    ro = BatchMoPARollout(env, RolloutConfig(async_planner=async_planner))
+    over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("MOPA_BENCH_ROLLOUT", "").split(",") if kv)}   # A/B knob
+    ro = BatchMoPARollout(env, RolloutConfig(async_planner=async_planner, **over))
     torch.manual_seed(8)
     nn = torch.nn
     ad = env.action_dim
@@ -280,30 +281,33 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         tx.launch(k)
         all_reduce_mean_(grads)
         return out
-    out = one(0)
-    env.reset(out["done"].bool())
+    # untimed calls first: one for lock-step; the asynchronous mode needs ~25 until planner launches start, run and finish
+    # at their steady rate
+    warm = 25 if async_planner else 1
+    for k in range(warm):
+        out = one(k)
+        env.reset(out["done"].bool() & out["stepped"])
     tx.drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    n_env_steps = n_agent_steps = 0
+    n_acc = torch.zeros(2, dtype=torch.int64, device=device)      # agent steps, env steps (read back once, after the loop)
     t0 = time.perf_counter()
     for t in range(agent_steps):
         _c0 = time.perf_counter()
-        out = one(t + 1)
+        out = one(warm + t)
         if os.environ.get("MOPA_BENCH_TRACE"):
             torch.cuda.current_stream().synchronize()
             print(f"[rollout {env_name} async={async_planner}] call {t}: {(time.perf_counter() - _c0) * 1e3:.1f} ms, jobs in flight {len(ro._jobs)}", file=sys.stderr)
         st = out["stepped"]
-        n_agent_steps += int(st.sum().item())
-        n_env_steps += int(((out["intra_steps"] + 1) * st).sum().item())
-        d = out["done"].bool() & st
-        if bool(d.any().item()):
-            env.reset(d)
-    gathered = tx.result(agent_steps)
+        n_acc[0] += st.sum()
+        n_acc[1] += ((out["intra_steps"] + 1) * st).sum()
+        env.reset(out["done"].bool() & st)
+    gathered = tx.result(warm + agent_steps - 1)
     tx.drain()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    n_agent_steps, n_env_steps = int(n_acc[0].item()), int(n_acc[1].item())
     c = {k: int(v.sum().item()) for k, v in ro.counters.items()}
     if world > 1:
         t = torch.tensor([dt, float(n_env_steps), float(n_agent_steps)] + [float(c[k]) for k in sorted(c)], dtype=torch.float64, device=device)
@@ -586,8 +590,8 @@ def main():
     if not args.no_rollout:
         if world == 1:
             ro["rollout"] = rollout_section(torch, ENV, args.envs, device, 3)
-            ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 40, async_planner=True)
-        ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 40, world, async_planner=True)
+            ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 100, async_planner=True)
+        ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 100, world, async_planner=True)
     if rank == 0:
         out.update(ro)
         print(json.dumps(out))

@@ -279,10 +279,10 @@ class BatchKinematicEnv:
             self.has_prev.zero_()
             self.ep_len.zero_()
         else:
-            mk = mask.to(torch.bool)
-            self.qpos[mk] = q[mk]
-            self.has_prev[mk] = 0
-            self.ep_len[mk] = 0
+            mk = mask.to(torch.bool)          # (torch.where, not mask indexing: no host read-back of the count)
+            self.qpos.copy_(torch.where(mk[:, None], q, self.qpos))
+            self.has_prev.copy_(torch.where(mk, torch.zeros_like(self.has_prev), self.has_prev))
+            self.ep_len.copy_(torch.where(mk, torch.zeros_like(self.ep_len), self.ep_len))
         self._launch(None, False, None)
         return self.obs
 

@@ -149,6 +149,28 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
            "plans_per_s": E / dt, "ms_per_batch": dt * 1e3, "consumed_checks_per_s": float(nchk.sum().item()) / dt,
            "success_rate": float((status == 0).float().mean().item()), "mean_path_len": float(plen.float().mean().item()),
            "mean_checks_per_plan": float(nchk.float().mean().item())}
+    # A launch lasts as long as its slowest query while most of the chip idles; launches on different streams
+    # overlap (per-stream scratch), which is how the asynchronous rollouts use the planner: 4 launches of E queries each
+    # (own sample streams: different seeds), each capped to a quarter of the CUs
+    from mopa_rl_amd.rollout import _side_streams
+    streams = _side_streams(device, 2) + [torch.cuda.Stream(device=device), torch.cuda.current_stream()]
+    nl = len(streams)
+
+    def burst():
+        for i, st in enumerate(streams):
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                bp.plan(start, goal, **dict(prm, seed=7 + 13 * i), stream=st, max_workgroups=max(1, torch.cuda.get_device_properties(device).multi_processor_count // nl))
+        for st in streams:
+            torch.cuda.current_stream().wait_stream(st)
+    burst()
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    burst()
+    torch.cuda.synchronize()
+    dtc = _t.perf_counter() - t0
+    out["concurrent"] = {"launches": nl, "queries": nl * E, "ms_total": dtc * 1e3, "plans_per_s": nl * E / dtc,
+                         "note": f"{nl} launches of {E} queries on {nl} streams, each capped to 1/{nl} of the CUs"}
     if with_cpu:
         out["cpu_baseline"] = plan_cpu_baseline(pi, start.cpu().numpy(), goal.cpu().numpy(), prm, status.cpu().numpy(),
                                                 plen.cpu().numpy(), nchk.cpu().numpy())

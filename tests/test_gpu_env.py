@@ -186,3 +186,57 @@ def test_env_abi_argument_errors(torch_mod):
     assert rc == 1 and b"null" in L.mopa_last_error()
     with pytest.raises(_lib.MopaError):
         env.step(torch_mod.zeros(4, 6, dtype=torch_mod.float64, device=env.device))
+
+
+@pytest.mark.parametrize("env_name", ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"])
+@pytest.mark.parametrize("record", [False, True])
+def test_waypoint_execution_forms_agree(env_name, record, torch_mod):
+    """`mopa_env_exec_batch` has two forms: one lane walking an env's waypoints step by step (k_env_exec), and all
+    (env, waypoint) steps side by side from pre-computed states (k_env_exec_pre / _step / _fold).  Same paths (ragged
+    lengths, some ending in `done` half way: short episodes), same discount: every output and all carried state equal,
+    bit for bit."""
+    import os
+    torch = torch_mod
+    from mopa_rl_amd.kinematic_env import make_env
+    E, L = 300, 9
+    outs = {}
+    for form in ("walk", "slots"):
+        env = make_env(env_name, E, seed=3, max_episode_steps=6)
+        env.reset()
+        g = torch.Generator(device=env.device)
+        g.manual_seed(11)
+        # a couple of ordinary steps first so that prev_state / has_prev / ep_len are not at their reset values everywhere
+        for _ in range(2):
+            a = torch.rand(E, env.action_dim, generator=g, dtype=torch.float64, device=env.device) * 2 - 1
+            env.step(a, is_planner=False)
+        env.reset(torch.arange(E, device=env.device) % 3 == 0)
+        steps = 0.04 * (torch.rand(E, L, env.n_arm, generator=g, dtype=torch.float64, device=env.device) * 2 - 1)
+        traj = env.qpos[:, None, :].repeat(1, L, 1)
+        traj[:, :, :env.n_arm] += torch.cumsum(steps, dim=1)
+        plen = torch.randint(0, L + 1, (E,), generator=g, device=env.device, dtype=torch.int64)
+        disc = torch.tensor([0.99 ** k for k in range(L)], dtype=torch.float64, device=env.device)
+        rew = torch.rand(E, generator=g, dtype=torch.float64, device=env.device)
+        done = torch.zeros(E, dtype=torch.uint8, device=env.device)
+        intra = torch.zeros(E, dtype=torch.int64, device=env.device)
+        extra = (torch.rand(E, generator=g, dtype=torch.float64, device=env.device) * 2 - 1) if env.action_dim > env.n_arm else None
+        rec = None
+        if record:
+            rec = {"ob": torch.zeros(E, L, env.obs.shape[1], dtype=torch.float64, device=env.device),
+                   "meta_rew": torch.zeros(E, L, dtype=torch.float64, device=env.device),
+                   "done": torch.zeros(E, L, dtype=torch.uint8, device=env.device),
+                   "n_exec": torch.zeros(E, dtype=torch.int64, device=env.device)}
+        os.environ["MOPA_ENV_EXEC"] = form
+        try:
+            env.exec_trajectories(traj.contiguous(), plen, disc, rew, done, intra, rec=rec, last_extra=extra)
+        finally:
+            del os.environ["MOPA_ENV_EXEC"]
+        torch.cuda.synchronize()
+        o = {"qpos": env.qpos, "prev": env.prev_state, "has_prev": env.has_prev, "ep_len": env.ep_len, "obs": env.obs, "reward": env.reward,
+             "done": env.done, "success": env.success, "smdp_rew": rew, "smdp_done": done, "intra": intra}
+        if rec:
+            o.update({"rec_" + k: v for k, v in rec.items()})
+        outs[form] = {k: v.cpu().numpy().copy() for k, v in o.items()}
+    assert outs["walk"]["smdp_done"].sum() > 10 and (outs["walk"]["intra"] > 2).sum() > 50
+    for k in outs["walk"]:
+        a, b = outs["walk"][k], outs["slots"][k]
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), k

@@ -213,6 +213,9 @@ class BatchKinematicEnv:
         self._gen.manual_seed(int(seed))
         self._qpos0 = torch.tensor(self.model.qpos0, dtype=f64, device=dev)
         self._init_arm = torch.tensor(self.spec.init_qpos, dtype=f64, device=dev)
+        row = np.array(self.model.qpos0, dtype=np.float64)
+        row[np.asarray(self.facts.arm_qpos_idx, dtype=np.int64)] = np.asarray(self.spec.init_qpos, dtype=np.float64)
+        self.init_qpos_row = row            # qpos0 with the arm at the env's init_qpos: the reset pose without its noise
         self._arm_idx = torch.tensor(f.arm_qpos_idx, dtype=torch.long, device=dev)
         self._jitter_idx = torch.tensor(f.reset_jitter_idx, dtype=torch.long, device=dev)
         self._planner = None

@@ -32,7 +32,7 @@ from typing import Dict, Optional
 import numpy as np
 
 from . import _lib
-from .agent_planning import (JointLimits, action_to_displacement, displacement_to_action, interpolation_steps,
+from .agent_planning import (JointLimits, action_to_displacement, displacement_to_action, interpolation_steps, max_interpolation_steps,
                              is_planner_action, simple_interpolate_batch)
 from .batch import BatchPlanner, _torch
 from .planner import ITERS_PER_SECOND
@@ -157,7 +157,17 @@ class BatchMoPARollout:
         self._t = 0
         self.busy = torch.zeros(self.E, dtype=torch.bool, device=dev)        # env waits for an RRT-Connect query (async_planner)
         self._jobs = []
-        self._pool = []           # (cur, target, env ids) of blocked envs waiting for the next RRT-Connect launch
+        # blocked envs waiting for the next RRT-Connect launch: mask + their (clipped) current state and target
+        self._pool_mask = torch.zeros(self.E, dtype=torch.bool, device=dev)
+        self._q_cur = torch.zeros(self.E, self.nq, dtype=torch.float64, device=dev)
+        self._q_tgt = torch.zeros(self.E, self.nq, dtype=torch.float64, device=dev)
+        self._k_interp = max_interpolation_steps(self.cfg.action_range, self.cfg.ac_scale)
+        self._interp_overflow = torch.zeros((), dtype=torch.bool, device=dev)
+        self._disc = {}
+        # a state that is certainly valid (the env's initial pose): stands in for the rows a launch has no business with
+        self._safe_q = torch.tensor(np.asarray(env.init_qpos_row, dtype=np.float64)[None], device=dev)
+        if not bool(self._valid(self._safe_q)[0]):
+            raise _lib.MopaError("the env's initial pose is not a valid state")
         self._streams = _side_streams(dev, max(1, self.cfg.planner_streams)) if self.cfg.async_planner else []
         self._next_stream = 0
         self.main_iters = max(1, int(round(self.cfg.timelimit * ITERS_PER_SECOND)))
@@ -552,66 +562,67 @@ class BatchMoPARollout:
             a = ac[:, :n].contiguous()
             extra_ac = ac_tr[:, n:env.action_dim]
         is_pl = is_planner_action(a, cfg.omega) & active
-        plan_ok = torch.zeros(E, dtype=torch.bool, device=dev)
-        path_len = torch.zeros(E, dtype=torch.int64, device=dev)
-        traj_pad = torch.zeros(E, 1, self.nq, dtype=torch.float64, device=dev)
-        pl_idx = torch.nonzero(is_pl).flatten()
-        if len(pl_idx):
-            target = cur[pl_idx].clone()
-            if not cfg.use_ik_target:
-                disp = action_to_displacement(a[pl_idx], cfg.ac_scale, cfg.omega, cfg.action_range, cfg.ac_space_type)
-                target[:, :n] += disp
-                # np.clip to the joint limits, unlimited entries restored (:121-131)
-                target = self.limits.clip_target(target)
+        # Everything below works on all E rows with masks -- no index lists, so no host read-back of how many envs take which
+        # branch.  Rows that are not planner actions carry a known-valid dummy state through the validity launches; nothing of
+        # theirs is used.
+        safe = self._safe_q
+        if cfg.use_ik_target:
             # (with use_ik_target the reference never moves target_qpos off curr_qpos -- :113-131 is skipped and
             # `_cart2dispalcement` keeps its result local --, so a planner step plans from the current state to itself: two
             # zero-motion env steps.  Reproduced as is.)
-            if cfg.invalid_target_handling:
-                target, _, tv = self.bp.pullback(cur[pl_idx].contiguous(), target.contiguous(), cfg.step_size, cfg.num_trials)
-                tv = tv.bool()
-            else:
-                tv = self._valid(target)
-            mark("target")
-            self.counters["mp_fail"][pl_idx[~tv]] += 1          # invalid target: success, valid, exact = False, False, True
-            self.counters["invalid"][pl_idx[~tv]] += 1
-            v_idx = torch.nonzero(tv).flatten()
-            if len(v_idx):
-                # ---- SACAgent.plan: straight-line pre-check for all of them in one launch (:198-204) ----
-                ids = pl_idx[v_idx].contiguous()
-                cur_v = self.clip_qpos(cur[ids].contiguous())
-                tgt_v = target[v_idx].contiguous()
-                traj_i, tlen, succ, _ = simple_interpolate_batch(self.bp, cur_v, tgt_v, cfg.ac_scale, self.arm)
-                ok_ids = ids[succ]
-                plan_ok[ok_ids] = True
-                self.counters["interpolation"][ok_ids] += 1
-                traj_pad = torch.zeros(E, traj_i.shape[1], self.nq, dtype=torch.float64, device=dev)
-                traj_pad[ok_ids] = traj_i[succ]
-                path_len[ok_ids] = tlen[succ].to(torch.int64)
-                mark("interpolate")
-                blocked = torch.nonzero(~succ).flatten()
-                if len(blocked):
-                    # ---- the blocked ones go to RRT-Connect; lock-step waits for it below, async_planner does not ----
-                    bid = ids[blocked].contiguous()
-                    self._pool.append((cur_v[blocked].contiguous(), tgt_v[blocked].contiguous(), bid))
-                    self.busy[bid] = True
-                    self._pend_ob[bid] = prev_ob[bid]
-                    self._pend_ac[bid] = ac_tr[bid]
-        if self._pool:
-            # One K3 launch takes about as long for 40 queries as for 4000 (its time is the latency of the slowest query), so the
-            # waiting envs of several calls share a launch: a job starts only when a side stream has no job in flight.
-            side = None
-            if cfg.async_planner:
-                used = {j["stream"] for j in self._jobs}
-                free = [st for st in self._streams if st not in used]
-                side = free[0] if free else None
-            if side is not None or not cfg.async_planner:
-                cu, tg, bi = (torch.cat([p[k] for p in self._pool]).contiguous() for k in range(3))
-                self._pool = []
+            target = cur
+        else:
+            target = cur.clone()
+            target[:, :n] += action_to_displacement(a, cfg.ac_scale, cfg.omega, cfg.action_range, cfg.ac_space_type)
+            target = self.limits.clip_target(target)          # np.clip to the joint limits, unlimited entries restored (:121-131)
+        target = torch.where(is_pl[:, None], target, safe).contiguous()
+        if cfg.invalid_target_handling:
+            target, _, tv = self.bp.pullback(torch.where(is_pl[:, None], cur, safe).contiguous(), target, cfg.step_size, cfg.num_trials)
+            tv = tv.bool()
+        else:
+            tv = self._valid(target)
+        mark("target")
+        bad_target = (is_pl & ~tv).to(torch.int64)       # invalid target: success, valid, exact = False, False, True
+        self.counters["mp_fail"] += bad_target
+        self.counters["invalid"] += bad_target
+        pv = is_pl & tv
+        # ---- SACAgent.plan: straight-line pre-check for all of them in one launch (:198-204) ----
+        cur_v = torch.where(pv[:, None], self.clip_qpos(cur), safe).contiguous()
+        tgt_v = torch.where(pv[:, None], target, safe).contiguous()
+        traj_i, tlen, succ, nst = simple_interpolate_batch(self.bp, cur_v, tgt_v, cfg.ac_scale, self.arm, fixed_steps=self._k_interp)
+        self._interp_overflow |= (nst > self._k_interp).any()
+        plan_ok = pv & succ
+        self.counters["interpolation"] += plan_ok.to(torch.int64)
+        traj_pad = torch.where(plan_ok[:, None, None], traj_i, torch.zeros_like(traj_i))
+        path_len = torch.where(plan_ok, tlen.to(torch.int64), torch.zeros_like(tlen, dtype=torch.int64))
+        mark("interpolate")
+        # ---- the blocked ones go to RRT-Connect; lock-step waits for it below, async_planner does not ----
+        blocked = pv & ~succ
+        self._q_cur = torch.where(blocked[:, None], cur_v, self._q_cur)
+        self._q_tgt = torch.where(blocked[:, None], tgt_v, self._q_tgt)
+        self._pool_mask |= blocked
+        self.busy |= blocked
+        self._pend_ob = torch.where(blocked[:, None], prev_ob, self._pend_ob)
+        self._pend_ac = torch.where(blocked[:, None], ac_tr, self._pend_ac)
+        # One K3 launch takes about as long for 40 queries as for 4000 (its time is the latency of the slowest query), so the
+        # waiting envs of several calls share a launch: a job starts only when a side stream has no job in flight (and only
+        # then the waiting envs are listed: the one read-back of this part).
+        side = None
+        if cfg.async_planner:
+            used = {j["stream"] for j in self._jobs}
+            free = [st for st in self._streams if st not in used]
+            side = free[0] if free else None
+        if side is not None or not cfg.async_planner:
+            bi = torch.nonzero(self._pool_mask).flatten()
+            if len(bi):
+                if bool(self._interp_overflow):
+                    raise _lib.MopaError(f"a straight-line pre-check needed more than {self._k_interp} steps (targets further than "
+                                         "action_range from the current state?)")
                 if cfg.async_planner and len(bi) > cfg.planner_job_cap:
-                    c = cfg.planner_job_cap
-                    self._pool = [(cu[c:].contiguous(), tg[c:].contiguous(), bi[c:].contiguous())]
-                    cu, tg, bi = cu[:c].contiguous(), tg[:c].contiguous(), bi[:c].contiguous()
-                self._jobs.append(self._rrt_launch(cu, tg, bi, side))
+                    bi = bi[:cfg.planner_job_cap]
+                bi = bi.contiguous()
+                self._pool_mask[bi] = False
+                self._jobs.append(self._rrt_launch(self._q_cur[bi].contiguous(), self._q_tgt[bi].contiguous(), bi, side))
         # ---- RRT-Connect jobs that are done (lock-step: all of them) ----
         finished = torch.zeros(E, dtype=torch.bool, device=dev)
         still = []
@@ -636,7 +647,7 @@ class BatchMoPARollout:
         self._jobs = still
         mark("plan")
         direct = active & ~is_pl
-        self.counters["rl"][direct] += 1
+        self.counters["rl"] += direct.to(torch.int64)
         sitting = self.busy & ~finished            # still waiting for their query: nothing of theirs is touched
         stepped = ~sitting
         # ---- direct execution (:336-356) and failed plans (:303-334: reward of the current state, one env step) in one launch
@@ -657,16 +668,17 @@ class BatchMoPARollout:
                    "meta_rew": torch.zeros(E, L, dtype=torch.float64, device=dev),
                    "done": torch.zeros(E, L, dtype=torch.uint8, device=dev),
                    "waypoint": traj_pad, "n_exec": torch.zeros(E, dtype=torch.int64, device=dev)}
-        if bool(plan_ok.any()):
-            # one launch: every env walks its own waypoints until its path ends or a step reports done
-            disc = torch.tensor([cfg.discount_factor ** k for k in range(L)], dtype=torch.float64, device=dev)
-            rew, done = rew.contiguous(), done.to(torch.uint8).contiguous()
-            env.exec_trajectories(traj_pad, torch.where(plan_ok, path_len, torch.zeros_like(path_len)).contiguous(), disc,
-                                  rew, done, intra, rec={k: rec[k] for k in ("ob", "meta_rew", "done", "n_exec")} if rec else None,
-                                  last_extra=extra_ac[:, 0].contiguous() if env.action_dim > n else None)
+        # one launch: every env walks its own waypoints until its path ends or a step reports done (envs without a path: length 0)
+        disc = self._disc.get(L)
+        if disc is None:
+            disc = self._disc[L] = torch.tensor([cfg.discount_factor ** k for k in range(L)], dtype=torch.float64, device=dev)
+        rew, done = rew.contiguous(), done.to(torch.uint8).contiguous()
+        env.exec_trajectories(traj_pad.contiguous(), torch.where(plan_ok, path_len, torch.zeros_like(path_len)).contiguous(), disc,
+                              rew, done, intra, rec={k: rec[k] for k in ("ob", "meta_rew", "done", "n_exec")} if rec else None,
+                              last_extra=extra_ac[:, 0].contiguous() if env.action_dim > n else None)
         mark("execute")
         env.has_prev.zero_()                                     # env._reset_prev_state()
-        self.t_env[stepped] += 1
+        self.t_env += stepped.to(torch.int64)
         self._t += 1
         res = {"ob": prev_ob, "ac": ac_tr, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra,
                "is_planner": is_pl | finished, "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok, "stepped": stepped}

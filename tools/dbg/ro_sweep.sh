@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the asynchronous rollout's planner-launch knobs on the bench's own rollout sections (GPU box)
-for c in "planner_workgroups=64,planner_streams=2" "planner_workgroups=64,planner_streams=3" "planner_workgroups=96,planner_streams=2" "planner_workgroups=128,planner_streams=2" "planner_workgroups=48,planner_streams=3,planner_job_cap=1024" "planner_workgroups=96,planner_streams=3,planner_job_cap=4096"; do
+for c in "$@"; do
   MOPA_BENCH_ROLLOUT=$c timeout 200 python bench.py --no-cpu --no-plan --no-env --steps 3 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())

@@ -1,3 +1,4 @@
+"""Times the two forms of mopa_pullback_batch (wave per env / all candidate rows through K1) on 3000 targets (GPU box)."""
 import sys, time, os; sys.path.insert(0, ".")
 import torch, numpy as np
 from mopa_rl_amd import _lib

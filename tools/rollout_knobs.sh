@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B of the asynchronous rollout's planner-launch knobs on the bench's own rollout sections (GPU box)
+# A/B of the asynchronous rollout's planner-launch knobs on the bench's own rollout sections (GPU box):
+#   bash tools/rollout_knobs.sh "planner_workgroups=64,planner_streams=2" "planner_workgroups=96,planner_streams=3" ...
 for c in "$@"; do
   MOPA_BENCH_ROLLOUT=$c timeout 200 python bench.py --no-cpu --no-plan --no-env --steps 3 2>/dev/null | tail -1 | python -c "
 import sys, json

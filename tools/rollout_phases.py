@@ -1,3 +1,5 @@
+"""Per-phase time of asynchronous agent_step calls (target / interpolate / plan / execute; each mark synchronises the main
+stream only) on the GPU box."""
 import sys, time; sys.path.insert(0, ".")
 import torch, numpy as np
 from mopa_rl_amd.kinematic_env import make_env

@@ -1,3 +1,5 @@
+"""Asynchronous rollout with uniform random actions: ms per agent_step call and agent steps/s for given planner-launch
+knobs (GPU box).  python tools/rollout_sweep.py <planner_workgroups> <planner_streams> <planner_job_cap> [env name]"""
 import sys, time; sys.path.insert(0, ".")
 import torch, numpy as np
 from mopa_rl_amd.kinematic_env import make_env

@@ -117,6 +117,7 @@ struct DevBuf {
 struct StreamScratch {
     DevBuf slab;        // lane-per-state kernels: pose slabs of the launch's waves + [profile words | tile counter]
     DevBuf mpr;         // v5: per-wave ring of deferred cylinder pairs
+    DevBuf cen;         // v5, scenes whose FP32 centre table does not fit LDS: the per-wave tables in global memory
     DevBuf mesh_list;   // [0] = count, then the states with a mesh pair past the main pass's broad phase
     size_t slab_waves = 0;
     DevBuf mv_cnt, mv_off, mv_env, mv_q, mv_valid, mv_scan;   // expanded motion validation (mopa_motion.inc)
@@ -863,6 +864,8 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
                 order[grp].push_back(p);
             }
             gp_tab[8 * n5 + mslot] = (int)order[0].size() | ((int)order[1].size() << 8) | ((int)order[2].size() << 16);
+            if (getenv("MOPA_DEBUG"))
+                fprintf(stderr, "[mopa]   geom slot %d: %zu moving + %zu static + %zu plane partners\n", mslot, order[0].size(), order[1].size(), order[2].size());
             size_t dst = (size_t)t5_padr[mslot];
             for (int grp = 0; grp < 3; grp++)
                 for (int p : order[grp]) {
@@ -1092,7 +1095,7 @@ extern "C" void mopa_scene_destroy(MopaScene *S) {
         if (q) (void)hipFree(q);
     for (auto &kv : S->scratch) {
         StreamScratch &sc = kv.second;
-        for (DevBuf *b : {&sc.slab, &sc.mpr, &sc.mesh_list, &sc.mv_cnt, &sc.mv_off, &sc.mv_env, &sc.mv_q, &sc.mv_valid, &sc.mv_scan, &sc.plan_q,
+        for (DevBuf *b : {&sc.slab, &sc.mpr, &sc.cen, &sc.mesh_list, &sc.mv_cnt, &sc.mv_off, &sc.mv_env, &sc.mv_q, &sc.mv_valid, &sc.mv_scan, &sc.plan_q,
                           &sc.plan_p, &sc.plan_ctr, &sc.pb_small, &sc.pb_rows, &sc.pb_act})
             if (b->p) (void)hipFree(b->p);
     }
@@ -1148,6 +1151,7 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             const size_t want = std::max(waves, (size_t)S->n_cu * 2 * kWavesPerBlock);
             HIP_TRY(grow(S, sc.slab, (want * (size_t)(S->hdr.nmg + S->hdr.n_save) * kSlabStride + 16) * sizeof(double)));
             HIP_TRY(grow(S, sc.mpr, want * (size_t)kMprCapV5 * kMprRow * sizeof(double)));
+            HIP_TRY(grow(S, sc.cen, want * (size_t)S->hdr.nmg * 3 * 64 * sizeof(float)));
             sc.slab_waves = want;
         }
         double *const d_slab = sc.slab.as<double>();
@@ -1171,7 +1175,7 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
                       : mesh_list   ? (min_dist ? k_is_valid_v5<true, false, true> : k_is_valid_v5<false, false, true>)
                                     : (min_dist ? k_is_valid_v5<true, false, false> : k_is_valid_v5<false, false, false>);
             hipLaunchKernelGGL(k5, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
-                               (long long)N, (long long)samples_per_env, valid, min_dist, d_slab, env_idx, sc.mpr.as<double>(), mesh_list);
+                               (long long)N, (long long)samples_per_env, valid, min_dist, d_slab, env_idx, sc.mpr.as<double>(), mesh_list, sc.cen.as<float>());
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
                            (long long)samples_per_env, valid, min_dist, d_slab, 0, env_idx, (const long long *)nullptr);

@@ -501,9 +501,48 @@ MOPA_HD V3 normalize3(V3 v) {
 // A mesh geom's record carries, instead of a size, where its convex hull lives: size[0] = offset (in doubles) of the
 // vertex array inside the scene's double blob `aux`, size[1] = number of vertices.
 // [3P] mjccd_support for a mesh: exhaustive search over the hull vertices, first maximum wins.
+// G > 1 (device only): G neighbouring lanes (an aligned group) evaluate the SAME query and share the vertex search -- lane
+// `sub` of the group takes vertices sub, sub + G, ... and the group's (value, index) pairs are folded with "larger value,
+// then lower index", which is the first maximum of the sequential scan.  All G lanes return the same vertex.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad_f64(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int G, bool MAXIMUM>
+__device__ __forceinline__ void coop_fold(double &bd, int &best) {
+    if (G >= 2) {
+        const double od = dpp_quad_f64<0xB1>(bd);               // quad_perm [1,0,3,2]: lane ^ 1
+        const int oi = __builtin_amdgcn_update_dpp(0, best, 0xB1, 0xf, 0xf, false);
+        if ((MAXIMUM ? od > bd : od < bd) || (od == bd && oi < best)) { bd = od; best = oi; }
+    }
+    if (G >= 4) {
+        const double od = dpp_quad_f64<0x4E>(bd);               // quad_perm [2,3,0,1]: lane ^ 2
+        const int oi = __builtin_amdgcn_update_dpp(0, best, 0x4E, 0xf, 0xf, false);
+        if ((MAXIMUM ? od > bd : od < bd) || (od == bd && oi < best)) { bd = od; best = oi; }
+    }
+}
+#endif
+template <int G = 1>
 MOPA_HD V3 mesh_support_local(const double *g, V3 ld, const double *aux) {
     const double *V = aux + (int)g[GO_SIZE];
     const int n = (int)g[GO_SIZE + 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (G > 1) {
+        static_assert(G == 1 || G == 2 || G == 4, "groups are quads or pairs of lanes");
+        const int sub = (int)(threadIdx.x & (G - 1));
+        int best = sub < n ? sub : 0;
+        double bd = dot3(ld, ld3(V + 3 * best));
+        for (int i = best + G; i < n; i += G) {
+            const double d = dot3(ld, ld3(V + 3 * i));
+            if (d > bd) { bd = d; best = i; }
+        }
+        coop_fold<G, true>(bd, best);
+        return ld3(V + 3 * best);
+    }
+#endif
     int best = 0;
     double bd = dot3(ld, ld3(V));
     for (int i = 1; i < n; i++) {
@@ -514,12 +553,12 @@ MOPA_HD V3 mesh_support_local(const double *g, V3 ld, const double *aux) {
 }
 // MESH = true: the instantiation used for primitive-vs-mesh pairs (kept apart so that scenes without meshes run
 // exactly the code they ran before)
-template <bool MESH = false>
+template <bool MESH = false, int G = 1>
 MOPA_HD V3 support_geom(const double *g, int type, V3 dir, const double *aux = nullptr) {
     V3 ld = matT_vec(g + GO_MAT, dir);
     V3 lr;
     if (MESH && type == G_MESH) {
-        lr = mesh_support_local(g, ld, aux);
+        lr = mesh_support_local<G>(g, ld, aux);
     } else if (type == G_CAPSULE) {
         lr.x = ld.x * g[GO_SIZE]; lr.y = ld.y * g[GO_SIZE];
         lr.z = fma(ld.z, g[GO_SIZE], signd(ld.z) * g[GO_SIZE + 1]);
@@ -537,10 +576,10 @@ MOPA_HD V3 support_geom(const double *g, int type, V3 dir, const double *aux = n
     }
     return add3(mat_vec(g + GO_MAT, lr), ld3(g + GO_POS));
 }
-template <bool MESH = false>
+template <bool MESH = false, int G = 1>
 MOPA_HD V3 support_md(const double *g1, int t1, const double *g2, int t2, V3 dir, const double *aux = nullptr) {
     V3 s1 = support_geom<false>(g1, t1, dir);          // meshes have the highest type code: always geom 2
-    V3 s2 = support_geom<MESH>(g2, t2, neg3(dir), aux);
+    V3 s2 = support_geom<MESH, G>(g2, t2, neg3(dir), aux);
     return sub3(s1, s2);
 }
 MOPA_HD V3 portal_dir(V3 v1, V3 v2, V3 v3) { return normalize3(cross3(sub3(v2, v1), sub3(v3, v1))); }
@@ -591,12 +630,12 @@ MOPA_HD double origin_tri_dist2(V3 x0, V3 B, V3 C) {
     return dist;
 }
 // true + depth on intersection
-template <bool MESH = false>
+template <bool MESH = false, int G = 1>
 MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2, double &depth, const double *aux = nullptr) {
     V3 v0 = sub3(ld3(g1 + GO_POS), ld3(g2 + GO_POS));
     if (vec_eq0(v0)) v0.x += kCcdEps * 10.0;
     V3 dir = normalize3(neg3(v0));
-    V3 v1 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
+    V3 v1 = support_md<MESH, G>(g1, t1, g2, t2, dir, aux);
     double dot = dot3(v1, dir);
     if (is_zero(dot) || dot < 0.0) return false;
     dir = cross3(v0, v1);
@@ -606,7 +645,7 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
         return true;
     }
     dir = normalize3(dir);
-    V3 v2 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
+    V3 v2 = support_md<MESH, G>(g1, t1, g2, t2, dir, aux);
     dot = dot3(v2, dir);
     if (is_zero(dot) || dot < 0.0) return false;
     dir = normalize3(cross3(sub3(v1, v0), sub3(v2, v0)));
@@ -619,7 +658,7 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
     int it = 0;
     for (;;) {
         if (++it > kMprPortalMaxIt) return false;
-        v3 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
+        v3 = support_md<MESH, G>(g1, t1, g2, t2, dir, aux);
         dot = dot3(v3, dir);
         if (is_zero(dot) || dot < 0.0) return false;
         bool cont = false;
@@ -638,7 +677,7 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
         dir = portal_dir(v1, v2, v3);
         dot = dot3(dir, v1);
         if (is_zero(dot) || dot > 0.0) break;
-        v4 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
+        v4 = support_md<MESH, G>(g1, t1, g2, t2, dir, aux);
         dot = dot3(v4, dir);
         if (!(is_zero(dot) || dot > 0.0) || portal_reach_tol(v1, v2, v3, v4, dir)) return false;
         expand_portal(v0, v1, v2, v3, v4);
@@ -646,7 +685,7 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
     int iterations = 0;
     for (;;) {
         dir = portal_dir(v1, v2, v3);
-        v4 = support_md<MESH>(g1, t1, g2, t2, dir, aux);
+        v4 = support_md<MESH, G>(g1, t1, g2, t2, dir, aux);
         if (portal_reach_tol(v1, v2, v3, v4, dir) || iterations > kMprMaxIt) {
             depth = sqrt(origin_tri_dist2(v1, v2, v3));
             return true;
@@ -655,23 +694,39 @@ MOPA_HD bool mpr_penetration(const double *g1, int t1, const double *g2, int t2,
         iterations++;
     }
 }
-template <bool MESH = false>
+template <bool MESH = false, int G = 1>
 MOPA_HD double d_convex(const double *A, int ta, const double *B, int tb, const double *aux = nullptr) {
     double depth;
-    if (mpr_penetration<MESH>(A, ta, B, tb, depth, aux)) return -depth;
+    if (mpr_penetration<MESH, G>(A, ta, B, tb, depth, aux)) return -depth;
     return kFar;
 }
 // [3P] mjc_PlaneConvex for a mesh: the hull vertex deepest along -n (first one on ties)
+template <int G = 1>
 MOPA_HD double d_plane_mesh(const double *P, const double *M, const double *aux) {
     const V3 n = col3(P + GO_MAT, 2);
     const V3 ln = matT_vec(M + GO_MAT, n);
     const double *V = aux + (int)M[GO_SIZE];
     const int nv = (int)M[GO_SIZE + 1];
     int best = 0;
-    double bd = dot3(ln, ld3(V));
-    for (int i = 1; i < nv; i++) {
-        const double d = dot3(ln, ld3(V + 3 * i));
-        if (d < bd) { bd = d; best = i; }
+    double bd;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (G > 1) {
+        const int sub = (int)(threadIdx.x & (G - 1));
+        best = sub < nv ? sub : 0;
+        bd = dot3(ln, ld3(V + 3 * best));
+        for (int i = best + G; i < nv; i += G) {
+            const double d = dot3(ln, ld3(V + 3 * i));
+            if (d < bd) { bd = d; best = i; }
+        }
+        coop_fold<G, false>(bd, best);
+    } else
+#endif
+    {
+        bd = dot3(ln, ld3(V));
+        for (int i = 1; i < nv; i++) {
+            const double d = dot3(ln, ld3(V + 3 * i));
+            if (d < bd) { bd = d; best = i; }
+        }
     }
     const V3 w = add3(mat_vec(M + GO_MAT, ld3(V + 3 * best)), ld3(M + GO_POS));
     return dot3(sub3(w, ld3(P + GO_POS)), n);
@@ -711,7 +766,7 @@ MOPA_HD int pair_code(int t1, int t2) {
 // `aux`: the scene's double blob (mesh hull vertices live in it); only the *_MESH codes read it, and only the
 // MESH = true instantiation contains them: scenes without a collidable mesh keep running exactly the code (and
 // register budget) they had before mesh support existed.
-template <bool MESH = false>
+template <bool MESH = false, int G = 1>
 MOPA_HD double geom_dist(int code, const double *A, int ta, const double *B, int tb, const double *aux = nullptr) {
     switch (code) {
         case PC_PLANE_SPHERE: return d_plane_sphere(A, B);
@@ -734,8 +789,8 @@ MOPA_HD double geom_dist(int code, const double *A, int ta, const double *B, int
             if (pre > 1e-9) return kFar;
             return d_convex<false>(A, ta, B, tb);
         }
-        case PC_PLANE_MESH: return MESH ? d_plane_mesh(A, B, aux) : kFar;
-        case PC_CONVEX_MESH: return MESH ? d_convex<MESH>(A, ta, B, tb, aux) : kFar;
+        case PC_PLANE_MESH: return MESH ? d_plane_mesh<G>(A, B, aux) : kFar;
+        case PC_CONVEX_MESH: return MESH ? d_convex<MESH, G>(A, ta, B, tb, aux) : kFar;
         default: return kFar;
     }
 }

@@ -12,7 +12,6 @@
 //   K4 k_env_step      (mopa_env.inc) one lane per env, kinematic env.step
 //   FP64 VALU bound, no MFMA (there is no dense contraction on this path).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cmath>

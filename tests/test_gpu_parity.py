@@ -288,6 +288,63 @@ def test_check_motion_matches_oracle(env, kernel, oracle_mod):
     assert 0 < ov.sum() < n
 
 
+def test_check_motion_large_batch_crosses_scan_chunks(oracle_mod):
+    """The expanded motion path scans the per-segment state counts in blocks of 256 and then the block sums 1024 at a time
+    (mopa_motion.inc): 300 000 segments = 1172 blocks, i.e. more than one pass of the block-sum scan, with ragged counts
+    (zero-length, one-state and long segments mixed) and a last block that is not full.  Verdicts against the oracle."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk("PusherObstacle-v0", oracle_mod)
+    bp = BatchPlanner(sc)
+    n = 300_000
+    qa, row = sample_states(pi, n, 77, "near")
+    rng = np.random.default_rng(5)
+    step = rng.normal(0, 0.03, size=qa.shape) * rng.choice([0.0, 0.2, 1.0, 8.0], size=(n, 1))
+    qb = np.clip(qa + step, pi.jnt_minimum, pi.jnt_maximum)
+    ov = orc.check_motion_batch(qa, qb, row, samples_per_env=n, nthreads=0)
+    v = bp.check_motion(torch.from_numpy(qa).cuda(), torch.from_numpy(qb).cuda(), torch.from_numpy(row).cuda(), samples_per_env=n)
+    torch.cuda.synchronize()
+    assert np.array_equal(v.cpu().numpy(), ov), f"{(v.cpu().numpy() != ov).sum()} motion verdicts differ"
+    assert 0.05 * n < ov.sum() < 0.95 * n
+
+
+def test_plan_results_do_not_depend_on_launch_shape(oracle_mod):
+    """A query's outcome is a function of (start, goal, its seed, its stream id) only: capping the launch's persistent
+    workgroups, giving per-query seeds instead of one seed, or planning a subset of the queries changes nothing."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk("SawyerPushObstacle-v0", oracle_mod)
+    bp = BatchPlanner(sc)
+    E = 96
+    qa, row = sample_states(pi, 6000, 43, "near")
+    ov, _ = orc.is_valid_batch(qa, row, samples_per_env=len(qa))
+    good = qa[ov == 1]
+    starts = np.repeat(row, E, axis=0)
+    goals = starts.copy()
+    starts[:, pi.ref_joint_pos_indexes] = good[:E]
+    goals[:, pi.ref_joint_pos_indexes] = good[E:2 * E]
+    s, g = torch.from_numpy(starts).cuda(), torch.from_numpy(goals).cuda()
+    prm = dict(max_iters=200, max_nodes=256, max_path=128)
+    ids = torch.arange(E, device="cuda", dtype=torch.int64)
+    base = [t.cpu().numpy() for t in bp.plan(s, g, seed=5, env_ids=ids, **prm)]
+    capped = [t.cpu().numpy() for t in bp.plan(s, g, seed=5, env_ids=ids, max_workgroups=3, **prm)]
+    seeds = torch.full((E,), 5, device="cuda", dtype=torch.int64)
+    seeded = [t.cpu().numpy() for t in bp.plan(s, g, seed=999, env_ids=ids, seeds=seeds, **prm)]
+    sub = torch.arange(0, E, 3, device="cuda", dtype=torch.int64)
+    part = [t.cpu().numpy() for t in bp.plan(s[sub].contiguous(), g[sub].contiguous(), seed=5, env_ids=sub.contiguous(), **prm)]
+    torch.cuda.synchronize()
+    assert (base[2] == 0).sum() > E // 4
+
+    def same(x, y):      # (path, path_len, status, n_checks): rows past a path's length are never written
+        for k in (1, 2, 3):
+            assert np.array_equal(x[k], y[k])
+        for e in range(len(x[1])):
+            assert np.array_equal(x[0][e, :x[1][e]].view(np.uint64), y[0][e, :y[1][e]].view(np.uint64))
+    same(base, capped)
+    same(base, seeded)
+    same([np.ascontiguousarray(a[::3]) for a in base], part)
+
+
 @pytest.mark.parametrize("env", ["SawyerPushObstacle-v0", "PusherObstacle-v0"])
 def test_plan_matches_oracle(env, oracle_mod):
     """Same (seed, env id) sample stream => identical tree growth, path, status and check count."""

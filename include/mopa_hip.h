@@ -343,6 +343,39 @@ int mopa_ik_solve_batch(MopaIk *ik, int64_t E, double *qpos_dev /*[E,nq] in/out*
 int mopa_ik_site_pose_batch(MopaIk *ik, int64_t E, const double *qpos_dev /*[E,nq]*/, double *site_pos_dev /*[E,3]*/,
                             double *site_mat_dev /*[E,9]*/, void *stream);
 
+/* ===== planner paths -> executable trajectories (reference motion_planners/sampling_based_planner.py:71-99: un-wrap by
+ * successive differences; rl/sac_agent.py:205-233: densification of long steps by simple_interpolate from the clipped
+ * predecessor).  Three launches around one validity launch; no scene handle (pure arithmetic on caller buffers):
+ *   mopa_paths_unwrap_batch    path rows [M, max_path, nq] as mopa_plan_batch wrote them are replaced IN PLACE by the
+ *                              un-wrapped rows (row 0 = cur); seg_count[q, i] = interpolation steps of the segment
+ *                              row i -> row i+1 (0 = no interpolation needed); n_walk[q] = sum of them; out_len[q] = rows of
+ *                              the final trajectory (0 for queries with status != 0)
+ *   mopa_paths_walk_batch      the interior states of all long segments, query after query at walk_off[q] (exclusive
+ *                              prefix sum of n_walk) -> walk [sum n_walk, nq]; the caller validates them
+ *                              (mopa_is_valid_batch on the rows' active columns, samples_per_env 1, rows as env rows)
+ *   mopa_paths_assemble_batch  out [M, out_rows, nq]: per waypoint its interior states then the waypoint;
+ *                              needs_fallback[q] = 1 when an interior state of q was invalid (the reference then plans
+ *                              that segment with the simple / main planner, rl/sac_agent.py:300-306: left to the caller)
+ * lo_state / hi_state / lo_shrunk / hi_shrunk [nq]: the agent's joint limits and limits +- joint_margin as the float32
+ * arrays the reference holds them in (values widened to double; +-inf for unlimited coordinates) -- `clip_qpos`.
+ * nq <= 64; arm coordinates are qpos[:n_arm]. */
+int mopa_paths_unwrap_batch(int device, int64_t M, int32_t nq, int32_t n_arm, double *path_dev /*[M,max_path,nq] in/out*/,
+                            int32_t max_path, const int32_t *path_len_dev /*[M]*/, const int32_t *status_dev /*[M]*/,
+                            const double *cur_dev /*[M,nq]*/, double ac_scale, int32_t interpolate, const double *lo_state_dev,
+                            const double *hi_state_dev, const double *lo_shrunk_dev, const double *hi_shrunk_dev,
+                            int32_t *seg_count_dev /*[M,max_path]*/, int32_t *n_walk_dev /*[M]*/, int32_t *out_len_dev /*[M]*/,
+                            void *stream);
+int mopa_paths_walk_batch(int device, int64_t M, int32_t nq, int32_t n_arm, const double *path_dev, int32_t max_path,
+                          const int32_t *path_len_dev, const int32_t *out_len_dev, double ac_scale, const double *lo_state_dev,
+                          const double *hi_state_dev, const double *lo_shrunk_dev, const double *hi_shrunk_dev,
+                          const int32_t *seg_count_dev, const int64_t *walk_off_dev /*[M]*/, double *walk_dev /*[sum n_walk,nq]*/,
+                          void *stream);
+int mopa_paths_assemble_batch(int device, int64_t M, int32_t nq, const double *path_dev, int32_t max_path,
+                              const int32_t *path_len_dev, const int32_t *out_len_dev, const int32_t *seg_count_dev,
+                              const int64_t *walk_off_dev, const double *walk_dev /*nullable when no query has interior states*/,
+                              const uint8_t *walk_valid_dev, double *out_dev /*[M,out_rows,nq]*/, int32_t out_rows,
+                              uint8_t *needs_fallback_dev /*[M]*/, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch",
+    "mopa_paths_unwrap_batch", "mopa_paths_walk_batch", "mopa_paths_assemble_batch",
 ]
 
 
@@ -135,6 +136,10 @@ def lib() -> C.CDLL:
                                       vp, vp, vp, vp]
     L.mopa_ik_site_pose_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
     L.mopa_scene_valid_kernel.argtypes = [vp, C.c_int64, C.c_char_p, C.c_int32]
+    i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
+    L.mopa_paths_unwrap_batch.argtypes = [C.c_int, i64, i32, i32, vp, i32, vp, vp, vp, f64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mopa_paths_walk_batch.argtypes = [C.c_int, i64, i32, i32, vp, i32, vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mopa_paths_assemble_batch.argtypes = [C.c_int, i64, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
     _lib = L
     return L
 

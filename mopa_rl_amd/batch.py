@@ -109,3 +109,42 @@ class BatchPlanner:
         _lib.check(_lib.lib().mopa_pullback_batch(self.scene.handle, _ptr(cur), _ptr(out), E, float(step_size), int(num_trials),
                                                   _ptr(trials), _ptr(valid), _stream_handle(stream)))
         return out, trials, valid
+
+
+def postprocess_paths(path, path_len, status, cur, n_arm: int, ac_scale: float, interpolate: bool, limits, is_valid, stream=None):
+    """Planner rows -> executable trajectories on the device (C ABI `mopa_paths_*`): un-wrap by successive differences
+    (reference motion_planners/sampling_based_planner.py:71-99; `path` [M, max_path, nq] is overwritten with the un-wrapped
+    rows), then -- `interpolate` -- the reference's densification of steps longer than ac_scale (rl/sac_agent.py:205-233)
+    with every interior state validated by `is_valid(rows [S, nq]) -> uint8/bool [S]`.
+
+    limits: agent_planning.JointLimits (float32 state limits + margin).  Returns (traj [M, L, nq], length [M] int64 -- 0 for
+    queries with status != 0 --, needs_fallback [M] bool: a long step of that query has an invalid interior state, the
+    reference plans such a step with its fallback planners and the caller has to).  One small read-back (totals)."""
+    torch = _torch()
+    L = _lib.lib()
+    M, max_path, nq = path.shape
+    dev = path.device
+    di = dev.index if dev.index is not None else torch.cuda.current_device()
+    st = _stream_handle(stream)
+    seg = torch.empty(M, max_path, dtype=torch.int32, device=dev)
+    n_walk = torch.empty(M, dtype=torch.int32, device=dev)
+    out_len = torch.empty(M, dtype=torch.int32, device=dev)
+    lim = [t.contiguous() for t in (limits.lo_state, limits.hi_state, limits.lo_shrunk, limits.hi_shrunk)]
+    _lib.check(L.mopa_paths_unwrap_batch(di, M, nq, int(n_arm), _ptr(path), max_path, _ptr(path_len), _ptr(status), _ptr(cur),
+                                         float(ac_scale), int(bool(interpolate)), *[_ptr(t) for t in lim], _ptr(seg), _ptr(n_walk),
+                                         _ptr(out_len), st))
+    walk_off = torch.cumsum(n_walk.to(torch.int64), 0) - n_walk.to(torch.int64)
+    tot_walk, rows = (int(x) for x in torch.stack([n_walk.sum(), out_len.max()]).cpu())
+    rows = max(rows, 1)
+    walk = walk_valid = None
+    if tot_walk > 0:
+        walk = torch.empty(tot_walk, nq, dtype=torch.float64, device=dev)
+        _lib.check(L.mopa_paths_walk_batch(di, M, nq, int(n_arm), _ptr(path), max_path, _ptr(path_len), _ptr(out_len), float(ac_scale),
+                                           *[_ptr(t) for t in lim], _ptr(seg), _ptr(walk_off), _ptr(walk), st))
+        walk_valid = is_valid(walk).to(torch.uint8).contiguous()
+    out = torch.zeros(M, rows, nq, dtype=torch.float64, device=dev)
+    need = torch.zeros(M, dtype=torch.uint8, device=dev)
+    _lib.check(L.mopa_paths_assemble_batch(di, M, nq, _ptr(path), max_path, _ptr(path_len), _ptr(out_len), _ptr(seg), _ptr(walk_off),
+                                           _ptr(walk) if walk is not None else None, _ptr(walk_valid) if walk_valid is not None else None,
+                                           _ptr(out), rows, _ptr(need), st))
+    return out, out_len.to(torch.int64), need.bool()

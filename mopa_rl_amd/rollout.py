@@ -66,8 +66,12 @@ class RolloutConfig:
     # MoPA + IK action space (config/__init__.py --use_ik_target / --ik_target; rl/trainer.py:93-125): the policy outputs a
     # Cartesian displacement of the ik_target site (3) + a rotation quaternion (4) [+ the gripper entry]
     async_planner: bool = False       # RRT-Connect on side streams; envs waiting for a query sit out (see agent_step)
-    planner_streams: int = 2          # RRT-Connect launches in flight at most (async_planner)
+    planner_streams: int = 3          # RRT-Connect launches in flight at most (async_planner)
     planner_job_cap: int = 2048       # queries per asynchronous launch at most (the rest waits for the next free stream)
+    planner_min_job: int = 1024       # queries an asynchronous launch waits for while other launches are in flight
+    device_paths: bool = True         # planner rows -> trajectories (un-wrap, densification) on the device (batch.postprocess_paths);
+                                      # False: the array-operation form on the host (also serves the rare queries whose
+                                      # densification needs the fallback planners)
     planner_workgroups: int = 64      # persistent workgroups of an asynchronous launch: a planner wave holds ~370 registers, no
                                       # validity wave (226) fits next to it on a SIMD, so launches that took every CU would stall
                                       # the main stream's kernels for their whole bulk phase
@@ -284,6 +288,8 @@ class BatchMoPARollout:
         cfg, n = self.cfg, self.n
         if job["stage"] == "split":
             return self._rrt_join(job, wait)
+        if job["stage"] in ("rrt", "device") and cfg.device_paths and self.nq <= 64 and "bucketed" not in job and "unwrapped" not in job:
+            return self._rrt_device(job, wait)
         while True:
             if job["event"] is not None:
                 if wait:
@@ -311,8 +317,11 @@ class BatchMoPARollout:
                     # drops row 0: tr[k] = tr[k-1] + (states[k] - states[k-1]), tr[0] = cur.  np.add.accumulate is that same
                     # strictly sequential sum, for all paths at once (rows past a path's length hold garbage and are cut off).
                     P = path_h[good]
-                    A = np.concatenate([cur_h[good][:, None, :], P[:, 1:] - P[:, :-1]], axis=1)
-                    T = np.add.accumulate(A, axis=1)
+                    if job.get("unwrapped"):       # rows that went through mopa_paths_unwrap_batch already (row 0 = cur)
+                        T = P
+                    else:
+                        A = np.concatenate([cur_h[good][:, None, :], P[:, 1:] - P[:, :-1]], axis=1)
+                        T = np.add.accumulate(A, axis=1)
                     nrow = plen_h[good] - 1
                     job["T"], job["nrow"] = T, nrow
                     if cfg.interpolation and T.shape[1] > 1:
@@ -342,6 +351,57 @@ class BatchMoPARollout:
                 return self._rrt_done(job)
             self._fallback_launch(job, "main")
 
+    def _rrt_device(self, job, wait: bool):
+        """Stage "rrt" with the path post-processing on the device (batch.postprocess_paths: three small launches around one
+        validity launch on the job's stream; one read-back of two totals).  Queries whose densification met an invalid
+        interior state -- they need the fallback planners -- go through the host form as a sub-job, from their un-wrapped
+        rows.  job["result"] then holds device tensors."""
+        import contextlib
+        torch = _torch()
+        cfg = self.cfg
+        if job["stage"] == "rrt":
+            if job["event"] is not None:
+                if wait:
+                    job["event"].synchronize()
+                elif not job["event"].query():
+                    return False
+            ctx = torch.cuda.stream(job["stream"]) if job["stream"] is not None else contextlib.nullcontext()
+            with ctx:
+                from .batch import postprocess_paths
+                out, ln, need = postprocess_paths(job["path"], job["plen"], job["status"], job["cur"], self.n, cfg.ac_scale,
+                                                  cfg.interpolation, self.limits, self._valid, stream=job["stream"])
+                st = job["status"]
+                ok = st == 0           # sentinel rows (sampling_based_planner.py:64-69): -5 goal invalid, -4 no exact solution
+                job["dev"] = [out, ln, ok, st != _lib.PLAN_INVALID_GOAL, st != _lib.PLAN_NO_EXACT]
+                rows = torch.nonzero(need).flatten()
+                if len(rows):
+                    sub = {k: job[k][rows].contiguous() for k in ("ids", "cur", "target", "steps", "plen", "status")}
+                    sub.update(path=job["path"][rows].contiguous(), event=None, stage="rrt", stream=job["stream"], unwrapped=True)
+                    job["sub"], job["sub_rows"] = sub, rows
+                if job["stream"] is not None:
+                    job["event"] = torch.cuda.Event()
+                    job["event"].record(job["stream"])
+            job["stage"] = "device"
+        # stage "device": the launches above (and the sub-job, if any) have to be finished
+        if job["event"] is not None:
+            if wait:
+                job["event"].synchronize()
+            elif not job["event"].query():
+                return False
+        out, ln, ok, v, e = job["dev"]
+        if "sub" in job:
+            if not self._rrt_advance(job["sub"], wait):
+                return False
+            tr_s, ln_s, *_ = job["sub"]["result"]
+            rows = job["sub_rows"]
+            tr_s, ln_s = torch.as_tensor(tr_s, device=out.device), torch.as_tensor(ln_s, device=out.device)
+            if tr_s.shape[1] > out.shape[1]:
+                out = torch.cat([out, torch.zeros(out.shape[0], tr_s.shape[1] - out.shape[1], self.nq, dtype=out.dtype, device=out.device)], dim=1)
+            out[rows, :tr_s.shape[1]] = tr_s
+            ln[rows] = ln_s
+        job["result"] = (out, ln, ok, v, e)
+        return True
+
     _BUCKETS = (6, 12, 24, 48)
 
     def _rrt_split(self, job, plen_h, wait):
@@ -357,6 +417,8 @@ class BatchMoPARollout:
             L = max(1, int(plen_h[rows].max()))
             sub = {k: job[k][rt] for k in ("ids", "cur", "target", "steps", "plen", "status")}
             sub.update(path=job["path"][rt, :L], event=None, stage="rrt", stream=job["stream"], bucketed=True)
+            if job.get("unwrapped"):
+                sub["unwrapped"] = True
             subs.append(sub)
             result_rows.append(rows)
         job["subs"], job["sub_rows"], job["stage"] = subs, result_rows, "split"
@@ -470,21 +532,20 @@ class BatchMoPARollout:
         fi = torch.as_tensor(fail, device=cur.device)
         job = self._rrt_launch(cur[fi].contiguous(), target[fi].contiguous(), env_ids[fi].contiguous())
         tr_j, ln_j, s_j, v_j, e_j = self._rrt_finish(job)
+        s_j, v_j, e_j = (x.cpu().numpy() if hasattr(x, "cpu") else x for x in (s_j, v_j, e_j))
         interpolation[fail] = False
         success[fail], valid[fail], exact[fail] = s_j, v_j, e_j
         traj_t, lens = self._merge_paths(traj_t, lens, tr_j, ln_j, fi)
         return traj_t, lens, success, interpolation, valid, exact
 
     def _merge_paths(self, traj_t, lens, tr_j, ln_j, rows):
-        """write a job's padded host-side trajectories (tr_j [M, L, nq], ln_j [M]; 0 = no path) into rows `rows` (device index
-        tensor) of traj_t / lens"""
+        """write a job's padded trajectories (tr_j [M, L, nq], ln_j [M]; 0 = no path; device tensors or host arrays) into rows
+        `rows` (device index tensor) of traj_t / lens"""
         torch = _torch()
-        if not ln_j.any():
-            return traj_t, lens
-        L = int(ln_j.max())
+        L = int(tr_j.shape[1])
         if L > traj_t.shape[1]:
             traj_t = torch.cat([traj_t, torch.zeros(traj_t.shape[0], L - traj_t.shape[1], self.nq, dtype=traj_t.dtype, device=traj_t.device)], dim=1)
-        traj_t[rows, :L] = torch.as_tensor(tr_j[:, :L], device=traj_t.device)
+        traj_t[rows, :L] = torch.as_tensor(tr_j, device=traj_t.device)
         lens[rows] = torch.as_tensor(ln_j, device=traj_t.device)
         return traj_t, lens
 
@@ -614,7 +675,9 @@ class BatchMoPARollout:
             side = free[0] if free else None
         if side is not None or not cfg.async_planner:
             bi = torch.nonzero(self._pool_mask).flatten()
-            if len(bi):
+            # (a launch costs the host about as much as a call: with several streams free, small pools wait for company
+            # unless nothing at all is in flight)
+            if len(bi) and (not cfg.async_planner or len(bi) >= cfg.planner_min_job or not self._jobs):
                 if bool(self._interp_overflow):
                     raise _lib.MopaError(f"a straight-line pre-check needed more than {self._k_interp} steps (targets further than "
                                          "action_range from the current state?)")

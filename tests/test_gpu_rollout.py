@@ -217,3 +217,39 @@ def test_pullback_kernel_equals_host_form(oracle_mod):
     want_t, want_n, want_v = handle_invalid_target_batch(bp, c, t, 0.02, 3)
     n = want_n.cpu().numpy()
     assert (n > 0).sum() > 30 and (~want_v.cpu().numpy()).sum() >= 0 and n.max() == 3
+
+
+@pytest.mark.parametrize("env_name", ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0"])
+def test_device_path_postprocessing_equals_host_form(env_name):
+    """Planner rows -> trajectories (un-wrap by successive differences, densification of long steps with validated
+    interior states) as the device launches `mopa_paths_*` against the array-operation form on the host, on the results of
+    real RRT-Connect queries (successes, sentinel rows, paths that need densification): same rows, lengths and flags, bit
+    for bit; queries the device form hands to the fallback planners come back through the host form."""
+    import torch
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    E = 192
+    res = {}
+    for dev_paths in (False, True):
+        env = make_env(env_name, E, seed=3)
+        env.reset()
+        # (a long planner range: most path steps exceed ac_scale in some joint and are densified)
+        ro = BatchMoPARollout(env, RolloutConfig(device_paths=dev_paths, timelimit=0.1, range=0.5))
+        g = torch.Generator(device=env.device)
+        g.manual_seed(4)
+        cur = ro.clip_qpos(env.qpos.clone())
+        tgt = cur.clone()
+        tgt[:, :ro.n] += (torch.rand(E, ro.n, generator=g, dtype=torch.float64, device=env.device) * 2 - 1) * 0.45
+        tgt = ro.limits.clip_target(tgt)
+        tgt, _, tv = ro.bp.pullback(cur.contiguous(), tgt.contiguous(), 0.02, 100)
+        ids = torch.arange(E, device=env.device)
+        job = ro._rrt_launch(cur.contiguous(), tgt.contiguous(), ids)
+        tr, ln, s, v, e = ro._rrt_finish(job)
+        conv = lambda x: x.cpu().numpy() if hasattr(x, "cpu") else np.asarray(x)
+        res[dev_paths] = tuple(conv(x) for x in (tr, ln, s, v, e)) + (conv(job["plen"]),)
+    (tr_h, ln_h, s_h, v_h, e_h, pl), (tr_d, ln_d, s_d, v_d, e_d, _) = res[False], res[True]
+    assert np.array_equal(ln_h, ln_d) and np.array_equal(s_h, s_d) and np.array_equal(v_h, v_d) and np.array_equal(e_h, e_d)
+    assert s_h.sum() > E // 3 and ((~s_h).sum() > 0 or env_name != "SawyerPushObstacle-v0")     # Push: sentinel rows too
+    assert (ln_h[s_h] > pl[s_h] - 1).sum() > 20         # densification happened: more rows than planner waypoints
+    for q in range(E):
+        assert np.array_equal(_bits(tr_h[q, :ln_h[q]]), _bits(tr_d[q, :ln_d[q]])), q

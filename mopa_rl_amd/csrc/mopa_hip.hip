@@ -1127,8 +1127,10 @@ static int grid_for(const MopaScene *S, int64_t N) {
 }
 
 // state validity of N states; env row of state i = env_idx ? env_idx[i] : i / samples_per_env
+// n_dev (nullable): the number of states is only known on the device (*n_dev <= N, N then sizes the launch): served by the
+// lane-per-state kernel, which reads it when it starts -- no host read-back between the producer of the states and this launch
 static int launch_is_valid(MopaScene *S, const double *q_active, const double *qpos_env, int64_t N, int64_t samples_per_env,
-                           const int *env_idx, uint8_t *valid, double *min_dist, void *stream) {
+                           const int *env_idx, uint8_t *valid, double *min_dist, void *stream, const long long *n_dev = nullptr) {
     if (!S || !valid || (N > 0 && (!q_active || !qpos_env))) return fail(MOPA_ERR_INVALID_ARG, "null argument");
     if (N < 0 || samples_per_env <= 0) return fail(MOPA_ERR_INVALID_ARG, "N < 0 or samples_per_env <= 0");
     if (N == 0) return MOPA_OK;
@@ -1140,7 +1142,8 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
     // env, e.g. the collision gate of the kinematic env.step) go to the latter.  Measured crossover on MI355X
     // (tools/crossover.py): 8192 states 155 vs 171 us, 12288 states 202 vs 168 us  =>  ~36 states per CU.
     const int64_t v2_min = S->v2_forced ? 64 : std::max<int64_t>(64, (int64_t)S->n_cu * 36);
-    if (S->use_v2 && (N >= v2_min || env_idx)) {
+    if (n_dev && !(S->use_v2 && S->use_v5)) return fail(MOPA_ERR_UNSUPPORTED, "a device-side state count needs the lane-per-state kernel");
+    if (S->use_v2 && (N >= v2_min || env_idx || n_dev)) {
         // one lane per state, 64-state tiles; 2 workgroups per CU keep the pose slab small and L2 resident
         int64_t tiles = (N + 63) / 64;
         int64_t blocks = std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)S->n_cu * 2);
@@ -1174,7 +1177,8 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
                       : mesh_list   ? (min_dist ? k_is_valid_v5<true, false, true> : k_is_valid_v5<false, false, true>)
                                     : (min_dist ? k_is_valid_v5<true, false, false> : k_is_valid_v5<false, false, false>);
             hipLaunchKernelGGL(k5, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
-                               (long long)N, (long long)samples_per_env, valid, min_dist, d_slab, env_idx, sc.mpr.as<double>(), mesh_list, sc.cen.as<float>());
+                               (long long)N, (long long)samples_per_env, valid, min_dist, d_slab, env_idx, sc.mpr.as<double>(), mesh_list, sc.cen.as<float>(),
+                               n_dev);
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
                            (long long)samples_per_env, valid, min_dist, d_slab, 0, env_idx, (const long long *)nullptr);

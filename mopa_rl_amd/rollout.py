@@ -69,6 +69,12 @@ class RolloutConfig:
     planner_streams: int = 3          # RRT-Connect launches in flight at most (async_planner)
     planner_job_cap: int = 2048       # queries per asynchronous launch at most (the rest waits for the next free stream)
     planner_min_job: int = 1024       # queries an asynchronous launch waits for while other launches are in flight
+    planner_first_iters: int = 300    # asynchronous launches first run with this iteration budget; the queries it does not solve
+                                      # (a few %) are launched again with the full budget, among their kind.  A query's outcome
+                                      # is a function of its endpoints and sample stream only, and a budget only ends the loop:
+                                      # the second run retraces the first and goes on, so results are those of one full run --
+                                      # but the many quick queries no longer wait for (or hold wave slots next to) the few that
+                                      # take 2000 iterations.  0: one launch with the full budget
     device_paths: bool = True         # planner rows -> trajectories (un-wrap, densification) on the device (batch.postprocess_paths);
                                       # False: the array-operation form on the host (also serves the rare queries whose
                                       # densification needs the fallback planners)
@@ -163,6 +169,8 @@ class BatchMoPARollout:
         self._jobs = []
         # blocked envs waiting for the next RRT-Connect launch: mask + their (clipped) current state and target
         self._pool_mask = torch.zeros(self.E, dtype=torch.bool, device=dev)
+        self._retry_mask = torch.zeros(self.E, dtype=torch.bool, device=dev)     # ... and those whose first, short launch ran out
+        self.n_retried = torch.zeros((), dtype=torch.int64, device=dev)
         self._q_cur = torch.zeros(self.E, self.nq, dtype=torch.float64, device=dev)
         self._q_tgt = torch.zeros(self.E, self.nq, dtype=torch.float64, device=dev)
         self._k_interp = max_interpolation_steps(self.cfg.action_range, self.cfg.ac_scale)
@@ -251,21 +259,23 @@ class BatchMoPARollout:
         self._t = int(value)
         self.t_env.fill_(int(value))
 
-    def _rrt_launch(self, cur_f, target_f, ids, stream=None):
+    def _rrt_launch(self, cur_f, target_f, ids, stream=None, iters=None):
         """RRT-Connect (K3) for the envs `ids` whose straight line is blocked (:205-209): asynchronous, optionally on a side
         stream.  The sample stream of a query is keyed by (cfg.seed + the env's own step count, env id), so an env's plans do
         not depend on which other envs are planned with it or when."""
         torch = _torch()
         cfg = self.cfg
         seeds = (self.t_env[ids] + cfg.seed).contiguous()
-        job = {"ids": ids, "cur": cur_f, "target": target_f, "steps": self.t_env[ids].clone(), "event": None, "stage": "rrt", "stream": stream}
+        iters = self.main_iters if iters is None else int(iters)
+        job = {"ids": ids, "cur": cur_f, "target": target_f, "steps": self.t_env[ids].clone(), "event": None, "stage": "rrt", "stream": stream,
+               "iters": iters}
         if stream is None:
-            job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=self.main_iters, max_nodes=cfg.max_nodes,
+            job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=iters, max_nodes=cfg.max_nodes,
                                                                       max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds)
         else:
             stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):
-                job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=self.main_iters, max_nodes=cfg.max_nodes,
+                job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=iters, max_nodes=cfg.max_nodes,
                                                                           max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds,
                                                                           stream=stream, max_workgroups=cfg.planner_workgroups)
                 for t in (cur_f, target_f, ids, seeds):
@@ -668,24 +678,34 @@ class BatchMoPARollout:
         # One K3 launch takes about as long for 40 queries as for 4000 (its time is the latency of the slowest query), so the
         # waiting envs of several calls share a launch: a job starts only when a side stream has no job in flight (and only
         # then the waiting envs are listed: the one read-back of this part).
-        side = None
-        if cfg.async_planner:
-            used = {j["stream"] for j in self._jobs}
-            free = [st for st in self._streams if st not in used]
-            side = free[0] if free else None
-        if side is not None or not cfg.async_planner:
-            bi = torch.nonzero(self._pool_mask).flatten()
+        two_phase = cfg.async_planner and 0 < cfg.planner_first_iters < self.main_iters
+        for retry in ((False, True) if two_phase else (False,)):
+            side = None
+            if cfg.async_planner:
+                used = {j["stream"] for j in self._jobs}
+                free = [st for st in self._streams if st not in used]
+                side = free[0] if free else None
+            if side is None and cfg.async_planner:
+                break
+            mask = self._retry_mask if retry else self._pool_mask
+            bi = torch.nonzero(mask).flatten()
             # (a launch costs the host about as much as a call: with several streams free, small pools wait for company
-            # unless nothing at all is in flight)
-            if len(bi) and (not cfg.async_planner or len(bi) >= cfg.planner_min_job or not self._jobs):
+            # unless nothing of their kind is in flight)
+            kind_in_flight = any(j.get("retry", False) == retry for j in self._jobs)
+            min_job = cfg.planner_min_job // 4 if retry else cfg.planner_min_job
+            if len(bi) and (not cfg.async_planner or len(bi) >= min_job or not kind_in_flight):
                 if bool(self._interp_overflow):
                     raise _lib.MopaError(f"a straight-line pre-check needed more than {self._k_interp} steps (targets further than "
                                          "action_range from the current state?)")
-                if cfg.async_planner and len(bi) > cfg.planner_job_cap:
-                    bi = bi[:cfg.planner_job_cap]
+                cap = cfg.planner_job_cap // 4 if retry else cfg.planner_job_cap
+                if cfg.async_planner and len(bi) > cap:
+                    bi = bi[:cap]
                 bi = bi.contiguous()
-                self._pool_mask[bi] = False
-                self._jobs.append(self._rrt_launch(self._q_cur[bi].contiguous(), self._q_tgt[bi].contiguous(), bi, side))
+                mask[bi] = False
+                iters = cfg.planner_first_iters if (two_phase and not retry) else self.main_iters
+                job = self._rrt_launch(self._q_cur[bi].contiguous(), self._q_tgt[bi].contiguous(), bi, side, iters=iters)
+                job["retry"] = retry
+                self._jobs.append(job)
         # ---- RRT-Connect jobs that are done (lock-step: all of them) ----
         finished = torch.zeros(E, dtype=torch.bool, device=dev)
         still = []
@@ -699,6 +719,15 @@ class BatchMoPARollout:
             jid = job["ids"]
             t = lambda x: torch.as_tensor(x, device=dev)
             s_t = t(s_j)
+            if job["iters"] < self.main_iters:
+                # first-phase launch: "no exact solution" may only mean that the short budget ran out -- those queries run
+                # again with the full budget (their envs stay busy); everything else is final
+                again = ~s_t & ~t(e_j)
+                self._retry_mask[jid[again]] = True
+                self.n_retried = self.n_retried + again.sum()
+                keep = ~again
+                jid, s_t = jid[keep], s_t[keep]
+                tr_j, ln_j, v_j, e_j = t(tr_j)[keep], t(ln_j)[keep], t(v_j)[keep], t(e_j)[keep]
             finished[jid] = True
             plan_ok[jid] = s_t
             self.counters["mp"][jid[s_t]] += 1

@@ -157,7 +157,9 @@ def test_async_planner_gives_every_env_the_same_transitions():
     for mode in ("lockstep", "async"):
         env = make_env(ENV, E, seed=12, max_episode_steps=1000)
         env.reset()
-        ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.15, max_nodes=512, max_path=128, num_trials=10, async_planner=(mode == "async")))
+        # (async: a first launch with 60 of the 300 iterations, the queries it does not solve run again with all 300)
+        ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.15, max_nodes=512, max_path=128, num_trials=10, async_planner=(mode == "async"),
+                                                 planner_first_iters=60, planner_min_job=1))
         seq = [[] for _ in range(E)]
         calls = n_sitting = 0
         while min(len(q) for q in seq) < T:
@@ -173,11 +175,13 @@ def test_async_planner_gives_every_env_the_same_transitions():
             n_sitting += int((~st).sum())
             calls += 1
             assert calls < 200
-        runs[mode] = (np.array([np.array(q[:T]) for q in seq]), calls, n_sitting, {k: v.clone() for k, v in ro.counters.items()})
+        runs[mode] = (np.array([np.array(q[:T]) for q in seq]), calls, n_sitting, {k: v.clone() for k, v in ro.counters.items()},
+                      getattr(ro, "n_retried", 0))
     a, b = runs["lockstep"], runs["async"]
     assert a[2] == 0 and a[1] == T
     assert np.array_equal(_bits(a[0]), _bits(b[0]))
     assert int(a[3]["mp"].sum()) > 0 and int(a[3]["mp_fail"].sum()) > 0      # RRT-Connect was exercised, both outcomes
+    assert b[4] > 0                                                           # ... and some queries needed the second launch
 
 
 def test_pullback_kernel_equals_host_form(oracle_mod):

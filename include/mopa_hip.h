@@ -343,6 +343,16 @@ int mopa_ik_solve_batch(MopaIk *ik, int64_t E, double *qpos_dev /*[E,nq] in/out*
 int mopa_ik_site_pose_batch(MopaIk *ik, int64_t E, const double *qpos_dev /*[E,nq]*/, double *site_pos_dev /*[E,3]*/,
                             double *site_mat_dev /*[E,9]*/, void *stream);
 
+/* The straight-line pre-check of SACAgent.plan / simple_interpolate (rl/sac_agent.py:198-204, 236-272) for E envs: the line
+ * cur -> target is cut into int(s) equal steps, s = max(1, max_j |diff_j| / (0.8 ac_scale)) over the arm joints qpos[:n_arm]
+ * (= the scene's active joints), each interior state a running sum from cur and validated (env row = cur); traj[e] = the
+ * valid prefix of the walk followed by the exact target, traj_len[e] = its rows, ok[e] = 1 when no interior state was
+ * invalid, n_steps[e] = int(s).  K (<= 64) is the fixed row capacity of the walk: callers pass an upper bound of int(s) and
+ * check n_steps <= K.  cur must already be clipped (clip_qpos).  Three launches, no read-back. */
+int mopa_interpolate_batch(MopaScene *scene, int64_t E, int32_t n_arm, int32_t K, const double *cur_dev /*[E,nq]*/,
+                           const double *target_dev /*[E,nq]*/, double ac_scale, double *traj_dev /*[E,K+1,nq]*/,
+                           int32_t *traj_len_dev /*[E]*/, uint8_t *ok_dev /*[E]*/, int32_t *n_steps_dev /*[E]*/, void *stream);
+
 /* ===== planner paths -> executable trajectories (reference motion_planners/sampling_based_planner.py:71-99: un-wrap by
  * successive differences; rl/sac_agent.py:205-233: densification of long steps by simple_interpolate from the clipped
  * predecessor).  Three launches around one validity launch; no scene handle (pure arithmetic on caller buffers):

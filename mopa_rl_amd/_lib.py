@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch",
-    "mopa_paths_unwrap_batch", "mopa_paths_walk_batch", "mopa_paths_assemble_batch",
+    "mopa_paths_unwrap_batch", "mopa_paths_walk_batch", "mopa_paths_assemble_batch", "mopa_interpolate_batch",
 ]
 
 
@@ -140,6 +140,7 @@ def lib() -> C.CDLL:
     L.mopa_paths_unwrap_batch.argtypes = [C.c_int, i64, i32, i32, vp, i32, vp, vp, vp, f64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mopa_paths_walk_batch.argtypes = [C.c_int, i64, i32, i32, vp, i32, vp, vp, f64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mopa_paths_assemble_batch.argtypes = [C.c_int, i64, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp]
+    L.mopa_interpolate_batch.argtypes = [vp, i64, i32, i32, vp, vp, f64, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -139,6 +139,19 @@ def simple_interpolate_batch(bp, curr_qpos, target_qpos, ac_scale: float, ref_id
         raise ValueError("the interpolated joints must be qpos[:n] (the reference slices qpos[:len(ref_joint_pos_indexes)])")
     if n < bp.na:
         raise ValueError("planner has more active joints than the interpolated ones")
+    if fixed_steps > 0 and ac_low == -1.0 and ac_high == 1.0 and n == bp.na:
+        # fixed width: the whole pre-check as three launches of the library (mopa_interpolate_batch), no read-back
+        from . import _lib
+        from .batch import _ptr, _stream_handle
+        K = int(fixed_steps)
+        cur_c, tgt_c = curr_qpos.contiguous(), target_qpos.contiguous()
+        traj = torch.zeros(E, K + 1, nq, dtype=torch.float64, device=cur_c.device)
+        tlen = torch.empty(E, dtype=torch.int32, device=cur_c.device)
+        ok = torch.empty(E, dtype=torch.uint8, device=cur_c.device)
+        nst = torch.empty(E, dtype=torch.int32, device=cur_c.device)
+        _lib.check(_lib.lib().mopa_interpolate_batch(bp.scene._h, E, n, K, _ptr(cur_c), _ptr(tgt_c), float(ac_scale), _ptr(traj), _ptr(tlen),
+                                                     _ptr(ok), _ptr(nst), _stream_handle(None)))
+        return traj, tlen.to(torch.int64), ok.bool(), nst.to(torch.int64)
     diff = target_qpos[:, :n] - curr_qpos[:, :n]
     scaling, n_steps = interpolation_steps(diff, ac_scale, ac_low, ac_high)
     if fixed_steps > 0:

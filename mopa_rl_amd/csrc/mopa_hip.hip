@@ -121,6 +121,7 @@ struct StreamScratch {
     size_t slab_waves = 0;
     DevBuf mv_cnt, mv_off, mv_env, mv_q, mv_valid, mv_scan;   // expanded motion validation (mopa_motion.inc)
     DevBuf plan_q, plan_p, plan_ctr;                          // planner: both trees of every env, env counter (mopa_planner.inc)
+    DevBuf ip_walk;                                           // straight-line pre-check: walk states + verdicts (mopa_paths.inc)
     DevBuf pb_small, pb_rows, pb_act;                         // batched pull-back: verdicts / slots, candidate rows, their active coordinates + verdicts
 };
 
@@ -1095,7 +1096,7 @@ extern "C" void mopa_scene_destroy(MopaScene *S) {
     for (auto &kv : S->scratch) {
         StreamScratch &sc = kv.second;
         for (DevBuf *b : {&sc.slab, &sc.mpr, &sc.cen, &sc.mesh_list, &sc.mv_cnt, &sc.mv_off, &sc.mv_env, &sc.mv_q, &sc.mv_valid, &sc.mv_scan, &sc.plan_q,
-                          &sc.plan_p, &sc.plan_ctr, &sc.pb_small, &sc.pb_rows, &sc.pb_act})
+                          &sc.plan_p, &sc.plan_ctr, &sc.pb_small, &sc.pb_rows, &sc.pb_act, &sc.ip_walk})
             if (b->p) (void)hipFree(b->p);
     }
     for (void *q : S->retired) (void)hipFree(q);

@@ -87,3 +87,38 @@ def test_plan_batch_equals_reference_gpu():
             assert lens[k] == G["plan_len"][k], k
             assert np.array_equal(_bits(traj[k, :lens[k]]), _bits(G["plan_traj"][k, :lens[k]])), k
     assert (F[:, 0] & (1 - F[:, 1])).sum() >= 5 and (F[:, 2] == 0).sum() >= 5      # RRT paths and invalid goals both present
+
+
+@pytest.mark.gpu
+def test_straight_line_precheck_library_form_equals_tensor_form():
+    """`simple_interpolate_batch` with a fixed width runs as `mopa_interpolate_batch` (three launches of the library); without
+    one as tensor operations around one validity launch (the form the reference-generated vectors above pin).  Same rows,
+    lengths, verdicts and step counts, bit for bit, on lines that are short, long, blocked and free."""
+    import torch
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.agent_planning import max_interpolation_steps, simple_interpolate_batch
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import default_qpos, planner_inputs
+    env = "SawyerPushObstacle-v0"
+    pi = planner_inputs(env)
+    sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+    bp = BatchPlanner(sc)
+    E = 1500
+    rng = np.random.default_rng(3)
+    cur = np.repeat(default_qpos(env, pi.model)[None], E, axis=0)
+    cur[:, :7] += rng.normal(0, 0.05, size=(E, 7))
+    tgt = cur.copy()
+    tgt[:, :7] += rng.uniform(-0.5, 0.5, size=(E, 7)) * rng.choice([0.05, 0.3, 1.0], size=(E, 1))
+    tgt[:, :7] = np.clip(tgt[:, :7], pi.jnt_minimum, pi.jnt_maximum)
+    c, t = torch.tensor(cur, device="cuda"), torch.tensor(tgt, device="cuda")
+    K = max_interpolation_steps(0.5, 0.05)
+    a = simple_interpolate_batch(bp, c, t, 0.05, list(range(7)))
+    b = simple_interpolate_batch(bp, c, t, 0.05, list(range(7)), fixed_steps=K)
+    torch.cuda.synchronize()
+    la, lb = a[1].cpu().numpy(), b[1].cpu().numpy()
+    assert np.array_equal(la, lb) and np.array_equal(a[2].cpu().numpy(), b[2].cpu().numpy()) and np.array_equal(a[3].cpu().numpy(), b[3].cpu().numpy())
+    ta, tb = a[0].cpu().numpy(), b[0].cpu().numpy()
+    for e in range(E):
+        assert np.array_equal(ta[e, :la[e]].view(np.uint64), tb[e, :lb[e]].view(np.uint64)), e
+    ok = a[2].cpu().numpy()
+    assert 0.1 * E < ok.sum() < 0.95 * E and a[3].max() > 8

@@ -140,7 +140,8 @@ def test_reuse_data_relabelling_equals_reference():
     assert n_checked == len(G["x_env"]) and n_checked > 30
 
 
-def test_async_planner_gives_every_env_the_same_transitions():
+@pytest.mark.parametrize("env_name", ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"])
+def test_async_planner_gives_every_env_the_same_transitions(env_name):
     """`async_planner`: RRT-Connect queries run on side streams while the other envs go on stepping; the envs waiting for a
     query sit out.  Every env must still go through exactly the transitions of the lock-step run (its plans are keyed by its own
     step count), only later in wall-clock order."""
@@ -149,13 +150,14 @@ def test_async_planner_gives_every_env_the_same_transitions():
     from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
     E, T = 192, 5
     rng = np.random.default_rng(4)
-    AC = rng.uniform(-1, 1, size=(E, T, 7)) * rng.choice([0.6, 0.9, 1.0], size=(E, T, 1))
+    n_ac = 8 if env_name == "SawyerLiftObstacle-v0" else 7
+    AC = rng.uniform(-1, 1, size=(E, T, n_ac)) * rng.choice([0.6, 0.9, 1.0], size=(E, T, 1))
     AC[: E // 2, 1, 1], AC[: E // 2, 1, 3] = 1.0, -1.0           # blocked straight lines: RRT-Connect queries
     AC[E // 4: 3 * E // 4, 3, 1], AC[E // 4: 3 * E // 4, 3, 3] = 1.0, -1.0
     ACt = torch.tensor(AC, device="cuda")
     runs = {}
     for mode in ("lockstep", "async"):
-        env = make_env(ENV, E, seed=12, max_episode_steps=1000)
+        env = make_env(env_name, E, seed=12, max_episode_steps=1000)
         env.reset()
         # (async: a first launch with 60 of the 300 iterations, the queries it does not solve run again with all 300)
         ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.15, max_nodes=512, max_path=128, num_trials=10, async_planner=(mode == "async"),
@@ -180,8 +182,9 @@ def test_async_planner_gives_every_env_the_same_transitions():
     a, b = runs["lockstep"], runs["async"]
     assert a[2] == 0 and a[1] == T
     assert np.array_equal(_bits(a[0]), _bits(b[0]))
-    assert int(a[3]["mp"].sum()) > 0 and int(a[3]["mp_fail"].sum()) > 0      # RRT-Connect was exercised, both outcomes
-    assert b[4] > 0                                                           # ... and some queries needed the second launch
+    assert int(a[3]["mp"].sum()) > 0                                          # RRT-Connect was exercised ...
+    if env_name == ENV:
+        assert int(a[3]["mp_fail"].sum()) > 0 and b[4] > 0                    # ... with both outcomes, and second launches
 
 
 def test_pullback_kernel_equals_host_form(oracle_mod):

@@ -483,6 +483,10 @@ def main():
                     "transition all-gather + gradient all-reduce at any rank count)")
     args = ap.parse_args()
 
+    # The rollouts keep planner launches in flight on side streams next to the main stream and (multi-GPU) RCCL's stream; the
+    # HIP runtime maps streams onto 4 hardware queues by default and streams that share a queue serialise -- a 48 ms planner
+    # launch would then sit in front of a collective.  Ask for more queues before the runtime comes up (user settings win).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from mopa_rl_amd import _lib

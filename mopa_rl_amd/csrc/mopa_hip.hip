@@ -153,7 +153,8 @@ struct MopaScene {
     int v2_lds_bytes = 0;
     int use_v2 = 1;
     int32_t *d_gp_tab = nullptr;   // v5: FP32 broad-phase table [n_gp][8]
-    int v5_lds_bytes = 0;
+    int v5_lds_bytes = 0;        // verdict-only instantiations of k_is_valid_v5 (hdr.v5_ent_cap entries per wave)
+    int v5_lds_bytes_md = 0, v5_ent_cap_md = 0;   // depth-reporting instantiations
     int use_v5 = 0;
     bool v5_cen_lds = true;   // FP32 centre table of a tile in LDS (false: read back from the pose slab; scenes with many moving geoms)
     bool v2_forced = false;   // MOPA_VALID_KERNEL=v2: lane-per-state kernel for every N >= 64 (tests, A/B runs)
@@ -1017,17 +1018,22 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
                 if (ec && std::string(ec) == "lds" && gp_word_mesh.empty()) cen_lds = true;   // (mesh scenes: always slab + gate)
                 const int n_cen = cen_lds ? nmg : 0;
                 cap = kEntCapV5Max;
-                while (cap > 256 && fixed + kWavesPerBlock * v5_lds_per_wave(n_cen, cap) > 80 * 1024) cap -= 64;
-                if (fixed + kWavesPerBlock * v5_lds_per_wave(n_cen, cap) <= 80 * 1024) break;
+                while (cap > 256 && fixed + kWavesPerBlock * v5_lds_per_wave(n_cen, cap, true) > 80 * 1024) cap -= 64;
+                if (fixed + kWavesPerBlock * v5_lds_per_wave(n_cen, cap, true) <= 80 * 1024) break;
                 if (ec && std::string(ec) == "lds") break;
             }
-            if (fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap) > 80 * 1024) {   // one workgroup per CU anyway
+            if (fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap, true) > 80 * 1024) {   // one workgroup per CU anyway
                 cap = 768;
                 cen_lds = gp_word_mesh.empty() && !(ec && std::string(ec) == "slab");
             }
             S->v5_cen_lds = cen_lds;
+            // (cap so far: the depth-reporting instantiations; the verdict-only ones have no depth words and take more entries)
+            S->v5_ent_cap_md = cap;
+            S->v5_lds_bytes_md = fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap, true);
+            const int budget = std::max(S->v5_lds_bytes_md, 80 * 1024);
+            while (cap + 64 <= kEntCapV5Max && fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap + 64, false) <= budget) cap += 64;
             h.v5_ent_cap = cap;
-            S->v5_lds_bytes = fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap);
+            S->v5_lds_bytes = fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap, false);
             if (std::getenv("MOPA_DEBUG"))
                 fprintf(stderr, "[mopa] scene: nmg %d nmb %d save slots %d pairs %d (+%d mesh) lds: wave-per-state %d, v2 %d, v5 %d (entry cap %d, fixed %d, centres in %s)\n", nmg, nmb, n_save,
                         (int)gp_word.size(), (int)gp_word_mesh.size(), S->lds_bytes, S->v2_lds_bytes, S->v5_lds_bytes, cap, fixed, cen_lds ? "LDS" : "slab");
@@ -1036,7 +1042,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
         // ... unless it would get one workgroup per CU where the second generation still gets two (LDS: the FP32 centre
         // table grows with the number of moving geoms; SawyerLift: 19 of them)
         const bool v5_fits2 = S->v5_lds_bytes <= 80 * 1024, v2_fits2 = S->v2_lds_bytes <= 80 * 1024;
-        S->use_v5 = !(ev && std::string(ev) == "v2") && S->use_v2 && max_pnum <= 64 && S->v5_lds_bytes <= kMaxLdsBytes && reach <= kV5MaxReach &&
+        S->use_v5 = !(ev && std::string(ev) == "v2") && S->use_v2 && max_pnum <= 64 && std::max(S->v5_lds_bytes, S->v5_lds_bytes_md) <= kMaxLdsBytes && reach <= kV5MaxReach &&
                     (v5_fits2 || !v2_fits2 || (ev && std::string(ev) == "v5"));
         if (ev && std::string(ev) == "v5") S->v2_forced = true;   // "v5" also forces the lane-per-state path for every N >= 64
     }
@@ -1177,7 +1183,9 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             auto k5 = S->v5_cen_lds ? (min_dist ? k_is_valid_v5<true, true, false> : k_is_valid_v5<false, true, false>)
                       : mesh_list   ? (min_dist ? k_is_valid_v5<true, false, true> : k_is_valid_v5<false, false, true>)
                                     : (min_dist ? k_is_valid_v5<true, false, false> : k_is_valid_v5<false, false, false>);
-            hipLaunchKernelGGL(k5, grid, block, S->v5_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
+            SceneHdr hk = S->hdr;
+            if (min_dist) hk.v5_ent_cap = S->v5_ent_cap_md;
+            hipLaunchKernelGGL(k5, grid, block, min_dist ? S->v5_lds_bytes_md : S->v5_lds_bytes, st, hk, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
                                (long long)N, (long long)samples_per_env, valid, min_dist, d_slab, env_idx, sc.mpr.as<double>(), mesh_list, sc.cen.as<float>(),
                                n_dev);
         } else

@@ -279,6 +279,10 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     env = make_env(env_name, E, device=device, seed=21 + int(os.environ.get("RANK", "0")), max_episode_steps=250)
     env.reset()
     over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("MOPA_BENCH_ROLLOUT", "").split(",") if kv)}   # A/B knob
+    if world > 1:
+        # main stream + planner side streams + RCCL's stream: the HIP runtime runs 4 hardware queues side by side (streams
+        # beyond that share one and serialise), so one planner stream less than the single-GPU default
+        over.setdefault("planner_streams", 2)
     ro = BatchMoPARollout(env, RolloutConfig(async_planner=async_planner, **over))
     torch.manual_seed(8)
     nn = torch.nn
@@ -483,10 +487,6 @@ def main():
                     "transition all-gather + gradient all-reduce at any rank count)")
     args = ap.parse_args()
 
-    # The rollouts keep planner launches in flight on side streams next to the main stream and (multi-GPU) RCCL's stream; the
-    # HIP runtime maps streams onto 4 hardware queues by default and streams that share a queue serialise -- a 48 ms planner
-    # launch would then sit in front of a collective.  Ask for more queues before the runtime comes up (user settings win).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     import torch.distributed as dist
     from mopa_rl_amd import _lib

@@ -284,6 +284,8 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         # beyond that share one and serialise), so one planner stream less than the single-GPU default
         over.setdefault("planner_streams", 2)
     ro = BatchMoPARollout(env, RolloutConfig(async_planner=async_planner, **over))
+    if os.environ.get("MOPA_BENCH_PHASES"):
+        ro.timing = {}           # per-phase times (each mark synchronises the main stream: slower calls, profiling only)
     torch.manual_seed(8)
     nn = torch.nn
     ad = env.action_dim
@@ -309,7 +311,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         return out
     # untimed calls first: one for lock-step; the asynchronous mode needs ~25 until planner launches start, run and finish
     # at their steady rate
-    warm = 25 if async_planner else 1
+    warm = int(os.environ.get("MOPA_BENCH_ROLLOUT_WARM", "25")) if async_planner else 1
     for k in range(warm):
         out = one(k)
         env.reset(out["done"].bool() & out["stepped"])
@@ -329,6 +331,8 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         n_acc[0] += st.sum()
         n_acc[1] += ((out["intra_steps"] + 1) * st).sum()
         env.reset(out["done"].bool() & st)
+    if os.environ.get("MOPA_BENCH_PHASES") and getattr(ro, "timing", None):
+        print(f"[rollout {env_name} async={async_planner}] phases ms/call:", {k: round(v / (warm + agent_steps) * 1e3, 3) for k, v in ro.timing.items()}, file=sys.stderr)
     gathered = tx.result(warm + agent_steps - 1)
     tx.drain()
     torch.cuda.synchronize()

@@ -58,6 +58,60 @@ def test_ik_bit_identical_to_oracle(env, tol, n_joints, with_quat, oracle_mod):
     assert 0 < n_ok < E            # both outcomes occur
 
 
+@pytest.mark.parametrize("with_quat", [False, True])
+def test_ik_at_bench_size_on_assembly(with_quat, oracle_mod):
+    """The bench's IK workload (BASELINE config 5: SawyerAssemblyObstacle, 8192 problems, max_steps 100, tol 1e-2), position and
+    position + orientation targets, every problem against the oracle: joint values and error norms bit for bit, step
+    counts and success flags equal."""
+    import torch
+    from mopa_rl_amd.ik import BatchIK
+    from mopa_rl_amd.scene import default_qpos, planner_inputs
+    env = "SawyerAssemblyObstacle-v0"
+    pi = planner_inputs(env)
+    m = pi.model
+    orc = oracle_mod.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    ik = BatchIK(m, "grip_site", list(pi.spec.robot_joints))
+    E = 8192
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0)
+    q0 = torch.tensor(default_qpos(env, m), device="cuda").repeat(E, 1)
+    q0[:, :7] += 0.2 * torch.randn(E, 7, generator=g, dtype=torch.float64, device="cuda")
+    qt = q0.clone()
+    qt[:, :7] += 0.3 * torch.randn(E, 7, generator=g, dtype=torch.float64, device="cuda")
+    pos, mat = ik.site_pose(qt.contiguous())                     # reachable targets: the site pose of a perturbed arm
+    tq = np.zeros((E, 4))
+    for e, R in enumerate(mat.cpu().numpy()):
+        tq[e] = oracle_mod.mat2quat(R) if hasattr(oracle_mod, "mat2quat") else _mat2quat(R)
+    tgt_pos, tgt_quat = pos.contiguous(), torch.tensor(tq, device="cuda")
+    qs = q0.clone().contiguous()
+    res = ik.solve(qs, tgt_pos, tgt_quat if with_quat else None, max_steps=100, tol=1e-2)
+    gq, ge, gs, gok = res.qpos.cpu().numpy(), res.err_norm.cpu().numpy(), res.steps.cpu().numpy(), res.success.cpu().numpy()
+    q0h, ph = q0.cpu().numpy(), tgt_pos.cpu().numpy()
+    for e in range(E):
+        oq, oe, os_, ook = orc.ik_solve(q0h[e], ph[e], ik.joint_ids, ik.site_body, ik.site_off, max_steps=100, tol=1e-2,
+                                        target_quat=tq[e] if with_quat else None)
+        assert np.array_equal(_bits(gq[e]), _bits(oq)) and _bits(ge[e]) == _bits(oe) and gs[e] == os_ and bool(gok[e]) == ook, e
+    assert gok.mean() > 0.9
+
+
+def _mat2quat(R):
+    """rotation matrix -> unit quaternion wxyz (Shepperd), only to pose this test's targets"""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        q = np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[0] = (R[k, j] - R[j, k]) / s
+        q[1 + i] = 0.25 * s
+        q[1 + j] = (R[j, i] + R[i, j]) / s
+        q[1 + k] = (R[k, i] + R[i, k]) / s
+    return q / np.linalg.norm(q)
+
+
 def test_single_problem_form_and_errors():
     from mopa_rl_amd import _lib
     from mopa_rl_amd.ik import BatchIK, qpos_from_site_pose

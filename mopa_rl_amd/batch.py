@@ -96,6 +96,72 @@ class BatchPlanner:
                                               _ptr(plen), _ptr(status), _ptr(nchk), _stream_handle(stream)))
         return path, plen, status, nchk
 
+    def plan_laddered(self, batches, max_iters: int = 2000, first_iters: int = 300, max_nodes: int = 1024, max_path: int = 256,
+                      retry_streams=None, first_stream=None, max_workgroups_first: int = 0, retry_min: int = 512):
+        """A stream of query batches through RRT-Connect with an iteration ladder.  `batches`: list of dicts with `start`,
+        `goal` ([E, nq] tensors), `seed` and optionally `env_ids` / `seeds` as for `plan`.  Every batch first runs with
+        `first_iters`; the queries that come back "no exact solution" (a few %: the ones that would have kept the whole
+        launch waiting for their 2000 iterations) run again with `max_iters` -- pooled over batches until `retry_min` of them
+        wait -- on other streams, next to the following batches' first launches.  A query's outcome depends on its endpoints and sample stream only and the budget merely
+        ends the loop, so the second run retraces the first and continues: each batch's (path, path_len, status, n_checks)
+        are those of `plan(..., max_iters=max_iters)`, bit for bit.  Returns the list of those tuples (after all launches
+        have finished).  One host read-back per batch (which queries go again)."""
+        torch = _torch()
+        if first_iters <= 0 or first_iters >= max_iters:
+            return [self.plan(b["start"], b["goal"], max_iters=max_iters, max_nodes=max_nodes, max_path=max_path, seed=b.get("seed", 0),
+                              env_ids=b.get("env_ids"), seeds=b.get("seeds")) for b in batches]
+        dev = batches[0]["start"].device
+        main = torch.cuda.current_stream(dev)
+        sa = first_stream if first_stream is not None else torch.cuda.Stream(device=dev)
+        sbs = list(retry_streams) if retry_streams else [torch.cuda.Stream(device=dev) for _ in range(2)]
+        sa.wait_stream(main)
+        for st in sbs:
+            st.wait_stream(main)
+        out, pend, wait = [], [], []         # wait: unsolved queries of finished first launches, pooled into retry launches
+        n_wait, n_retry = 0, 0
+
+        def retry():
+            nonlocal n_wait, n_retry, wait
+            sb = sbs[n_retry % len(sbs)]
+            n_retry += 1
+            sb.wait_stream(sa)
+            with torch.cuda.stream(sb):
+                cat = lambda k: torch.cat([w[k] for w in wait]).contiguous()
+                r2 = self.plan(cat("start"), cat("goal"), max_iters=max_iters, max_nodes=max_nodes, max_path=max_path, seed=0,
+                               env_ids=cat("ids"), seeds=cat("seeds"), stream=sb)
+            pend.append(([(w["batch"], w["rows"]) for w in wait], r2, sb))
+            wait, n_wait = [], 0
+
+        for i, b in enumerate(batches):
+            E = b["start"].shape[0]
+            ids = b.get("env_ids")
+            if ids is None:
+                ids = torch.arange(E, device=dev, dtype=torch.int64)
+            with torch.cuda.stream(sa):
+                res = self.plan(b["start"], b["goal"], max_iters=first_iters, max_nodes=max_nodes, max_path=max_path, seed=b.get("seed", 0),
+                                env_ids=ids, seeds=b.get("seeds"), stream=sa, max_workgroups=max_workgroups_first)
+                again = torch.nonzero(res[2] == _lib.PLAN_NO_EXACT).flatten()       # (waits for this launch: the one read-back)
+                if len(again):
+                    seeds = (b["seeds"][again] if b.get("seeds") is not None
+                             else torch.full((len(again),), int(b.get("seed", 0)), dtype=torch.int64, device=dev))
+                    wait.append(dict(start=b["start"][again], goal=b["goal"][again], ids=ids[again], seeds=seeds, batch=i, rows=again))
+                    n_wait += len(again)
+            out.append(list(res))
+            if n_wait >= retry_min:
+                retry()
+        if n_wait:
+            retry()
+        for parts, r2, sb in pend:
+            with torch.cuda.stream(sb):
+                o = 0
+                for bi, rows in parts:
+                    for k in range(4):
+                        out[bi][k][rows] = r2[k][o:o + len(rows)]
+                    o += len(rows)
+            main.wait_stream(sb)
+        main.wait_stream(sa)
+        return [tuple(o) for o in out]
+
     def pullback(self, cur, target, step_size: float, num_trials: int, stream=None):
         """The rollout's invalid-target back-off (rl/mopa_rollouts.py:133-143) for E envs in one launch.
         cur / target: [E, nq] float64 GPU tensors.  Returns (target' [E, nq], n_trials [E] int32, valid [E] uint8)."""

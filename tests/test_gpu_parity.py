@@ -308,6 +308,40 @@ def test_check_motion_large_batch_crosses_scan_chunks(oracle_mod):
     assert 0.05 * n < ov.sum() < 0.95 * n
 
 
+def test_laddered_planning_equals_one_full_launch(oracle_mod):
+    """`BatchPlanner.plan_laddered`: a short first launch, the unsolved queries again with the full budget on another stream,
+    several batches in flight -- every batch's results equal those of one launch with the full budget."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk("SawyerPushObstacle-v0", oracle_mod)
+    bp = BatchPlanner(sc)
+    E = 256
+    qa, row = sample_states(pi, 8000, 47, "near")
+    ov, _ = orc.is_valid_batch(qa, row, samples_per_env=len(qa))
+    good = qa[ov == 1]
+    batches = []
+    for b in range(3):
+        starts = np.repeat(row, E, axis=0)
+        goals = starts.copy()
+        starts[:, pi.ref_joint_pos_indexes] = good[2 * b * E:(2 * b + 1) * E]
+        goals[:, pi.ref_joint_pos_indexes] = good[(2 * b + 1) * E:(2 * b + 2) * E]
+        batches.append(dict(start=torch.from_numpy(starts).cuda(), goal=torch.from_numpy(goals).cuda(), seed=11 + b))
+    prm = dict(max_iters=400, max_nodes=512, max_path=128)
+    lad = bp.plan_laddered(batches, first_iters=40, **prm)
+    torch.cuda.synchronize()
+    n_retried = 0
+    for b, got in zip(batches, lad):
+        want = bp.plan(b["start"], b["goal"], seed=b["seed"], **prm)
+        first = bp.plan(b["start"], b["goal"], seed=b["seed"], max_iters=40, max_nodes=512, max_path=128)
+        n_retried += int((first[2] == -4).sum())
+        w, g = [t.cpu().numpy() for t in want], [t.cpu().numpy() for t in got]
+        for k in (1, 2, 3):
+            assert np.array_equal(w[k], g[k])
+        for e in range(E):
+            assert np.array_equal(w[0][e, :w[1][e]].view(np.uint64), g[0][e, :g[1][e]].view(np.uint64))
+    assert n_retried > 20
+
+
 def test_plan_results_do_not_depend_on_launch_shape(oracle_mod):
     """A query's outcome is a function of (start, goal, its seed, its stream id) only: capping the launch's persistent
     workgroups, giving per-query seeds instead of one seed, or planning a subset of the queries changes nothing."""

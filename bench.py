@@ -171,12 +171,12 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
     dtc = _t.perf_counter() - t0
     out["concurrent"] = {"launches": nl, "queries": nl * E, "ms_total": dtc * 1e3, "plans_per_s": nl * E / dtc,
                          "note": f"{nl} launches of {E} queries on {nl} streams, each capped to 1/{nl} of the CUs"}
-    # ... and a stream of batches through the iteration ladder (BatchPlanner.plan_laddered): 300 iterations first, the ~3 % it
+    # ... and a stream of batches through the iteration ladder (BatchPlanner.plan_laddered): 200 iterations first, the ~3 % it
     # does not solve again with all 2000 on other streams while the next batches' first launches run -- results identical
     # to full-budget launches (tests/test_gpu_parity.py::test_laddered_planning_equals_one_full_launch)
     nb = 8
     batches = [dict(start=start, goal=goal, seed=7 + 13 * i) for i in range(nb)]
-    lad_kw = dict(max_iters=prm["max_iters"], first_iters=300, max_nodes=prm["max_nodes"], max_path=prm["max_path"],
+    lad_kw = dict(max_iters=prm["max_iters"], first_iters=200, max_nodes=prm["max_nodes"], max_path=prm["max_path"],
                   first_stream=streams[0], retry_streams=streams[1:3])
     bp.plan_laddered(batches[:2], **lad_kw)
     torch.cuda.synchronize()
@@ -187,7 +187,7 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
     same = all(bool((a == b).all().item()) for a, b in zip(lad[0][1:], (plen, status, nchk)))
     out["laddered"] = {"batches": nb, "queries": nb * E, "ms_total": dtl * 1e3, "ms_per_batch": dtl * 1e3 / nb, "plans_per_s": nb * E / dtl,
                        "first_batch_equals_full_launch": same,
-                       "note": f"{nb} batches of {E} queries: first launch with 300 iterations, unsolved queries again with {prm['max_iters']} on 2 other streams"}
+                       "note": f"{nb} batches of {E} queries: first launch with 200 iterations, unsolved queries again with {prm['max_iters']} on 2 other streams"}
     if with_cpu:
         out["cpu_baseline"] = plan_cpu_baseline(pi, start.cpu().numpy(), goal.cpu().numpy(), prm, status.cpu().numpy(),
                                                 plen.cpu().numpy(), nchk.cpu().numpy())

@@ -281,7 +281,7 @@ def env_step_section(torch, E, device, steps, with_cpu):
 SAC_GRAD_FLOATS = 145678 + 2 * 78337       # actor + two critics for obs 40 / ac 7 (the payload of sync_grads)
 
 
-def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_planner=False):
+def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_planner=False, use_ik=False):
     """End-to-end MoPA rollout step (mopa_rl_amd/rollout.py), SURVEY 8d configs 3 / 4: a SAC actor (stock PyTorch, random-init
     obs-256-256-256-(2 x ac) MLP, f32; a = tanh(mu + sigma * eps)) samples the action from the obs inside the timed loop,
     then per env either a direct env step or target / pull-back / straight-line pre-check / RRT-Connect / densification /
@@ -300,12 +300,14 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         # main stream + planner side streams + RCCL's stream: the HIP runtime runs 4 hardware queues side by side (streams
         # beyond that share one and serialise), so one planner stream less than the single-GPU default
         over.setdefault("planner_streams", 2)
+    if use_ik:
+        over["use_ik_target"] = 1       # MoPA + IK action space (BASELINE config 5): Cartesian displacement + rotation quaternion
     ro = BatchMoPARollout(env, RolloutConfig(async_planner=async_planner, **over))
     if os.environ.get("MOPA_BENCH_PHASES"):
         ro.timing = {}           # per-phase times (each mark synchronises the main stream: slower calls, profiling only)
     torch.manual_seed(8)
     nn = torch.nn
-    ad = env.action_dim
+    ad = ro.ac_dim
     actor = nn.Sequential(nn.Linear(env.obs.shape[1], 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(),
                           nn.Linear(256, 2 * ad)).to(device)
     g = torch.Generator(device=device)
@@ -365,6 +367,8 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         c = {k: int(t[3 + i].item()) for i, k in enumerate(sorted(c))}
     mode = ("async_planner: RRT-Connect on side streams, envs waiting for a query sit out (each env's transitions are those of the "
             "lock-step run)") if async_planner else "lock-step: every call waits for its slowest RRT-Connect query"
+    if use_ik:
+        mode += "; IK action space: the actor's Cartesian displacement + quaternion -> joint displacement through the batched damped-LS IK (K5)"
     return {"config": f"{env_name}, {E} envs per GPU x {world} GPU(s), {agent_steps} calls of agent_step; actions sampled by a random-init SAC actor "
                       f"({env.obs.shape[1]}-256-256-256-{2 * ad} MLP, f32, tanh-Gaussian) from the obs (omega 0.7), kinematic env; {mode}",
             "agent_steps_per_s": n_agent_steps / dt, "env_steps_per_s": n_env_steps / dt, "s_per_agent_step_batch": dt / agent_steps,
@@ -639,6 +643,9 @@ def main():
             ro["rollout"] = rollout_section(torch, ENV, args.envs, device, 3)
             ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 100, async_planner=True)
         ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 100, world, async_planner=True)
+        # BASELINE config 5: SawyerAssemblyObstacle with the IK action space, 8192 envs per GPU
+        ro["rollout_assembly_ik"] = rollout_section(torch, "SawyerAssemblyObstacle-v0", 2 * args.envs, device, 60, world, async_planner=True,
+                                                    use_ik=True)
     if rank == 0:
         out.update(ro)
         print(json.dumps(out))

@@ -170,6 +170,7 @@ class BatchMoPARollout:
         # blocked envs waiting for the next RRT-Connect launch: mask + their (clipped) current state and target
         self._pool_mask = torch.zeros(self.E, dtype=torch.bool, device=dev)
         self._retry_mask = torch.zeros(self.E, dtype=torch.bool, device=dev)     # ... and those whose first, short launch ran out
+        self._wait_since = torch.zeros(self.E, dtype=torch.int64, device=dev)    # call in which an env started to wait
         self.n_retried = torch.zeros((), dtype=torch.int64, device=dev)
         self._q_cur = torch.zeros(self.E, self.nq, dtype=torch.float64, device=dev)
         self._q_tgt = torch.zeros(self.E, self.nq, dtype=torch.float64, device=dev)
@@ -672,6 +673,7 @@ class BatchMoPARollout:
         self._q_cur = torch.where(blocked[:, None], cur_v, self._q_cur)
         self._q_tgt = torch.where(blocked[:, None], tgt_v, self._q_tgt)
         self._pool_mask |= blocked
+        self._wait_since = torch.where(blocked, torch.full_like(self._wait_since, self._t), self._wait_since)
         self.busy |= blocked
         self._pend_ob = torch.where(blocked[:, None], prev_ob, self._pend_ob)
         self._pend_ac = torch.where(blocked[:, None], ac_tr, self._pend_ac)
@@ -699,7 +701,9 @@ class BatchMoPARollout:
                                          "action_range from the current state?)")
                 cap = cfg.planner_job_cap // 4 if retry else cfg.planner_job_cap
                 if cfg.async_planner and len(bi) > cap:
-                    bi = bi[:cap]
+                    # the envs that have waited longest go first (a plain prefix would starve the high env indices whenever
+                    # more envs wait than a launch takes)
+                    bi = bi[torch.argsort(self._wait_since[bi], stable=True)[:cap]]
                 bi = bi.contiguous()
                 mask[bi] = False
                 iters = cfg.planner_first_iters if (two_phase and not retry) else self.main_iters

@@ -139,7 +139,8 @@ def simple_interpolate_batch(bp, curr_qpos, target_qpos, ac_scale: float, ref_id
         raise ValueError("the interpolated joints must be qpos[:n] (the reference slices qpos[:len(ref_joint_pos_indexes)])")
     if n < bp.na:
         raise ValueError("planner has more active joints than the interpolated ones")
-    if fixed_steps > 0 and ac_low == -1.0 and ac_high == 1.0 and n == bp.na:
+    if (fixed_steps > 0 and ac_low == -1.0 and ac_high == 1.0 and n == bp.na and curr_qpos.is_cuda
+            and getattr(getattr(bp, "scene", None), "_h", None) is not None):
         # fixed width: the whole pre-check as three launches of the library (mopa_interpolate_batch), no read-back
         from . import _lib
         from .batch import _ptr, _stream_handle

@@ -172,7 +172,9 @@ int mopa_plan_batch(MopaScene *scene, const double *start_dev /*[E,nq]*/, const 
                     const MopaPlanParams *params, double *path_dev /*[E,max_path,nq]*/, int32_t *path_len_dev /*[E]*/,
                     int32_t *status_dev /*[E]*/, int64_t *n_checks_dev /*[E] or NULL*/, void *stream);
 
-/* The rollout's invalid-target back-off (rl/mopa_rollouts.py:133-143) for E envs in one launch: while target[e] (a full
+/* The rollout's invalid-target back-off (rl/mopa_rollouts.py:133-143) for E envs, asynchronous (no read-back unless E * num_trials
+ * rows would exceed 1 GiB of scratch; E < 256: one wave per env walks its trials, otherwise all candidate rows of all
+ * invalid targets go through one validity launch -- same results): while target[e] (a full
  * qpos row, validated with its own passive entries) is invalid and fewer than num_trials steps were taken,
  *   target[e] += step_size * (cur[e] - target[e]) / ||cur[e] - target[e]||   (Euclidean norm over all nq entries, squares
  * summed left to right).  target is updated in place; n_trials[e] = steps taken, valid[e] = verdict of the final row. */

@@ -260,3 +260,41 @@ def test_device_path_postprocessing_equals_host_form(env_name):
     assert (ln_h[s_h] > pl[s_h] - 1).sum() > 20         # densification happened: more rows than planner waypoints
     for q in range(E):
         assert np.array_equal(_bits(tr_h[q, :ln_h[q]]), _bits(tr_d[q, :ln_d[q]])), q
+
+
+def test_path_postprocessing_edge_cases():
+    """`postprocess_paths`: a batch of sentinel rows only (no path at all), one-row paths (start == goal: nothing to execute but
+    the waypoint count is 0) and the argument checks of the C entry points."""
+    import ctypes as C
+    import torch
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.batch import BatchPlanner, postprocess_paths
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    env = make_env(ENV, 8, seed=1)
+    env.reset()
+    ro = BatchMoPARollout(env, RolloutConfig())
+    M, P, nq = 5, 16, ro.nq
+    dev = env.device
+    cur = env.qpos[:M].clone().contiguous()
+    path = torch.zeros(M, P, nq, dtype=torch.float64, device=dev)
+    path[:, 0] = cur
+    plen = torch.tensor([1, 1, 0, 0, 1], dtype=torch.int32, device=dev)
+    status = torch.tensor([0, _lib.PLAN_NO_EXACT, _lib.PLAN_INVALID_GOAL, _lib.PLAN_NO_EXACT, 0], dtype=torch.int32, device=dev)
+    out, ln, need = postprocess_paths(path, plen, status, cur, ro.n, 0.05, True, ro.limits, ro._valid)
+    assert ln.tolist() == [0, 0, 0, 0, 0] and not bool(need.any()) and out.shape[0] == M
+    # a two-row path with one long step: start -> start + 0.13 in joint 0  =>  int(0.13 / 0.04) = 3 interior states + the waypoint
+    path[0, 1] = cur[0]
+    path[0, 1, 0] += 0.13
+    plen[0] = 2
+    out, ln, need = postprocess_paths(path.clone(), plen, status, cur, ro.n, 0.05, True, ro.limits, lambda q: torch.ones(len(q), dtype=torch.uint8, device=dev))
+    assert ln.tolist() == [4, 0, 0, 0, 0]
+    got = out[0, :4, 0].cpu().numpy() - float(cur[0, 0])
+    assert np.allclose(got, [0.13 / 3.25 * k for k in (1, 2, 3)] + [0.13], atol=1e-12)
+    # ... and flagged for the fallback planners when an interior state is invalid
+    out, ln, need = postprocess_paths(path.clone(), plen, status, cur, ro.n, 0.05, True, ro.limits, lambda q: torch.zeros(len(q), dtype=torch.uint8, device=dev))
+    assert need.tolist() == [True, False, False, False, False]
+    L = _lib.lib()
+    assert L.mopa_paths_unwrap_batch(0, 1, 65, 7, None, 4, None, None, None, 0.05, 1, None, None, None, None, None, None, None, None) == 1   # MOPA_ERR_INVALID_ARG
+    assert L.mopa_paths_unwrap_batch(0, 0, 36, 7, None, 4, None, None, None, 0.05, 1, None, None, None, None, None, None, None, None) == 0
+    assert L.mopa_interpolate_batch(ro.scene._h, 4, 7, 0, None, None, 0.05, None, None, None, None, None) == 1   # MOPA_ERR_INVALID_ARG

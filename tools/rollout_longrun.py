@@ -1,3 +1,5 @@
+"""Asynchronous rollouts for 4000 calls (uniform random actions, Push and Lift): memory, waiting envs, the slowest env's step
+count (fairness of the planner queue) and the counters every 1000 calls.  GPU box."""
 import sys, time; sys.path.insert(0, ".")
 import torch, numpy as np
 from mopa_rl_amd.kinematic_env import make_env

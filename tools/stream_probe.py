@@ -1,3 +1,5 @@
+"""Which torch streams share a hardware queue with the main stream / with each other (a busy stream then holds up the other):
+launches a ~15 ms sleep kernel on one stream and times a tiny op on another.  GPU box."""
 import time, torch
 dev = torch.device("cuda:0")
 main = torch.cuda.current_stream(dev)

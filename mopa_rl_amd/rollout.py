@@ -720,6 +720,12 @@ class BatchMoPARollout:
                 still.append(job)
                 continue
             tr_j, ln_j, s_j, v_j, e_j = job["result"]
+            if job["stream"] is not None:
+                # results allocated on the job's side stream are read by this stream's launches below: tell the allocator,
+                # or the next job could be handed their memory while those launches are still queued
+                for x in (tr_j, ln_j, s_j, v_j, e_j):
+                    if hasattr(x, "record_stream"):
+                        x.record_stream(torch.cuda.current_stream())
             jid = job["ids"]
             t = lambda x: torch.as_tensor(x, device=dev)
             s_t = t(s_j)

@@ -1,0 +1,164 @@
+"""Servo-dynamics facts of a Sawyer env (stage A): the actuated kinematic tree, LUMPED for simulation.
+
+The reference's `env.step` runs `int(frame_dt / dt)` = 75 MuJoCo sub-steps per call with the arm's position servos
+tracking `desired_state` and `qfrc_applied = qfrc_bias` as gravity compensation
+(env/sawyer/sawyer_push_obstacle.py:186-203, env/base.py:388-392; servo gains env/assets/xml/common/
+sawyer_joint_pos_act.xml, joint damping / armature sawyer_dependencies.xml:38,66-78, timestep :11).  The dynamic state of
+that loop -- when nothing is in contact -- is the arm's own tree: 7 hinges + the 2 gripper slides.  This module derives,
+from a :class:`CompiledModel`, what the HIP kernel (`csrc/mopa_dyn.inc`) and the test oracle both take as input:
+
+  * one body per dof, parents before children; bodies welded to a jointed body (head, screen, gripper base, finger
+    tips, the peg ...) are folded into that body's mass / centre of mass / inertia tensor (exact: a weld is rigid);
+  * each body's frame relative to its parent dynamic body (welded intermediates composed), the base frame in the world;
+  * per dof: damping, armature, joint range, servo gain / force range, whether the env gravity-compensates it.
+
+Everything here is host-side set-up in plain numpy; nothing is on the hot path.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from .mjcf import JNT_HINGE, JNT_SLIDE, _quat_mul, _quat_to_mat
+
+DYN_MAX = 9   # dofs the kernel keeps per env (LDS budget, csrc/mopa_dyn.inc)
+
+
+@dataclass
+class DynFacts:
+    nd: int
+    body: np.ndarray          # [nd] model body id of each dynamic body
+    parent: np.ndarray        # [nd] i32, -1 = fixed base
+    jtype: np.ndarray         # [nd] i32
+    qadr: np.ndarray          # [nd] i32
+    rel_pos: np.ndarray       # [nd,3]
+    rel_quat: np.ndarray      # [nd,4]
+    axis: np.ndarray          # [nd,3]
+    jpos: np.ndarray          # [nd,3]
+    qref: np.ndarray          # [nd]
+    mass: np.ndarray          # [nd]
+    ipos: np.ndarray          # [nd,3]
+    inertia: np.ndarray       # [nd,6] xx yy zz xy xz yz about the COM, body axes
+    damping: np.ndarray
+    armature: np.ndarray
+    limited: np.ndarray       # i32
+    lo: np.ndarray
+    hi: np.ndarray
+    actuated: np.ndarray      # i32
+    kp: np.ndarray
+    force_lo: np.ndarray
+    force_hi: np.ndarray
+    gravcomp: np.ndarray      # i32
+    gravity: np.ndarray       # [3]
+    timestep: float
+    nsub: int
+
+
+def _compose(p1, q1, p2, q2):
+    """frame 2 given in frame 1, frame 1 given in frame 0  ->  frame 2 in frame 0"""
+    return p1 + _quat_to_mat(q1) @ p2, _quat_mul(q1, q2)
+
+
+def dyn_facts(model, facts, frame_dt: float = 0.15) -> DynFacts:
+    """`facts`: the env's :class:`EnvFacts` (arm / actuator qpos addresses, joint limits as the env clamps them)."""
+    m = model
+    if len(getattr(m, "body_mass", ())) == 0:
+        raise ValueError("compiled scene carries no inertials (recompile with tools/compile_scenes.py)")
+    jnt_of_qadr = {int(a): j for j, a in enumerate(m.jnt_qposadr)}
+    root = int(m.jnt_body[jnt_of_qadr[int(facts.arm_qpos_idx[0])]])
+    nb = len(m.body_names)
+
+    def in_subtree(b):
+        while b > 0:
+            if b == root:
+                return True
+            b = int(m.body_parent[b])
+        return False
+
+    sub = [b for b in range(1, nb) if in_subtree(b)]
+    dyn_bodies = [b for b in sub if m.body_jntnum[b] > 0]
+    for b in dyn_bodies:
+        j = int(m.body_jntadr[b])
+        if m.body_jntnum[b] != 1 or int(m.jnt_type[j]) not in (JNT_HINGE, JNT_SLIDE):
+            raise ValueError(f"body {m.body_names[b]!r}: the dynamic tree takes one hinge / slide joint per body")
+        if m.jnt_stiffness[j] != 0.0:
+            raise ValueError("joint stiffness is not modelled")
+    nd = len(dyn_bodies)
+    if nd > DYN_MAX:
+        raise ValueError(f"{nd} dofs in the actuated tree, the kernel keeps at most {DYN_MAX}")
+    idx = {b: i for i, b in enumerate(dyn_bodies)}
+
+    def owner(b):      # the dynamic body a (possibly welded) body moves with; -1: fixed to the world
+        while b > 0 and b not in idx:
+            b = int(m.body_parent[b])
+        return idx.get(b, -1)
+
+    def frame_in(b, anc):   # pose of body b's frame in the frame of its ancestor `anc` (0 = world)
+        p, q = np.zeros(3), np.array([1.0, 0.0, 0.0, 0.0])
+        chain = []
+        while b != anc:
+            chain.append(b)
+            b = int(m.body_parent[b])
+        for c in reversed(chain):
+            p, q = _compose(p, q, np.asarray(m.body_pos[c], dtype=np.float64), np.asarray(m.body_quat[c], dtype=np.float64))
+        return p, q
+
+    parent = np.full(nd, -1, dtype=np.int32)
+    rel_pos, rel_quat = np.zeros((nd, 3)), np.zeros((nd, 4))
+    mass, ipos, inertia = np.zeros(nd), np.zeros((nd, 3)), np.zeros((nd, 6))
+    for i, b in enumerate(dyn_bodies):
+        pb = int(m.body_parent[b])
+        parent[i] = owner(pb)
+        anc = dyn_bodies[parent[i]] if parent[i] >= 0 else 0
+        rel_pos[i], rel_quat[i] = frame_in(b, anc)
+        # lump: the body itself + everything welded to it
+        parts = []
+        for w in sub:
+            if owner(w) != i:
+                continue
+            if w != b and m.body_jntnum[w] > 0:
+                continue
+            if m.body_mass[w] <= 0.0:
+                continue
+            p, q = frame_in(w, b)
+            R = _quat_to_mat(q)
+            xx, yy, zz, xy, xz, yz = m.body_inertia[w]
+            T = R @ np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]) @ R.T
+            parts.append((float(m.body_mass[w]), p + R @ np.asarray(m.body_ipos[w], dtype=np.float64), T))
+        mt = sum(p[0] for p in parts)
+        if mt <= 0.0:
+            raise ValueError(f"dynamic body {m.body_names[b]!r} has no mass")
+        c = sum(p[0] * p[1] for p in parts) / mt
+        T = np.zeros((3, 3))
+        for pm, pc, pT in parts:
+            d = pc - c
+            T += pT + pm * (float(d @ d) * np.eye(3) - np.outer(d, d))
+        mass[i], ipos[i] = mt, c
+        inertia[i] = [T[0, 0], T[1, 1], T[2, 2], T[0, 1], T[0, 2], T[1, 2]]
+
+    jid = np.array([int(m.body_jntadr[b]) for b in dyn_bodies])
+    qadr = m.jnt_qposadr[jid].astype(np.int32)
+    arm = set(int(a) for a in facts.arm_qpos_idx)
+    actuated, kp = np.zeros(nd, dtype=np.int32), np.zeros(nd)
+    flo, fhi = np.full(nd, -np.inf), np.full(nd, np.inf)
+    n_act = len(facts.act_qpos_idx)
+    for k in range(n_act):
+        i = int(np.where(qadr == int(facts.act_qpos_idx[k]))[0][0])
+        if int(m.act_kind[k]) != 1:
+            raise ValueError("only position servos are modelled")
+        actuated[i], kp[i] = 1, float(m.act_gain[k])
+        if m.act_forcelimited[k]:
+            flo[i], fhi[i] = m.act_forcerange[k]
+    nsub = int(frame_dt / float(m.opt[3]))
+    return DynFacts(
+        nd=nd, body=np.array(dyn_bodies, dtype=np.int32), parent=parent, jtype=m.jnt_type[jid].astype(np.int32), qadr=qadr,
+        rel_pos=rel_pos, rel_quat=rel_quat, axis=np.asarray(m.jnt_axis[jid], dtype=np.float64).copy(),
+        jpos=np.asarray(m.jnt_pos[jid], dtype=np.float64).copy(), qref=np.asarray(m.jnt_ref[jid], dtype=np.float64).copy(),
+        mass=mass, ipos=ipos, inertia=inertia,
+        damping=np.asarray(m.jnt_damping[jid], dtype=np.float64).copy(), armature=np.asarray(m.jnt_armature[jid], dtype=np.float64).copy(),
+        limited=np.asarray(facts.qpos_limited, dtype=np.int32)[qadr].copy(), lo=np.asarray(facts.qpos_min, dtype=np.float64)[qadr].copy(),
+        hi=np.asarray(facts.qpos_max, dtype=np.float64)[qadr].copy(),
+        actuated=actuated, kp=kp, force_lo=flo, force_hi=fhi,
+        gravcomp=np.array([1 if int(a) in arm else 0 for a in qadr], dtype=np.int32),
+        gravity=np.asarray(m.opt[:3], dtype=np.float64).copy(), timestep=float(m.opt[3]), nsub=nsub)

@@ -168,6 +168,22 @@ class CompiledModel:
     act_joint: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))        # [nu] joint id
     act_ctrllimited: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))  # [nu]
     act_ctrlrange: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), dtype=np.float64))
+    # ---- dynamics (servo dynamics of SURVEY.md 8 f4b; absent in scenes compiled before they were kept) ----
+    # body inertials as MuJoCo's compiler derives them (explicit <inertial>, else summed over ALL the body's geoms at
+    # their density / mass -- `inertiafromgeom="auto"`), kept as COM + full tensor about the COM in the body frame
+    # (MuJoCo stores the same thing as a principal frame `body_iquat` + `body_inertia` diagonal)
+    body_mass: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))       # [nbody]
+    body_ipos: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), dtype=np.float64))  # [nbody,3]
+    body_inertia: np.ndarray = field(default_factory=lambda: np.zeros((0, 6), dtype=np.float64))  # [nbody,6] xx yy zz xy xz yz
+    jnt_damping: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))     # [njnt]
+    jnt_armature: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))    # [njnt]
+    jnt_stiffness: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))   # [njnt]
+    act_kind: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))          # [nu] 0 motor, 1 position, 2 velocity
+    act_gain: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))        # [nu] kp / kv / 1
+    act_gear: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))        # [nu] gear[0]
+    act_forcelimited: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))  # [nu]
+    act_forcerange: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), dtype=np.float64))
+    opt: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))             # [4] gravity xyz, timestep
     meta: Dict[str, object] = field(default_factory=dict)
 
     # ---- name lookups mirroring the mujoco-py calls the reference makes ----
@@ -201,6 +217,8 @@ class CompiledModel:
     ).split()
     _OPTIONAL = "geom_dataid mesh_vertadr mesh_vertnum mesh_vert".split()   # absent in scenes without collidable meshes
     _ACT = "act_joint act_ctrllimited act_ctrlrange".split()                  # absent in scenes compiled before actuators were kept
+    _DYN = ("body_mass body_ipos body_inertia jnt_damping jnt_armature jnt_stiffness act_kind act_gain act_gear act_forcelimited "
+            "act_forcerange opt").split()                                   # absent in scenes compiled before round 3
     _LISTS = "body_names jnt_names all_geom_names geom_mesh site_names".split()
 
     def to_json(self) -> str:
@@ -208,7 +226,8 @@ class CompiledModel:
         for k in self._LISTS:
             d[k] = getattr(self, k)
         d["act_names"] = list(self.act_names)
-        for k in self._ARRAYS + ([k for k in self._OPTIONAL] if len(self.mesh_vertnum) else []) + self._ACT:
+        for k in self._ARRAYS + ([k for k in self._OPTIONAL] if len(self.mesh_vertnum) else []) + self._ACT + \
+                (self._DYN if len(self.body_mass) else []):
             a = getattr(self, k)
             d[k] = {"dtype": str(a.dtype), "shape": list(a.shape),
                     "data": [float(x).hex() if a.dtype.kind == "f" else int(x) for x in a.ravel()]}
@@ -221,7 +240,7 @@ class CompiledModel:
         for k in cls._LISTS:
             kw[k] = list(d[k])
         kw["act_names"] = list(d.get("act_names", []))
-        for k in cls._ARRAYS + [k for k in cls._OPTIONAL + cls._ACT if k in d]:
+        for k in cls._ARRAYS + [k for k in cls._OPTIONAL + cls._ACT + cls._DYN if k in d]:
             e = d[k]
             if e["dtype"].startswith("float"):
                 a = np.array([float.fromhex(x) for x in e["data"]], dtype=np.float64)
@@ -321,6 +340,66 @@ def _load_mesh(path: str, scale) -> Tuple[np.ndarray, np.ndarray]:
     return hv, centroid
 
 
+
+def _read_stl(path: str, scale) -> np.ndarray:
+    """Binary-STL triangles [ntri, 3, 3] (float64, scaled), mesh frame."""
+    raw = open(path, "rb").read()
+    ntri = int(np.frombuffer(raw[80:84], dtype="<u4")[0])
+    if len(raw) != 84 + 50 * ntri:
+        raise MjcfError(f"{path}: only binary STL meshes are supported")
+    rec = np.frombuffer(raw[84:], dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]))
+    return rec["v"].astype(np.float64) * np.asarray(scale, dtype=np.float64)
+
+
+def _mesh_mass_props(tri: np.ndarray) -> Tuple[float, np.ndarray, np.ndarray]:
+    """(volume, centroid, unit-density inertia tensor about the centroid) of the closed triangle surface `tri`, by the
+    divergence theorem over signed tetrahedra (origin, a, b, c).  MuJoCo's compiler derives a mesh geom's mass and
+    inertia from its triangles the same way (mass = density * volume)."""
+    a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+    det = np.einsum("ij,ij->i", a, np.cross(b, c))
+    vol = det.sum() / 6.0
+    if not vol > 0:
+        raise MjcfError("mesh with non-positive volume (open or inward-facing surface)")
+    centroid = ((a + b + c) * det[:, None]).sum(0) / 24.0 / vol
+    # second moments  S = integral of x x^T dV  (canonical tetrahedron formula)
+    S = np.zeros((3, 3))
+    for p, q in ((a, a), (b, b), (c, c)):
+        S += np.einsum("i,ij,ik->jk", det, p, q) * 2.0
+    for p, q in ((a, b), (a, c), (b, c)):
+        S += np.einsum("i,ij,ik->jk", det, p, q) + np.einsum("i,ij,ik->jk", det, q, p)
+    S /= 120.0
+    S -= vol * np.outer(centroid, centroid)
+    inertia = np.trace(S) * np.eye(3) - S
+    return float(vol), centroid, inertia
+
+
+def _shape_mass_props(gtype: int, size) -> Tuple[float, np.ndarray]:
+    """(volume, unit-density inertia diagonal about the centre, own axes) of a primitive geom."""
+    r = float(size[0])
+    if gtype == GEOM_SPHERE:
+        v = 4.0 / 3.0 * math.pi * r ** 3
+        return v, np.full(3, 0.4 * v * r * r)
+    if gtype == GEOM_CAPSULE:
+        l = float(size[1])
+        vc, vs = math.pi * r * r * 2.0 * l, 4.0 / 3.0 * math.pi * r ** 3
+        ixx = vc * (3.0 * r * r + 4.0 * l * l) / 12.0 + vs * (0.4 * r * r + 0.75 * r * l + l * l)
+        return vc + vs, np.array([ixx, ixx, vc * r * r / 2.0 + vs * 0.4 * r * r])
+    if gtype == GEOM_CYLINDER:
+        l = float(size[1])
+        v = math.pi * r * r * 2.0 * l
+        ixx = v * (3.0 * r * r + 4.0 * l * l) / 12.0
+        return v, np.array([ixx, ixx, v * r * r / 2.0])
+    if gtype == GEOM_BOX:
+        a, b, c = (float(x) for x in size[:3])
+        v = 8.0 * a * b * c
+        return v, np.array([v * (b * b + c * c) / 3.0, v * (a * a + c * c) / 3.0, v * (a * a + b * b) / 3.0])
+    raise MjcfError(f"no mass properties for geom type {GEOM_TYPE_NAMES.get(gtype, gtype)}")
+
+
+def _quat_to_mat(q) -> np.ndarray:
+    return np.stack([_quat_rotate(q, e) for e in np.eye(3)], axis=1)
+
+
 class _Builder:
     def __init__(self, xml_path: str):
         self.xml_path = xml_path
@@ -334,6 +413,12 @@ class _Builder:
         for c in root.findall("compiler"):
             comp.update(c.attrib)
         self.to_rad = 1.0 if comp.get("angle", "degree") == "radian" else math.pi / 180.0
+        self.inertiafromgeom = comp.get("inertiafromgeom", "auto")
+        optn: Dict[str, str] = {}
+        for o in root.findall("option"):
+            optn.update(o.attrib)
+        self.gravity = np.array(_floats(optn.get("gravity", "0 0 -9.81")), dtype=np.float64)
+        self.timestep = float(optn.get("timestep", "0.002"))
         self.eulerseq = comp.get("eulerseq", "xyz")
         self.defaults = _Defaults()
         for d in root.findall("default"):
@@ -372,7 +457,7 @@ class _Builder:
 
     def build(self) -> CompiledModel:
         world = {"name": "world", "parent": 0, "pos": np.zeros(3), "quat": np.array([1.0, 0, 0, 0]),
-                 "jntadr": -1, "jntnum": 0}
+                 "jntadr": -1, "jntnum": 0, "inertial": None}
         self.bodies.append(world)
         # world-level elements of every <worldbody> section, in document order
         wbs = self.root.findall("worldbody")
@@ -398,7 +483,10 @@ class _Builder:
         bid = len(self.bodies)
         b = {"name": elem.attrib.get("name", f"body{bid}"), "parent": parent,
              "pos": np.array(_floats(elem.attrib.get("pos", "0 0 0")), dtype=np.float64),
-             "quat": self._orient(elem.attrib), "jntadr": -1, "jntnum": 0}
+             "quat": self._orient(elem.attrib), "jntadr": -1, "jntnum": 0, "inertial": None}
+        ine = elem.find("inertial")
+        if ine is not None:
+            b["inertial"] = dict(ine.attrib)
         self.bodies.append(b)
         self._body_contents(elem, bid, childclass)
         for ch in elem:
@@ -427,7 +515,9 @@ class _Builder:
         limited = at.get("limited", "false") == "true"
         j = {"name": at.get("name", f"joint{jid}"), "type": jtype, "qposadr": self.nq, "body": bid,
              "axis": axis, "pos": np.array(_floats(at.get("pos", "0 0 0")), dtype=np.float64),
-             "ref": ref, "limited": int(limited), "range": np.array(rng, dtype=np.float64)}
+             "ref": ref, "limited": int(limited), "range": np.array(rng, dtype=np.float64),
+             "damping": float(at.get("damping", "0")), "armature": float(at.get("armature", "0")),
+             "stiffness": float(at.get("stiffness", "0"))}
         self.joints.append(j)
         body = self.bodies[bid]
         if body["jntnum"] == 0:
@@ -462,7 +552,8 @@ class _Builder:
         g = {"name": at.get("name", ""), "type": gtype, "body": bid, "size": np.array(size, dtype=np.float64),
              "pos": pos, "quat": quat, "contype": int(at.get("contype", "1")),
              "conaffinity": int(at.get("conaffinity", "1")), "margin": float(at.get("margin", "0")),
-             "mesh": at.get("mesh", "")}
+             "mesh": at.get("mesh", ""), "density": float(at.get("density", "1000")),
+             "mass": (float(at["mass"]) if "mass" in at else None)}
         self.geoms.append(g)
 
     def _site(self, elem: ET.Element, bid: int, childclass: Optional[str]) -> None:
@@ -470,6 +561,58 @@ class _Builder:
         self.sites.append({"name": at.get("name", ""), "body": bid,
                            "pos": np.array(_floats(at.get("pos", "0 0 0")), dtype=np.float64),
                            "quat": self._orient(at)})
+
+    def _inertials(self, geoms: List[dict]):
+        """Body mass / COM / inertia tensor about the COM (body frame) by MuJoCo's compile rule: an explicit <inertial>
+        wins (unless inertiafromgeom="true"); otherwise every geom of the body contributes density * volume (or its
+        `mass`) -- visual mesh geoms included, so bodies that carry a mesh and a collision primitive count both."""
+        nb = len(self.bodies)
+        mass, ipos, inertia = np.zeros(nb), np.zeros((nb, 3)), np.zeros((nb, 6))
+        mesh_cache: Dict[str, Tuple[float, np.ndarray, np.ndarray]] = {}
+        for b in range(1, nb):
+            ine = self.bodies[b]["inertial"]
+            if ine is not None and self.inertiafromgeom != "true":
+                m = float(ine["mass"])
+                R = _quat_to_mat(self._orient(ine))
+                if "fullinertia" in ine:
+                    xx, yy, zz, xy, xz, yz = _floats(ine["fullinertia"])
+                    T = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]])
+                else:
+                    T = np.diag(_floats(ine.get("diaginertia", "0 0 0")))
+                T = R @ T @ R.T
+                c = np.array(_floats(ine.get("pos", "0 0 0")))
+            elif self.inertiafromgeom == "false":
+                continue
+            else:
+                parts = []
+                for g in geoms:
+                    if g["body"] != b or g["type"] == GEOM_PLANE:
+                        continue
+                    R = _quat_to_mat(g["quat"])
+                    if g["type"] == GEOM_MESH:
+                        if g["mesh"] not in mesh_cache:
+                            path, scale = self.mesh_assets[g["mesh"]]
+                            mesh_cache[g["mesh"]] = _mesh_mass_props(_read_stl(path, scale))
+                        vol, cen, Ti = mesh_cache[g["mesh"]]
+                        gc = g["pos"] + R @ cen
+                        Ti = R @ Ti @ R.T
+                    else:
+                        vol, d = _shape_mass_props(g["type"], g["size"])
+                        gc = g["pos"]
+                        Ti = R @ np.diag(d) @ R.T
+                    gm = g["mass"] if g["mass"] is not None else g["density"] * vol
+                    parts.append((gm, gc, Ti * (gm / vol)))
+                m = sum(p[0] for p in parts)
+                if not parts or m <= 0.0:
+                    continue
+                c = sum(p[0] * p[1] for p in parts) / m
+                T = np.zeros((3, 3))
+                for gm, gc, Ti in parts:
+                    d = gc - c
+                    T += Ti + gm * (float(d @ d) * np.eye(3) - np.outer(d, d))
+            mass[b], ipos[b] = m, c
+            inertia[b] = [T[0, 0], T[1, 1], T[2, 2], T[0, 1], T[0, 2], T[1, 2]]
+        return mass, ipos, inertia
 
     # ----------------------------------------------------------------------
     def _finish(self) -> CompiledModel:
@@ -554,6 +697,7 @@ class _Builder:
             # the geom frame follows the re-centred mesh; size = half extents of the hull's AABB (as MuJoCo reports it)
             g["pos"] = g["pos"] + _quat_rotate(g["quat"], centroid)
             g["size"] = 0.5 * (hv.max(0) - hv.min(0))
+        body_mass, body_ipos, body_inertia = self._inertials(geoms)
         acts = []
         jnames = [j["name"] for j in self.joints]
         for sec in self.root.findall("actuator"):
@@ -561,9 +705,16 @@ class _Builder:
                 at = self._attrs(el, None)
                 if "joint" not in at:
                     raise MjcfError(f"actuator <{el.tag}> without joint= is not supported by this MJCF subset")
+                if el.tag not in ("motor", "position", "velocity"):
+                    raise MjcfError(f"actuator <{el.tag}> is not supported by this MJCF subset")
                 acts.append({"name": at.get("name", ""), "joint": jnames.index(at["joint"]),
                              "limited": int(at.get("ctrllimited", "false") == "true"),
-                             "range": (_floats(at.get("ctrlrange", "0 0")) + [0.0, 0.0])[:2]})
+                             "range": (_floats(at.get("ctrlrange", "0 0")) + [0.0, 0.0])[:2],
+                             "kind": ("motor", "position", "velocity").index(el.tag),
+                             "gain": float(at.get({"motor": "_", "position": "kp", "velocity": "kv"}[el.tag], "1")),
+                             "gear": _floats(at.get("gear", "1"))[0],
+                             "flimited": int(at.get("forcelimited", "false") == "true"),
+                             "frange": (_floats(at.get("forcerange", "0 0")) + [0.0, 0.0])[:2]})
         nj = len(self.joints)
         jr = np.zeros((nj, 2))
         for i, j in enumerate(self.joints):
@@ -603,6 +754,14 @@ class _Builder:
             act_names=[a["name"] for a in acts], act_joint=arr(acts, "joint", np.int32),
             act_ctrllimited=arr(acts, "limited", np.int32),
             act_ctrlrange=np.array([a["range"] for a in acts], dtype=np.float64).reshape(-1, 2),
+            body_mass=body_mass, body_ipos=body_ipos, body_inertia=body_inertia,
+            jnt_damping=arr(self.joints, "damping", np.float64), jnt_armature=arr(self.joints, "armature", np.float64),
+            jnt_stiffness=arr(self.joints, "stiffness", np.float64),
+            act_kind=arr(acts, "kind", np.int32), act_gain=arr(acts, "gain", np.float64),
+            act_gear=arr(acts, "gear", np.float64),
+            act_forcelimited=arr(acts, "flimited", np.int32),
+            act_forcerange=np.array([a["frange"] for a in acts], dtype=np.float64).reshape(-1, 2),
+            opt=np.array([*self.gravity, self.timestep], dtype=np.float64),
             meta={"source": os.path.basename(self.xml_path)},
         )
 

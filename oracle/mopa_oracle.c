@@ -1474,9 +1474,16 @@ int orc_env_obs_dim(const OrcEnvDesc *d) {
 }
 int orc_env_action_dim(const OrcEnvDesc *d) { return d->n_arm + (d->kind == 1 ? 1 : 0); }
 
-void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *prev_state, uint8_t *has_prev,
-                  int32_t *ep_len, const double *action, int is_planner, int move, double *obs, double *reward,
-                  uint8_t *done, uint8_t *success) {
+#include "mopa_oracle_dyn.inc"
+
+/* dyn == NULL: the kinematic limit (K4).  dyn != NULL (SURVEY 8 f4b stage A): `_do_simulation` is the contact-free servo
+ * dynamics of mopa_oracle_dyn.inc -- nsub sub-steps towards ctrl, qvel / bias_lag carried per env; obs then reports the
+ * joint velocities, and the reference's order is kept: physics -> reward / obs -> joint-limit clamp (env/base.py:269-290;
+ * a no-op here, the sub-steps stop a joint at the same limits). */
+static void env_step_impl(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDesc *dyn, double *qvel, double *bias_lag,
+                          double *qpos, double *prev_state, uint8_t *has_prev,
+                          int32_t *ep_len, const double *action, int is_planner, int move, double *obs, double *reward,
+                          uint8_t *done, uint8_t *success) {
     const int na = d->n_arm;
     if (action && (move & 2)) return;   /* flags: bit 0 = the actuated joints move, bit 1 = env sits this step out */
     move &= 1;
@@ -1491,11 +1498,23 @@ void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *
             prev_state[j] = desired;
         }
         for (int k = na; k < d->n_act; k++) ctrl[k] = qpos[d->act_qpos_idx[k]] + action[na];   /* Lift: gripper_state + action[-1] */
+        if (dyn) {
+            if (move) {
+                double dctrl[ORC_DYN_MAX];
+                for (int i = 0; i < dyn->nd; i++) dctrl[i] = 0.0;
+                for (int k = 0; k < d->n_act; k++)
+                    for (int i = 0; i < dyn->nd; i++)
+                        if (dyn->qadr[i] == d->act_qpos_idx[k]) dctrl[i] = clampd(ctrl[k], d->act_lo[k], d->act_hi[k]);
+                orc_dyn_step(dyn, qpos, qvel, bias_lag, dctrl, dyn->nsub);
+            }
+            *has_prev = 1;
+        } else {
         if (move)
             for (int k = 0; k < d->n_act; k++) qpos[d->act_qpos_idx[k]] = clampd(ctrl[k], d->act_lo[k], d->act_hi[k]);
         *has_prev = 1;
         for (int i = 0; i < s->nq; i++)
             if (d->qpos_limited[i]) qpos[i] = clampd(qpos[i], d->qpos_min[i], d->qpos_max[i]);
+        }
     }
     double *buf = (double *)malloc(sizeof(double) * 16 * s->nbody);
     double *xpos = buf, *xquat = buf + 3 * s->nbody, *xmat = buf + 7 * s->nbody;
@@ -1508,9 +1527,9 @@ void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *
     int succ = 0;
     int o = 0;
     for (int j = 0; j < na; j++) obs[o++] = qpos[d->arm_qpos_idx[j]];          /* joint_pos */
-    for (int j = 0; j < na; j++) obs[o++] = 0.0;                               /* joint_vel */
+    for (int j = 0; j < na; j++) obs[o++] = dyn ? dyn_vel_of(dyn, qvel, d->arm_qpos_idx[j]) : 0.0;          /* joint_vel */
     for (int j = 0; j < d->n_grip; j++) obs[o++] = qpos[d->grip_qpos_idx[j]];  /* gripper_qpos */
-    for (int j = 0; j < d->n_grip; j++) obs[o++] = 0.0;                        /* gripper_qvel */
+    for (int j = 0; j < d->n_grip; j++) obs[o++] = dyn ? dyn_vel_of(dyn, qvel, d->grip_qpos_idx[j]) : 0.0;  /* gripper_qvel */
     for (int i = 0; i < 3; i++) obs[o++] = eef[i];                             /* eef_pos */
     obs[o++] = eq[1]; obs[o++] = eq[2]; obs[o++] = eq[3]; obs[o++] = eq[0];    /* eef_quat, xyzw */
     if (d->kind == 0) {
@@ -1576,8 +1595,38 @@ void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *
         *reward = r;
         *success = (uint8_t)succ;
         *done = (uint8_t)(succ || *ep_len == d->max_episode_steps);
+        if (dyn)     /* `_after_step`'s clamp, after reward / obs as in the reference */
+            for (int i = 0; i < s->nq; i++)
+                if (d->qpos_limited[i]) qpos[i] = clampd(qpos[i], d->qpos_min[i], d->qpos_max[i]);
     }
     free(buf);
+}
+
+void orc_env_step(const OrcScene *s, const OrcEnvDesc *d, double *qpos, double *prev_state, uint8_t *has_prev,
+                  int32_t *ep_len, const double *action, int is_planner, int move, double *obs, double *reward,
+                  uint8_t *done, uint8_t *success) {
+    env_step_impl(s, d, NULL, NULL, NULL, qpos, prev_state, has_prev, ep_len, action, is_planner, move, obs, reward, done, success);
+}
+
+void orc_env_step_dyn(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDesc *dyn, double *qpos, double *qvel, double *bias_lag,
+                      double *prev_state, uint8_t *has_prev, int32_t *ep_len, const double *action, int is_planner, int move,
+                      double *obs, double *reward, uint8_t *done, uint8_t *success) {
+    env_step_impl(s, d, dyn, qvel, bias_lag, qpos, prev_state, has_prev, ep_len, action, is_planner, move, obs, reward, done, success);
+}
+
+void orc_env_step_dyn_batch(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDesc *dyn, int64_t E, double *qpos, double *qvel,
+                            double *bias_lag, double *prev_state, uint8_t *has_prev, int32_t *ep_len, const double *action,
+                            int is_planner, const uint8_t *move_mask, double *obs, double *reward, uint8_t *done,
+                            uint8_t *success, int nthreads) {
+    const int od = orc_env_obs_dim(d), ad = orc_env_action_dim(d);
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (int64_t e = 0; e < E; e++)
+        env_step_impl(s, d, dyn, qvel + e * dyn->nd, bias_lag + e * dyn->nd, qpos + e * s->nq, prev_state + e * d->n_arm,
+                      has_prev + e, ep_len + e, action ? action + e * ad : NULL, is_planner, move_mask ? move_mask[e] : 1,
+                      obs + e * od, reward + e, done + e, success + e);
 }
 
 /* E envs, rows contiguous; OpenMP across envs (bench.py cpu_baseline of the env-step metric) */

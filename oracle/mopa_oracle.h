@@ -121,6 +121,39 @@ void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, doubl
                         int32_t *ep_len, const double *action, int is_planner, const uint8_t *move_mask, double *obs,
                         double *reward, uint8_t *done, uint8_t *success, int nthreads);
 
+
+/* (stage A) contact-free servo dynamics of the actuated kinematic tree -- see mopa_oracle_dyn.inc.
+ * The tree is given LUMPED: one body per dof (bodies welded to it folded into its inertia), parents before children. */
+#define ORC_DYN_MAX 12
+typedef struct OrcDynDesc {
+    int32_t nd;
+    const int32_t *parent;                  /* [nd] parent dynamic body, -1 = the fixed base */
+    const int32_t *jtype;                   /* [nd] 2 slide, 3 hinge (mjtJoint) */
+    const int32_t *qadr;                    /* [nd] qpos address of the dof */
+    const double *rel_pos, *rel_quat;       /* [nd,3] [nd,4] body frame in its parent dynamic body's frame (base: world) */
+    const double *axis, *jpos, *qref;       /* [nd,3] [nd,3] [nd]  joint axis / anchor in the body frame, reference value */
+    const double *mass, *ipos, *inertia;    /* [nd] [nd,3] [nd,6]  lumped; inertia about the COM in body axes: xx yy zz xy xz yz */
+    const double *damping, *armature;       /* [nd] */
+    const int32_t *limited; const double *lo, *hi;   /* [nd] joint range (inelastic stop) */
+    const int32_t *actuated;                /* [nd] a position servo drives this dof: force = clamp(kp ctrl - kp q, force range) */
+    const double *kp, *force_lo, *force_hi; /* [nd] */
+    const int32_t *gravcomp;                /* [nd] qfrc_applied = the qfrc_bias of the previous mj_forward (the env's gravity compensation) */
+    double gravity[3], timestep;
+    int32_t nsub;                           /* sub-steps per env.step (frame_dt / timestep) */
+} OrcDynDesc;
+/* qfrc_bias [nd] (RNE with qacc = 0, gravity included) and, if M != NULL, the joint-space inertia [nd,nd] (CRB + armature) */
+void orc_dyn_forward(const OrcDynDesc *d, const double *qpos, const double *qvel /*[nd]*/, double *bias, double *M);
+/* n sub-steps of mj_step towards ctrl [nd] (already ctrl-range clamped; entries of unactuated dofs ignored); in place */
+void orc_dyn_step(const OrcDynDesc *d, double *qpos /*[nq]*/, double *qvel /*[nd]*/, double *bias_lag /*[nd]*/,
+                  const double *ctrl /*[nd]*/, int n);
+void orc_env_step_dyn(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDesc *dyn, double *qpos, double *qvel, double *bias_lag,
+                      double *prev_state, uint8_t *has_prev, int32_t *ep_len, const double *action, int is_planner, int move,
+                      double *obs, double *reward, uint8_t *done, uint8_t *success);
+void orc_env_step_dyn_batch(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDesc *dyn, int64_t E, double *qpos, double *qvel,
+                            double *bias_lag, double *prev_state, uint8_t *has_prev, int32_t *ep_len, const double *action,
+                            int is_planner, const uint8_t *move_mask, double *obs, double *reward, uint8_t *done,
+                            uint8_t *success, int nthreads);
+
 /*  damped-LS IK of a site pose, one env, in place on qpos -- see mopa_oracle.c.
  * site_quat: orientation of the site in its body's frame (NULL = identity); target_quat NULL = position target only. */
 void orc_ik_solve(const OrcScene *s, int n_joints, const int32_t *joint_ids /*model joint ids, <= 8*/, int site_body,

@@ -89,6 +89,13 @@ def lib():
         L.orc_env_step_batch.restype = None
         L.orc_env_step_batch.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), C.c_int64, _dp, _dp, _u8p, _ip, _dp, C.c_int, _u8p,
                                          _dp, _dp, _u8p, _u8p, C.c_int]
+        L.orc_dyn_forward.restype = None
+        L.orc_dyn_forward.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp]
+        L.orc_dyn_step.restype = None
+        L.orc_dyn_step.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp, C.c_int]
+        L.orc_env_step_dyn_batch.restype = None
+        L.orc_env_step_dyn_batch.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), C.POINTER(OrcDynDesc), C.c_int64, _dp, _dp, _dp,
+                                             _dp, _u8p, _ip, _dp, C.c_int, _u8p, _dp, _dp, _u8p, _u8p, C.c_int]
         _lib = L
     return _lib
 
@@ -115,6 +122,57 @@ class OrcEnvDesc(C.Structure):
     ]
 
 
+class OrcDynDesc(C.Structure):
+    _fields_ = [
+        ("nd", C.c_int32), ("parent", _ip), ("jtype", _ip), ("qadr", _ip), ("rel_pos", _dp), ("rel_quat", _dp),
+        ("axis", _dp), ("jpos", _dp), ("qref", _dp), ("mass", _dp), ("ipos", _dp), ("inertia", _dp),
+        ("damping", _dp), ("armature", _dp), ("limited", _ip), ("lo", _dp), ("hi", _dp),
+        ("actuated", _ip), ("kp", _dp), ("force_lo", _dp), ("force_hi", _dp), ("gravcomp", _ip),
+        ("gravity", C.c_double * 3), ("timestep", C.c_double), ("nsub", C.c_int32),
+    ]
+
+
+class OracleDyn:
+    """The servo dynamics of mopa_oracle_dyn.inc over a `mopa_rl_amd.dynamics.DynFacts` (plain arrays)."""
+
+    def __init__(self, f):
+        self.f, self.nd = f, int(f.nd)
+        self._keep = []
+        d = OrcDynDesc()
+
+        def ip(a):
+            a, p = _i(a); self._keep.append(a); return p
+
+        def dp(a):
+            a, p = _d(a); self._keep.append(a); return p
+
+        d.nd = self.nd
+        d.parent, d.jtype, d.qadr = ip(f.parent), ip(f.jtype), ip(f.qadr)
+        d.rel_pos, d.rel_quat, d.axis, d.jpos, d.qref = dp(f.rel_pos), dp(f.rel_quat), dp(f.axis), dp(f.jpos), dp(f.qref)
+        d.mass, d.ipos, d.inertia = dp(f.mass), dp(f.ipos), dp(f.inertia)
+        d.damping, d.armature = dp(f.damping), dp(f.armature)
+        d.limited, d.lo, d.hi = ip(f.limited), dp(f.lo), dp(f.hi)
+        d.actuated, d.kp, d.force_lo, d.force_hi, d.gravcomp = ip(f.actuated), dp(f.kp), dp(f.force_lo), dp(f.force_hi), ip(f.gravcomp)
+        d.gravity = (C.c_double * 3)(*[float(x) for x in f.gravity])
+        d.timestep, d.nsub = float(f.timestep), int(f.nsub)
+        self.desc = d
+
+    def forward(self, qpos, qvel, want_M: bool = True):
+        q, qp = _d(qpos)
+        v, vp = _d(qvel)
+        bias = np.zeros(self.nd)
+        M = np.zeros((self.nd, self.nd)) if want_M else None
+        lib().orc_dyn_forward(C.byref(self.desc), qp, vp, bias.ctypes.data_as(_dp), M.ctypes.data_as(_dp) if want_M else None)
+        return bias, M
+
+    def step(self, qpos, qvel, bias_lag, ctrl, n: int = 1):
+        """n sub-steps in place on copies; returns (qpos, qvel, bias_lag)."""
+        q, v, lag = (np.array(x, dtype=np.float64, copy=True) for x in (qpos, qvel, bias_lag))
+        c, cp = _d(ctrl)
+        lib().orc_dyn_step(C.byref(self.desc), q.ctypes.data_as(_dp), v.ctypes.data_as(_dp), lag.ctypes.data_as(_dp), cp, int(n))
+        return q, v, lag
+
+
 def atan2(y: float, x: float) -> float:
     return lib().orc_atan2(float(y), float(x))
 
@@ -132,8 +190,9 @@ class OracleEnv:
     `facts` is mopa_rl_amd.kinematic_env.EnvFacts (plain name->id data, no product code runs here)."""
 
     def __init__(self, scene: "OracleScene", facts, E: int, ac_scale=0.05, distance_threshold=0.06, success_reward=150.0,
-                 max_episode_steps=250):
+                 max_episode_steps=250, dyn=None):
         self.scene, self.E, self.nq = scene, int(E), scene.nq
+        self.dyn = OracleDyn(dyn) if dyn is not None else None     # DynFacts: env.step runs the servo dynamics
         self._keep = []
         d = OrcEnvDesc()
 
@@ -164,6 +223,9 @@ class OracleEnv:
         self.reward = np.zeros(self.E)
         self.done = np.zeros(self.E, dtype=np.uint8)
         self.success = np.zeros(self.E, dtype=np.uint8)
+        if self.dyn is not None:
+            self.qvel = np.zeros((self.E, self.dyn.nd))
+            self.bias_lag = np.zeros((self.E, self.dyn.nd))
 
     def _call(self, e, action, is_planner, move):
         L = lib()
@@ -182,12 +244,24 @@ class OracleEnv:
         self.ep_len[:] = 0
         for e in range(self.E):
             self._call(e, None, 0, 1)
+        if self.dyn is not None:      # reset: at rest, qfrc_bias of the `sim.forward()` that follows set_state
+            self.qvel[:] = 0.0
+            for e in range(self.E):
+                self.bias_lag[e] = self.dyn.forward(self.qpos[e], self.qvel[e], want_M=False)[0]
         return self.obs
 
     def step(self, action, is_planner=False, move_mask=None, nthreads: int = 1):
         action = np.ascontiguousarray(action, dtype=np.float64)
         assert action.shape == (self.E, self.action_dim)
         mm = None if move_mask is None else np.ascontiguousarray(move_mask, dtype=np.uint8)
+        if self.dyn is not None:
+            lib().orc_env_step_dyn_batch(
+                self.scene._h, C.byref(self.desc), C.byref(self.dyn.desc), self.E, self.qpos.ctypes.data_as(_dp),
+                self.qvel.ctypes.data_as(_dp), self.bias_lag.ctypes.data_as(_dp), self.prev_state.ctypes.data_as(_dp),
+                self.has_prev.ctypes.data_as(_u8p), self.ep_len.ctypes.data_as(_ip), action.ctypes.data_as(_dp), int(is_planner),
+                mm.ctypes.data_as(_u8p) if mm is not None else None, self.obs.ctypes.data_as(_dp),
+                self.reward.ctypes.data_as(_dp), self.done.ctypes.data_as(_u8p), self.success.ctypes.data_as(_u8p), int(nthreads))
+            return self.obs, self.reward, self.done, self.success
         lib().orc_env_step_batch(
             self.scene._h, C.byref(self.desc), self.E, self.qpos.ctypes.data_as(_dp), self.prev_state.ctypes.data_as(_dp),
             self.has_prev.ctypes.data_as(_u8p), self.ep_len.ctypes.data_as(_ip), action.ctypes.data_as(_dp), int(is_planner),

@@ -1,0 +1,153 @@
+"""CPU tests of the servo-dynamics oracle (SURVEY.md 8 f4b stage A; oracle/mopa_oracle_dyn.inc): the equations against an
+independent Jacobian-based reference over the un-lumped model (tests/dyn_ref.py), and the invariants of the reference's
+env loop (gravity compensation holds the arm, the servo converges to desired_state, energy bookkeeping)."""
+import numpy as np
+import pytest
+
+from mopa_rl_amd.dynamics import dyn_facts
+from mopa_rl_amd.kinematic_env import env_facts
+from mopa_rl_amd.scene import ENV_SPECS, load_scene
+from oracle import oracle as O
+
+import dyn_ref
+
+ENVS = ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"]
+
+
+def _setup(env):
+    m = load_scene(ENV_SPECS[env].scene)
+    f = env_facts(env, m)
+    d = dyn_facts(m, f)
+    q0 = np.array(m.qpos0, dtype=np.float64)
+    q0[f.arm_qpos_idx] = ENV_SPECS[env].init_qpos
+    return m, f, d, O.OracleDyn(d), q0
+
+
+def _random_state(rng, m, f, d, q0):
+    q = q0.copy()
+    for i in range(d.nd):
+        lo, hi = (d.lo[i], d.hi[i]) if d.limited[i] else (-3.0, 3.0)
+        q[d.qadr[i]] = rng.uniform(lo, hi)
+    return q, rng.normal(0, 1.0, d.nd) * np.where(d.jtype == 3, 1.0, 0.02)
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_tree_is_the_arm_and_the_gripper(env):
+    m, f, d, od, q0 = _setup(env)
+    assert d.nd == 9 and list(d.parent) == [-1, 0, 1, 2, 3, 4, 5, 6, 6]
+    assert list(d.qadr[:7]) == list(f.arm_qpos_idx) and sorted(d.qadr[7:]) == sorted(f.grip_qpos_idx)
+    assert d.nsub == 75 and d.timestep == 0.002 and list(d.gravity) == [0.0, 0.0, -9.81]
+    assert list(d.gravcomp) == [1] * 7 + [0, 0]
+    assert list(d.actuated[:7]) == [1] * 7 and list(d.actuated[7:]) == ([1, 1] if env == "SawyerLiftObstacle-v0" else [0, 0])
+    assert list(d.kp[:7]) == [500, 500, 200, 200, 50, 50, 50]        # sawyer_joint_pos_act.xml
+    assert list(d.damping[:7]) == [50, 50, 25, 25, 10, 10, 10] and list(d.damping[7:]) == [100, 100]
+    assert list(d.armature) == [0.1] * 7 + [5, 5]
+    # lumping conserves mass: every body of the arm's subtree is in exactly one lump
+    sub = dyn_ref.subtree_bodies(m, int(d.body[0]))
+    assert abs(d.mass.sum() - m.body_mass[sub].sum()) < 1e-12
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_mass_matrix_and_bias_match_the_jacobian_reference(env):
+    m, f, d, od, q0 = _setup(env)
+    rng = np.random.default_rng(3)
+    for _ in range(6):
+        q, v = _random_state(rng, m, f, d, q0)
+        bias, M = od.forward(q, v)
+        Mr, _ = dyn_ref.mass_matrix(m, q, list(d.body), d.armature)
+        br = dyn_ref.bias_force(m, q, v, list(d.body), list(d.qadr), d.armature)
+        assert np.allclose(M, M.T, rtol=0, atol=0)
+        assert np.abs(M - Mr).max() < 1e-11 * max(1.0, np.abs(Mr).max())
+        assert np.abs(bias - br).max() < 2e-6 * max(1.0, np.abs(br).max())
+        assert np.linalg.eigvalsh(M).min() > 0.09      # >= the smallest armature
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_gravity_compensation_holds_the_arm_still(env):
+    """zero action: ctrl = q, qfrc_applied = qfrc_bias  =>  the arm's acceleration is exactly zero, sub-step after sub-step;
+    only the (uncompensated) gripper slides creep, by less than m g / damping."""
+    m, f, d, od, q0 = _setup(env)
+    lag, _ = od.forward(q0, np.zeros(d.nd), want_M=False)
+    ctrl = q0[d.qadr].copy()
+    q, v, lag2 = od.step(q0, np.zeros(d.nd), lag, ctrl, n=75)
+    if env == "SawyerLiftObstacle-v0":
+        # the finger servos (kp 1e4) hold the slides against gravity: 0.03 kg * g / 1e4 = 3e-5 m of sag at most
+        assert np.abs(q[d.qadr[7:]] - q0[d.qadr[7:]]).max() < 5e-5
+    else:
+        assert 0 < np.abs(v[7:]).max() < 0.01 * 9.81 / 100 * 1.01
+    # the slides' motion reacts on the arm through M only at the 1e-7 level
+    assert np.abs(q[d.qadr[:7]] - q0[d.qadr[:7]]).max() < 1e-6
+    assert np.abs(v[:7]).max() < 1e-5
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_servo_converges_to_desired_state(env):
+    m, f, d, od, q0 = _setup(env)
+    lag, _ = od.forward(q0, np.zeros(d.nd), want_M=False)
+    ctrl = q0[d.qadr].copy()
+    ctrl[:7] += np.array([0.05, -0.05, 0.05, -0.05, 0.05, -0.05, 0.05])
+    q, v = q0.copy(), np.zeros(d.nd)
+    err = []
+    for _ in range(40):                       # 40 env steps of 75 sub-steps = 6 s
+        q, v, lag = od.step(q, v, lag, ctrl, n=75)
+        err.append(np.abs(q[d.qadr[:7]] - ctrl[:7]).max())
+    assert err[0] < 0.05 and err[0] > 0.005          # one env.step does NOT reach the target (zeta ~ 0.5: it overshoots later)
+    env_ = [max(err[k:k + 4]) for k in range(0, 40, 4)]          # the oscillation's envelope decays
+    assert all(b < a for a, b in zip(env_, env_[1:]))
+    assert err[-1] < 1e-5 and np.abs(v[:7]).max() < 1e-5
+
+
+def test_energy_bookkeeping_without_servo_or_damping():
+    """no damping, no actuation, no gravity compensation: the semi-implicit Euler step keeps the total energy of the
+    free-swinging arm to O(h) (a wrong Coriolis / gravity term drifts by orders of magnitude more)."""
+    m, f, d, od, q0 = _setup("SawyerPushObstacle-v0")
+    import copy
+    d2 = copy.copy(d)
+    d2.damping = np.zeros(d.nd)
+    d2.actuated = np.zeros(d.nd, dtype=np.int32)
+    d2.gravcomp = np.zeros(d.nd, dtype=np.int32)
+    d2.limited = np.zeros(d.nd, dtype=np.int32)
+    od2 = O.OracleDyn(d2)
+
+    def energy(q, v):
+        _, M = od2.forward(q, v)
+        P, R = dyn_ref.fk(m, q)
+        pe = 0.0
+        for b in dyn_ref.subtree_bodies(m, int(d.body[0])):
+            pe += m.body_mass[b] * 9.81 * (P[b] + R[b] @ m.body_ipos[b])[2]
+        return 0.5 * v @ M @ v + pe
+
+    q, v, lag = q0.copy(), np.zeros(d.nd), np.zeros(d.nd)
+    e0 = energy(q, v)
+    q, v, lag = od2.step(q, v, lag, np.zeros(d.nd), n=200)      # 0.4 s of free fall of the arm
+    e1 = energy(q, v)
+    ke = 0.5 * v @ od2.forward(q, v)[1] @ v
+    assert ke > 1.0                                   # it did fall
+    assert abs(e1 - e0) < 0.02 * ke
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_env_step_with_dynamics(env):
+    """orc_env_step_dyn: obs carries the joint velocities, the arm lags its target, episode bookkeeping as in the kinematic env."""
+    m, f, d, od, q0 = _setup(env)
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(env, m)
+    orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    E = 3
+    ed = O.OracleEnv(orc, f, E, dyn=d)
+    ek = O.OracleEnv(orc, f, E)
+    rows = np.repeat(q0[None], E, 0)
+    ed.set_state(rows)
+    ek.set_state(rows)
+    rng = np.random.default_rng(1)
+    for t in range(3):
+        a = rng.uniform(-1, 1, size=(E, ed.action_dim))
+        od_, rd, dd, _ = ed.step(a)
+        ok_, rk, dk, _ = ek.step(a)
+        jv = od_[:, 7:14]
+        assert np.abs(jv).max() > 1e-3 and np.all(ok_[:, 7:14] == 0.0)
+        # the dynamic arm moves towards the same desired state but has not reached it
+        des = ek.qpos[:, f.arm_qpos_idx]
+        assert np.all(np.abs(ed.qpos[:, f.arm_qpos_idx] - des) < 0.06)
+        assert np.abs(ed.qpos[:, f.arm_qpos_idx] - des).max() > 1e-3
+        assert np.array_equal(ed.prev_state, ek.prev_state) and np.array_equal(ed.ep_len, ek.ep_len)

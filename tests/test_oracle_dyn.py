@@ -141,13 +141,13 @@ def test_env_step_with_dynamics(env):
     ek.set_state(rows)
     rng = np.random.default_rng(1)
     for t in range(3):
-        a = rng.uniform(-1, 1, size=(E, ed.action_dim))
-        od_, rd, dd, _ = ed.step(a)
-        ok_, rk, dk, _ = ek.step(a)
+        a = rng.uniform(-0.05, 0.05, size=(E, ed.action_dim))      # planner-style steps: desired_state chains on prev_state
+        od_, rd, dd, _ = ed.step(a, is_planner=True)
+        ok_, rk, dk, _ = ek.step(a, is_planner=True)
         jv = od_[:, 7:14]
         assert np.abs(jv).max() > 1e-3 and np.all(ok_[:, 7:14] == 0.0)
         # the dynamic arm moves towards the same desired state but has not reached it
         des = ek.qpos[:, f.arm_qpos_idx]
-        assert np.all(np.abs(ed.qpos[:, f.arm_qpos_idx] - des) < 0.06)
+        assert np.all(np.abs(ed.qpos[:, f.arm_qpos_idx] - des) < 0.12)
         assert np.abs(ed.qpos[:, f.arm_qpos_idx] - des).max() > 1e-3
         assert np.array_equal(ed.prev_state, ek.prev_state) and np.array_equal(ed.ep_len, ek.ep_len)

@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
+    "mopa_env_attach_dynamics", "mopa_env_dyn_dofs", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch",
     "mopa_paths_unwrap_batch", "mopa_paths_walk_batch", "mopa_paths_assemble_batch", "mopa_interpolate_batch",
 ]
@@ -67,6 +68,16 @@ class MopaEnvDesc(C.Structure):
         ("qpos_min", _dp), ("qpos_max", _dp), ("qpos_limited", _ip),
         ("ac_scale", C.c_double), ("distance_threshold", C.c_double), ("success_reward", C.c_double),
         ("max_episode_steps", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+class MopaDynDesc(C.Structure):
+    _fields_ = [
+        ("nd", C.c_int32), ("parent", _ip), ("jtype", _ip), ("qadr", _ip), ("rel_pos", _dp), ("rel_quat", _dp),
+        ("axis", _dp), ("jpos", _dp), ("qref", _dp), ("mass", _dp), ("ipos", _dp), ("inertia", _dp),
+        ("damping", _dp), ("armature", _dp), ("limited", _ip), ("lo", _dp), ("hi", _dp),
+        ("actuated", _ip), ("kp", _dp), ("force_lo", _dp), ("force_hi", _dp), ("gravcomp", _ip),
+        ("gravity", C.c_double * 3), ("timestep", C.c_double), ("nsub", C.c_int32),
     ]
 
 
@@ -129,6 +140,11 @@ def lib() -> C.CDLL:
     L.mopa_env_action_dim.argtypes = [vp]
     L.mopa_env_exec_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mopa_env_desired_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp, vp]
+    L.mopa_env_attach_dynamics.argtypes = [vp, C.POINTER(MopaDynDesc)]
+    L.mopa_env_dyn_dofs.argtypes = [vp]
+    L.mopa_env_dyn_forward_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]
+    L.mopa_env_dyn_substeps_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp]
+    L.mopa_env_step_dyn_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
     L.mopa_ik_create.argtypes = [C.POINTER(MopaIkDesc), C.POINTER(vp)]
     L.mopa_ik_destroy.argtypes = [vp]
     L.mopa_ik_destroy.restype = None

@@ -1317,5 +1317,6 @@ extern "C" const char *mopa_planner_status(const MopaScene *S) { return S ? S->s
 #include "mopa_planner.inc"
 #include "mopa_pullback.inc"
 #include "mopa_env.inc"
+#include "mopa_dyn.inc"
 #include "mopa_ik.inc"
 #include "mopa_paths.inc"

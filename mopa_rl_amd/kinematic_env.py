@@ -13,6 +13,11 @@ the "env-steps/sec" half of the metric, and the planner-side rollouts of MoPA-RL
 path is executed kinematically by construction).  Checked against the reference's own env classes run over a
 sim-shaped adapter (tests/golden/ref_py_env_*.npz, tools/gen_ref_py_golden.py) and bit for bit against the CPU oracle.
 
+`dynamics=True` (stage A) puts the physics back for a robot that touches nothing: `_do_simulation` becomes
+the reference's 75 sub-steps of force-limited position servos with gravity compensation, on the arm's own tree (K6,
+`csrc/mopa_dyn.inc`, `dynamics.py`): the arm lags `desired_state` as the real one does, the obs carries joint velocities,
+`qvel` / `bias_lag` are carried per env.  Still no contacts: manipulated objects do not move.
+
 `block_invalid=True` adds the one piece of contact behaviour a kinematic arm can have: a step whose desired state is
 in collision (K1 validity kernel, same rule as the planner) is not executed -- the arm stays where it is.
 
@@ -152,7 +157,7 @@ class BatchKinematicEnv:
 
     def __init__(self, env_name: str, num_envs: int, device=None, seed: int = 0, max_episode_steps: int = 250,
                  distance_threshold: float = 0.06, success_reward: float = 150.0, ac_scale: Optional[float] = None,
-                 block_invalid: bool = False, model=None):
+                 block_invalid: bool = False, model=None, dynamics: bool = False, frame_dt: float = 0.15):
         torch = _torch()
         if env_name not in ENV_KIND:
             raise _lib.MopaError(f"no batched kinematic env for {env_name!r}")
@@ -220,6 +225,25 @@ class BatchKinematicEnv:
         self._jitter_idx = torch.tensor(f.reset_jitter_idx, dtype=torch.long, device=dev)
         self._planner = None
         self._scene = None
+        self.dynamics = bool(dynamics)
+        self.dyn = None
+        if self.dynamics:
+            from .dynamics import dyn_facts
+            self.dyn = df = dyn_facts(self.model, f, frame_dt=frame_dt)
+            dd = _lib.MopaDynDesc()
+            dd.nd = df.nd
+            dd.parent, dd.jtype, dd.qadr = ip(df.parent), ip(df.jtype), ip(df.qadr)
+            dd.rel_pos, dd.rel_quat, dd.axis, dd.jpos, dd.qref = dp(df.rel_pos), dp(df.rel_quat), dp(df.axis), dp(df.jpos), dp(df.qref)
+            dd.mass, dd.ipos, dd.inertia = dp(df.mass), dp(df.ipos), dp(df.inertia)
+            dd.damping, dd.armature = dp(df.damping), dp(df.armature)
+            dd.limited, dd.lo, dd.hi = ip(df.limited), dp(df.lo), dp(df.hi)
+            dd.actuated, dd.kp, dd.force_lo, dd.force_hi, dd.gravcomp = ip(df.actuated), dp(df.kp), dp(df.force_lo), dp(df.force_hi), ip(df.gravcomp)
+            dd.gravity = (C.c_double * 3)(*[float(x) for x in df.gravity])
+            dd.timestep, dd.nsub = float(df.timestep), int(df.nsub)
+            _lib.check(L.mopa_env_attach_dynamics(self._h, C.byref(dd)))
+            assert L.mopa_env_dyn_dofs(self._h) == df.nd
+            self.qvel = torch.zeros(self.E, df.nd, dtype=f64, device=dev)        # velocities of the dynamic dofs (arm, gripper)
+            self.bias_lag = torch.zeros(self.E, df.nd, dtype=f64, device=dev)    # qfrc_bias of the last mj_forward
         self._desired = torch.zeros(self.E, self.n_arm, dtype=f64, device=dev)
         self._move = torch.zeros(self.E, dtype=torch.uint8, device=dev)
         if block_invalid:
@@ -243,6 +267,13 @@ class BatchKinematicEnv:
             pass
 
     def _launch(self, action, is_planner: bool, move_mask, stream=None):
+        if self.dynamics:
+            _lib.check(_lib.lib().mopa_env_step_dyn_batch(
+                self._h, self.E, _ptr(self.qpos), _ptr(self.qvel), _ptr(self.bias_lag), _ptr(self.prev_state), _ptr(self.has_prev),
+                _ptr(self.ep_len), _ptr(action) if action is not None else None, int(bool(is_planner)),
+                _ptr(move_mask) if move_mask is not None else None, _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
+                _ptr(self.success), _stream_handle(stream)))
+            return
         _lib.check(_lib.lib().mopa_env_step_batch(
             self._h, self.E, _ptr(self.qpos), _ptr(self.prev_state), _ptr(self.has_prev), _ptr(self.ep_len),
             _ptr(action) if action is not None else None, int(bool(is_planner)),
@@ -256,6 +287,8 @@ class BatchKinematicEnv:
         (envs with more action entries than arm joints, i.e. Lift): the policy's gripper action, applied at the LAST
         waypoint of a path (:163-167); the other waypoints carry `form_action`'s gripper difference.  rec: optional dict
         with 'ob' [E,L,obs_dim] f64, 'meta_rew' [E,L] f64, 'done' [E,L] uint8, 'n_exec' [E] int64 filled per executed waypoint."""
+        if self.dynamics:
+            raise _lib.MopaError("waypoint execution with dynamics=True is not built yet (each waypoint is 75 dependent sub-steps)")
         L = int(traj.shape[1])
         r = rec or {}
         p = lambda k: _ptr(r[k]) if k in r else None
@@ -286,6 +319,7 @@ class BatchKinematicEnv:
             self.qpos.copy_(torch.where(mk[:, None], q, self.qpos))
             self.has_prev.copy_(torch.where(mk, torch.zeros_like(self.has_prev), self.has_prev))
             self.ep_len.copy_(torch.where(mk, torch.zeros_like(self.ep_len), self.ep_len))
+        self._rest(mask)
         self._launch(None, False, None)
         return self.obs
 
@@ -294,8 +328,39 @@ class BatchKinematicEnv:
         self.qpos.copy_(qpos)
         self.has_prev.zero_()
         self.ep_len.zero_()
+        self._rest(None)
         self._launch(None, False, None)
         return self.obs
+
+    def _rest(self, mask):
+        """dynamics: the (re)set envs are at rest; bias_lag <- qfrc_bias of the `sim.forward()` that follows a reset."""
+        if not self.dynamics:
+            return
+        torch = _torch()
+        skip = None
+        if mask is None:
+            self.qvel.zero_()
+        else:
+            mk = mask.to(torch.bool)
+            self.qvel.copy_(torch.where(mk[:, None], torch.zeros_like(self.qvel), self.qvel))
+            skip = ((~mk).to(torch.uint8) * 2).contiguous()       # bit 1: env sits this call out
+        _lib.check(_lib.lib().mopa_env_dyn_forward_batch(self._h, self.E, _ptr(self.qpos), _ptr(self.qvel), _ptr(self.bias_lag), None,
+                                                         _ptr(skip) if skip is not None else None, None))
+
+    def dyn_substeps(self, ctrl, n: int = 1, stream=None):
+        """n raw sub-steps towards servo targets ctrl [E, nd] (tests / parity per sub-step)."""
+        _lib.check(_lib.lib().mopa_env_dyn_substeps_batch(self._h, self.E, _ptr(self.qpos), _ptr(self.qvel), _ptr(self.bias_lag),
+                                                          _ptr(ctrl), int(n), _stream_handle(stream)))
+
+    def dyn_forward(self, want_M: bool = False):
+        """(qfrc_bias [E, nd], packed lower triangle of M [E, nd (nd + 1) / 2] or None) at the current (qpos, qvel)."""
+        torch = _torch()
+        nd = self.dyn.nd
+        bias = torch.zeros(self.E, nd, dtype=torch.float64, device=self.device)
+        M = torch.zeros(self.E, nd * (nd + 1) // 2, dtype=torch.float64, device=self.device) if want_M else None
+        _lib.check(_lib.lib().mopa_env_dyn_forward_batch(self._h, self.E, _ptr(self.qpos), _ptr(self.qvel), _ptr(bias),
+                                                         _ptr(M) if want_M else None, None, None))
+        return bias, M
 
     def step(self, action, is_planner: bool = False, stream=None):
         """`env.step(action, is_planner)` for all E envs.  action: float64 [E, action_dim] on the GPU (7 arm entries; Lift:

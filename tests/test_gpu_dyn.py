@@ -1,0 +1,158 @@
+"""GPU parity of K6 (`k_env_dyn`, the servo dynamics inside env.step; SURVEY.md 8 f4b stage A) against
+oracle/mopa_oracle_dyn.inc: qfrc_bias, the joint-space inertia, every sub-step's (qpos, qvel, lagged bias) and whole
+env.step rollouts (obs with joint velocities, reward, flags, carried state) must be equal BIT FOR BIT."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ENVS = ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"]
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+    assert torch.cuda.is_available(), "the gpu-marked tests need a HIP device"
+    return torch
+
+
+def _setup(oracle_mod, env_name, E, **kw):
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(env_name)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    env = make_env(env_name, E, dynamics=True, **kw)
+    ref = oracle_mod.OracleEnv(orc, env.facts, E, ac_scale=env.ac_scale, dyn=env.dyn, **kw)
+    return pi, env, ref
+
+
+def _states(env, E, seed, spread=1.0):
+    """qpos rows with the dynamic dofs anywhere in their range (some ON a limit), velocities of either sign."""
+    d = env.dyn
+    rng = np.random.default_rng(seed)
+    q = np.tile(env.init_qpos_row, (E, 1))
+    lo = np.where(d.limited == 1, d.lo, -3.0)
+    hi = np.where(d.limited == 1, d.hi, 3.0)
+    mid, half = 0.5 * (lo + hi), 0.5 * (hi - lo)
+    q[:, d.qadr] = mid + spread * half * rng.uniform(-1, 1, size=(E, d.nd))
+    edge = rng.random((E, d.nd)) < 0.05
+    q[:, d.qadr] = np.where(edge, np.where(rng.random((E, d.nd)) < 0.5, lo, hi), q[:, d.qadr])
+    v = rng.normal(0, 1.0, size=(E, d.nd)) * np.where(d.jtype == 3, 1.0, 0.02)
+    return q, v
+
+
+@pytest.mark.parametrize("env_name", ENVS)
+def test_forward_bias_and_inertia_bit_exact(oracle_mod, torch_mod, env_name):
+    torch = torch_mod
+    E = 200
+    pi, env, ref = _setup(oracle_mod, env_name, E)
+    q, v = _states(env, E, seed=1)
+    env.set_state(torch.tensor(q, device=env.device))
+    env.qvel.copy_(torch.tensor(v, device=env.device))
+    bias, M = env.dyn_forward(want_M=True)
+    bias, M = bias.cpu().numpy(), M.cpu().numpy()
+    nd = env.dyn.nd
+    il = np.tril_indices(nd)
+    for e in range(E):
+        ob, oM = ref.dyn.forward(q[e], v[e])
+        assert np.array_equal(_bits(bias[e]), _bits(ob)), f"env {e}: qfrc_bias"
+        assert np.array_equal(_bits(M[e]), _bits(oM[il])), f"env {e}: M"
+
+
+@pytest.mark.parametrize("env_name", ENVS)
+@pytest.mark.parametrize("n", [1, 7, 75])
+def test_substeps_bit_exact(oracle_mod, torch_mod, env_name, n):
+    torch = torch_mod
+    E = 130
+    pi, env, ref = _setup(oracle_mod, env_name, E)
+    d = env.dyn
+    q, v = _states(env, E, seed=10 + n)
+    rng = np.random.default_rng(n)
+    ctrl = q[:, d.qadr] + rng.uniform(-0.3, 0.3, size=(E, d.nd)) * np.where(d.jtype == 3, 1.0, 0.05)
+    env.set_state(torch.tensor(q, device=env.device))
+    env.qvel.copy_(torch.tensor(v, device=env.device))
+    lag0 = env.dyn_forward()[0]
+    env.bias_lag.copy_(lag0)
+    env.dyn_substeps(torch.tensor(ctrl, device=env.device), n)
+    gq, gv, gl = env.qpos.cpu().numpy(), env.qvel.cpu().numpy(), env.bias_lag.cpu().numpy()
+    lag0 = lag0.cpu().numpy()
+    hit = 0
+    for e in range(E):
+        oq, ov, ol = ref.dyn.step(q[e], v[e], lag0[e], ctrl[e], n)
+        assert np.array_equal(_bits(gq[e]), _bits(oq)), f"env {e}: qpos after {n} sub-steps"
+        assert np.array_equal(_bits(gv[e]), _bits(ov)), f"env {e}: qvel"
+        assert np.array_equal(_bits(gl[e]), _bits(ol)), f"env {e}: lagged bias"
+        hit += int(np.any((oq[d.qadr] == d.lo) | (oq[d.qadr] == d.hi)))
+    assert hit > 0      # the joint stops were exercised
+
+
+@pytest.mark.parametrize("env_name", ENVS)
+@pytest.mark.parametrize("E", [5, 130])
+def test_env_step_rollout_bit_identical_to_oracle(oracle_mod, torch_mod, env_name, E):
+    torch = torch_mod
+    pi, env, ref = _setup(oracle_mod, env_name, E, max_episode_steps=5)
+    q, _ = _states(env, E, seed=E, spread=0.5)
+    env.set_state(torch.tensor(q, device=env.device))
+    ref.set_state(q)
+
+    def compare(what):
+        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(ref.qpos)), f"{what}: qpos"
+        assert np.array_equal(_bits(env.qvel.cpu().numpy()), _bits(ref.qvel)), f"{what}: qvel"
+        assert np.array_equal(_bits(env.bias_lag.cpu().numpy()), _bits(ref.bias_lag)), f"{what}: bias_lag"
+        assert np.array_equal(_bits(env.obs.cpu().numpy()), _bits(ref.obs)), f"{what}: obs"
+        assert np.array_equal(_bits(env.prev_state.cpu().numpy()), _bits(ref.prev_state)), f"{what}: prev_state"
+        assert np.array_equal(env.ep_len.cpu().numpy(), ref.ep_len) and np.array_equal(env.has_prev.cpu().numpy(), ref.has_prev), what
+
+    compare("after set_state")
+    rng = np.random.default_rng(7 + E)
+    n_done = 0
+    for t in range(6):
+        is_planner = bool(t % 3 == 1)
+        a = rng.uniform(-0.08, 0.08, size=(E, env.action_dim)) if is_planner else rng.uniform(-1.5, 1.5, size=(E, env.action_dim))
+        if env.action_dim > 7:
+            a[:, 7] = rng.uniform(-0.01, 0.01, size=E)
+        obs, rew, done, info = env.step(torch.tensor(a, device=env.device), is_planner=is_planner)
+        ref.step(a, is_planner=is_planner)
+        compare(f"step {t}")
+        assert np.array_equal(_bits(rew.cpu().numpy()), _bits(ref.reward)), f"step {t}: reward"
+        assert np.array_equal(done.cpu().numpy(), ref.done) and np.array_equal(info["success"].cpu().numpy(), ref.success)
+        assert np.abs(obs[:, 7:14].cpu().numpy()).max() > 1e-3          # the obs carries joint velocities now
+        n_done += int(ref.done.sum())
+    assert n_done == E          # every env hit max_episode_steps once
+
+
+def test_move_mask_and_partial_reset(oracle_mod, torch_mod):
+    """bit 1: env sits out; bit 0 clear: command recorded, no physics; reset(mask) puts only those envs at rest."""
+    torch = torch_mod
+    E = 70
+    pi, env, ref = _setup(oracle_mod, "SawyerPushObstacle-v0", E)
+    q, _ = _states(env, E, seed=3, spread=0.4)
+    env.set_state(torch.tensor(q, device=env.device))
+    ref.set_state(q)
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-1, 1, size=(E, 7))
+    env.step(torch.tensor(a, device=env.device))
+    ref.step(a)
+    mm = rng.integers(0, 4, size=E).astype(np.uint8)
+    a = rng.uniform(-1, 1, size=(E, 7))
+    env._launch(torch.tensor(a, device=env.device), False, torch.tensor(mm, device=env.device))
+    ref.step(a, move_mask=mm)
+    assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(ref.qpos))
+    assert np.array_equal(_bits(env.qvel.cpu().numpy()), _bits(ref.qvel))
+    assert np.array_equal(_bits(env.obs.cpu().numpy()), _bits(ref.obs))
+    assert np.array_equal(env.ep_len.cpu().numpy(), ref.ep_len)
+    # partial reset
+    mask = torch.tensor(rng.random(E) < 0.5, device=env.device)
+    v_before = env.qvel.clone()
+    env.reset(mask)
+    mk = mask.cpu().numpy()
+    assert np.all(env.qvel.cpu().numpy()[mk] == 0.0)
+    assert np.array_equal(_bits(env.qvel.cpu().numpy()[~mk]), _bits(v_before.cpu().numpy()[~mk]))
+    lag = env.bias_lag.cpu().numpy()
+    qn = env.qpos.cpu().numpy()
+    for e in np.where(mk)[0][:10]:
+        assert np.array_equal(_bits(lag[e]), _bits(ref.dyn.forward(qn[e], np.zeros(env.dyn.nd), want_M=False)[0]))

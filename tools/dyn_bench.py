@@ -1,0 +1,25 @@
+"""Time env.step with the servo dynamics (K6) next to the kinematic step: `python tools/dyn_bench.py [E]`."""
+import sys
+import time
+import torch
+sys.path.insert(0, ".")
+from mopa_rl_amd.kinematic_env import make_env
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+for name in ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"]:
+    for dyn in (False, True):
+        env = make_env(name, E, dynamics=dyn)
+        env.reset()
+        a = (torch.rand(E, env.action_dim, dtype=torch.float64, device=env.device) * 2 - 1).contiguous()
+        for _ in range(3):
+            env.step(a)
+        torch.cuda.synchronize()
+        n = 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            env.step(a)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        print(f"{name:28s} E={E} dynamics={dyn!s:5s} {dt * 1e3:8.3f} ms/step  {E / dt / 1e6:8.3f} M env-steps/s"
+              + (f"  ({E * 75 / dt / 1e6:.1f} M sub-steps/s)" if dyn else ""), flush=True)
+        env.close()

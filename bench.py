@@ -5,10 +5,13 @@
 
 A "step" is one pass of the hot path over one batch of synthetic planner
 states: E envs x S states/env per GPU, SawyerPushObstacle-v0 (7-DoF arm, 27
-collidable primitives, 232 non-ignored candidate pairs).  Inputs are resident
+collidable primitives, 241 non-ignored candidate pairs).  Inputs are resident
 in HBM before the timed region.  One process per GPU; envs are sharded across
 ranks (weak scaling: per-GPU work is fixed) and every step ends with an RCCL
 all-gather of the uint8 validity masks, the only exchange the path has.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks
+itself (re-exec under torch.distributed.run on 127.0.0.1); under an external
+launcher WORLD_SIZE must equal N -- anything else is an error, not a 1-GPU run.
 
 Prints ONE JSON line (rank 0) following the driver's contract, extended with
   roofline      achieved algorithmic GB/s of the validity kernel vs the HBM roof
@@ -273,9 +276,77 @@ def env_step_section(torch, E, device, steps, with_cpu):
                                        "single_thread_value": E / dt_1,
                                        "sample": f"the same {steps + 2} x {E} steps through the oracle's orc_env_step_batch "
                                                  "(OpenMP over envs); our C restatement, not MuJoCo"}
+        blk["dynamics"] = env_dynamics_block(torch, env_name, E, device, g, with_cpu and tag == "push")
         out[tag] = blk
     out["steps_per_s"] = out["push"]["steps_per_s"]
+    out["steps_per_s_dynamics"] = out["push"]["dynamics"]["steps_per_s"]
     return out
+
+
+def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20):
+    """env.step with `_do_simulation` = the reference's 75 sub-steps of force-limited position servos + gravity compensation
+    on the arm's own tree (K6 `k_env_dyn`, SURVEY.md 8 f4b stage A).  Contact-free: the manipulated object does not move."""
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.scene import planner_inputs
+    env = make_env(env_name, E, device=device, seed=11, dynamics=True, max_episode_steps=1 << 30)
+    acts = (torch.rand(steps + 2, E, env.action_dim, generator=g, dtype=torch.float64, device=device) * 2 - 1).contiguous()
+    env.reset()
+    q_init = env.qpos.clone()
+    env.step(acts[0]); env.step(acts[1])
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for t in range(steps):
+        env.step(acts[2 + t])
+    ev1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nd, nsub = env.dyn.nd, env.dyn.nsub
+    bytes_per_step = 6 * nd * 8 + 2 * env.action_dim * 8 + env.obs_dim * 8 + 18       # q / qvel / lagged bias in+out, action, prev_state, obs, flags
+    blk = {"dynamics": f"servo, contact-free: {nsub} sub-steps of h = {env.dyn.timestep} s per env.step on {nd} dofs (RNE bias + CRB inertia + "
+                       "implicit-damping Euler, kp / forcerange servos, lagged qfrc_bias as gravity compensation); joint limits = inelastic "
+                       "stop; the manipulated object does not move (no contacts) -- labelled, NOT MuJoCo's constraint solver",
+           "config": f"{env_name} env.step with servo dynamics, {E} envs, uniform policy actions in [-1,1]",
+           "steps_per_s": E * steps / dt, "ms_per_batch": dt / steps * 1e3, "substeps_per_s": E * steps * nsub / dt,
+           "gpu_ms_per_batch": ev0.elapsed_time(ev1) / steps,
+           "algorithmic_bytes_per_env_step": bytes_per_step, "achieved_GBps": E * steps * bytes_per_step / dt / 1e9,
+           "bound": "latency of ~5 k dependent FP64 operations per sub-step on one lane per env (64 waves at 4096 envs); not HBM"}
+    if with_cpu:
+        from oracle import oracle as O
+        pi = planner_inputs(env_name)
+        orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+        n = min(E, 1024)
+        k = 4
+        ref = O.OracleEnv(orc, env.facts, n, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn)
+        ref.set_state(q_init[:n].cpu().numpy())
+        a_host = acts[:, :n].cpu().numpy()
+        cores = host_cores()
+        t0 = time.perf_counter()
+        for t in range(k):
+            ref.step(a_host[t], nthreads=cores)
+        dt_cpu = time.perf_counter() - t0
+        # parity: the GPU envs after the same k steps from the same reset state
+        chk = make_env(env_name, n, device=device, seed=11, dynamics=True, max_episode_steps=1 << 30)
+        chk.set_state(q_init[:n].clone())
+        for t in range(k):
+            chk.step(acts[t, :n].contiguous())
+        torch.cuda.synchronize()
+        blk["parity_mismatches_vs_oracle"] = int((chk.obs.cpu().numpy().view(np.uint64) != ref.obs.view(np.uint64)).sum()
+                                                 + (chk.qvel.cpu().numpy().view(np.uint64) != ref.qvel.view(np.uint64)).sum()
+                                                 + (chk.qpos.cpu().numpy().view(np.uint64) != ref.qpos.view(np.uint64)).sum())
+        one = O.OracleEnv(orc, env.facts, 64, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn)
+        one.set_state(q_init[:64].cpu().numpy())
+        t0 = time.perf_counter()
+        one.step(a_host[0][:64], nthreads=1)
+        dt_1 = time.perf_counter() - t0
+        blk["cpu_baseline"] = {"value": n * k / dt_cpu, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                               "single_thread_value": 64 / dt_1,
+                               "sample": f"the first {n} envs x {k} steps of the same rollout through the oracle's orc_env_step_dyn_batch "
+                                         "(OpenMP over envs); our C restatement of the mj_step pipeline, not MuJoCo"}
+        chk.close()
+    env.close()
+    return blk
 
 
 SAC_GRAD_FLOATS = 145678 + 2 * 78337       # actor + two critics for obs 40 / ac 7 (SURVEY section 2: the payload of sync_grads)
@@ -510,7 +581,22 @@ def main():
     ap.add_argument("--no-env", action="store_true", help="skip the kinematic env.step section")
     ap.add_argument("--no-rollout", action="store_true", help="skip the end-to-end rollout sections (Push at 1 GPU; Lift with the "
                     "transition all-gather + gradient all-reduce at any rank count)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="test hook: launch / rendezvous / one collective, no GPU work "
+                    "(checks that --gpus N really yields N ranks; runs on a CPU-only box with MOPA_BENCH_BACKEND=gloo)")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launch the ranks ourselves: one process per GPU under torch.distributed.run (reference rank set-up: rl/main.py:24-35)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
 
     import torch
     import torch.distributed as dist
@@ -521,6 +607,32 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to report a "
+                         f"{args.gpus}-GPU number from {world} process(es)")
+    if args.rendezvous_only:
+        backend = os.environ.get("MOPA_BENCH_BACKEND", "nccl")
+        seen = 1
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+                t = torch.ones(1, device=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend)
+                t = torch.ones(1)
+            dist.all_reduce(t)
+            seen = int(t.item())
+            assert dist.get_world_size() == args.gpus
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "valid-state collision checks/sec", "value": None, "unit": "checks/s", "n_gpus": world,
+                              "rendezvous_only": True, "ranks_seen_by_all_reduce": seen,
+                              "config": {"parallelism": f"env-shard x{world}"},
+                              "exchange": {"backend": backend, "collectives": ["all_gather(uint8 masks)", "all_gather(transitions)",
+                                                                               "all_reduce(gradients)"]}}))
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # test-only knobs: MOPA_BENCH_DEVICE pins every rank to one device and MOPA_BENCH_BACKEND=gloo swaps the collective
@@ -535,6 +647,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)   # "nccl" == RCCL on ROCm
         else:
             dist.init_process_group(backend)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     pi = planner_inputs(ENV)
     scene = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold,
@@ -600,6 +713,9 @@ def main():
                        "envs_per_gpu": E, "states_per_env": S, "pairs_checked_per_state": scene.npair_checked,
                        "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(uint8 masks), triple-buffered, overlapped with the next steps' kernels" if world > 1 else "")},
             "valid_fraction": n_valid / N,
+            "exchange": {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None, "ranks": world,
+                         "collectives": (["all_gather(uint8 masks) per validity step", "all_gather(transition records) + all_reduce(gradient-sized "
+                                          "buffer) per rollout call"] if world > 1 else [])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": scene.valid_kernel(N), "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,

@@ -129,6 +129,11 @@ class BatchPlanner:
                 cat = lambda k: torch.cat([w[k] for w in wait]).contiguous()
                 r2 = self.plan(cat("start"), cat("goal"), max_iters=max_iters, max_nodes=max_nodes, max_path=max_path, seed=0,
                                env_ids=cat("ids"), seeds=cat("seeds"), stream=sb)
+            # the pooled slices were allocated on `sa` and are read by the cat on `sb`: tell the caching allocator, or the
+            # next first launch on `sa` may be handed their blocks while `sb` still waits behind an earlier retry
+            for w in wait:
+                for k in ("start", "goal", "ids", "seeds", "rows"):
+                    w[k].record_stream(sb)
             pend.append(([(w["batch"], w["rows"]) for w in wait], r2, sb))
             wait, n_wait = [], 0
 
@@ -160,6 +165,11 @@ class BatchPlanner:
                     o += len(rows)
             main.wait_stream(sb)
         main.wait_stream(sa)
+        for o in out:              # results live in blocks of `sa`'s pool (patched on the retry streams), consumed on `main`
+            for t in o:
+                t.record_stream(main)
+                for sb in sbs:
+                    t.record_stream(sb)
         return [tuple(o) for o in out]
 
     def pullback(self, cur, target, step_size: float, num_trials: int, stream=None):

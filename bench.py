@@ -395,7 +395,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     def one(k):
         a = act()
         out = ro.agent_step(a)
-        tx.pack(k, out["ob"], a, out["rew"], out["done"], out["intra_steps"], out["ob_next"])
+        tx.pack(k, out["ob"], out["ac"], out["rew"], out["done"], out["intra_steps"], out["ob_next"], stepped=out["stepped"])
         tx.launch(k)
         all_reduce_mean_(grads)
         return out

@@ -1179,6 +1179,10 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             mesh_list = sc.mesh_list.as<long long>();
             HIP_TRY(hipMemsetAsync(mesh_list, 0, sizeof(long long), st));
         }
+        // a device-side count stops the main pass at *n_dev; an ungated mesh pass would still walk all N worst-case rows
+        // (uninitialised candidates beyond *n_dev): only the gated form (work list built by the main pass) is served
+        if (n_dev && S->n_mesh_gp > 0 && !mesh_list)
+            return fail(MOPA_ERR_UNSUPPORTED, "a device-side state count on a scene with mesh pairs needs the gated mesh pass");
         if (S->use_v5) {
             auto k5 = S->v5_cen_lds ? (min_dist ? k_is_valid_v5<true, true, false> : k_is_valid_v5<false, true, false>)
                       : mesh_list   ? (min_dist ? k_is_valid_v5<true, false, true> : k_is_valid_v5<false, false, true>)

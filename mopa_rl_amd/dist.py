@@ -118,7 +118,9 @@ class OverlappedGather:
 class TransitionExchange:
     """All-gather of the transition records of one agent step (every rank fills the same replay
     buffer; the reference keeps one buffer per MPI rank and never exchanges transitions, rl/dataset.py).  A record is one
-    float32 row per env:  ob | ac | rew | done | intra_steps | ob_next  (Lift: 35 + 8 + 3 + 35 = 81 floats = 324 B).
+    float32 row per env:  ob | ac | rew | done | intra_steps | stepped | ob_next  (Lift: 35 + 8 + 4 + 35 = 82 floats = 328 B;
+    `stepped` = 1 for envs that completed a transition this call -- with the asynchronous planner the rows of envs still
+    waiting for a query are meaningless and a receiving rank drops them by this column).
     `pack(k, ...)` fills the local buffer of step k on the current stream, `launch(k)` starts the asynchronous all-gather on
     the backend's stream (so it overlaps whatever the current stream does next -- the next agent step's validity / planner
     launches), `result(k)` waits for it and returns the fields as views of the gathered [world * E, W] tensor.  Buffers are
@@ -129,7 +131,7 @@ class TransitionExchange:
         import torch
         self.world, self.rank = world_info()
         self.E, self.obs_dim, self.ac_dim, self.depth = int(n_envs), int(obs_dim), int(ac_dim), int(depth)
-        self.width = 2 * self.obs_dim + self.ac_dim + 3
+        self.width = 2 * self.obs_dim + self.ac_dim + 4
         self.local = [torch.zeros(self.E, self.width, dtype=torch.float32, device=device) for _ in range(depth)]
         self.gathered = ([torch.zeros(self.world * self.E, self.width, dtype=torch.float32, device=device) for _ in range(depth)]
                          if self.world > 1 else None)
@@ -144,7 +146,7 @@ class TransitionExchange:
             self.pending[b].wait()
             self.pending[b] = None
 
-    def pack(self, k: int, ob, ac, rew, done, intra_steps, ob_next):
+    def pack(self, k: int, ob, ac, rew, done, intra_steps, ob_next, stepped=None):
         b = k % self.depth
         self._wait(b)
         buf, o, a = self.local[b], self.obs_dim, self.ac_dim
@@ -153,7 +155,11 @@ class TransitionExchange:
         buf[:, o + a] = rew
         buf[:, o + a + 1] = done
         buf[:, o + a + 2] = intra_steps
-        buf[:, o + a + 3:] = ob_next
+        if stepped is None:
+            buf[:, o + a + 3] = 1.0
+        else:
+            buf[:, o + a + 3] = stepped
+        buf[:, o + a + 4:] = ob_next
         return buf
 
     def launch(self, k: int):
@@ -166,7 +172,7 @@ class TransitionExchange:
         self._wait(b)
         g, o, a = (self.gathered[b] if self.world > 1 else self.local[b]), self.obs_dim, self.ac_dim
         return {"ob": g[:, :o], "ac": g[:, o:o + a], "rew": g[:, o + a], "done": g[:, o + a + 1], "intra_steps": g[:, o + a + 2],
-                "ob_next": g[:, o + a + 3:]}
+                "stepped": g[:, o + a + 3], "ob_next": g[:, o + a + 4:]}
 
     def drain(self):
         for b in range(self.depth):

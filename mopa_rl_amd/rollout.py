@@ -87,7 +87,7 @@ class RolloutConfig:
     max_world_size: tuple = (1.2, 1.2, 2.0)
 
 
-def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30):
+def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30, grip_qpos_idx=None):
     """The `reuse_data` relabelling of rl/mopa_rollouts.py:204-300 on the record of one `agent_step(..., record=True)`:
     for every env that executed a planner path with more than 3 waypoints, up to min(len, max_reuse_data) random
     (start, goal) waypoint pairs become extra transitions  ob_list[start] --inverse-displacement action--> ob_list[goal]
@@ -95,7 +95,12 @@ def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30):
     intra_steps = goal - start - 1, kept only if the relabelled action is a planner action inside [-1, 1].
     `rng`: a numpy RandomState-like object (`randint(low, high)`) shared by all envs, or a callable env -> such an object
     (the reference draws from the global np.random, one env per process).
+    `grip_qpos_idx`: qpos address of the first gripper joint for envs whose action has a gripper entry (Lift, dof 8):
+    `env.form_action` appends that joint's difference (env/sawyer/sawyer.py:283-299), `valid_action` checks the whole vector,
+    `is_planner_ac` the arm entries.
     Returns a list of dicts (env, start, goal, ob, ac, rew, done, intra_steps, ob_next) of numpy values."""
+    if cfg.use_ik_target:
+        raise NotImplementedError("reuse_data relabelling for the IK action space (cart_list / quat_list, rl/mopa_rollouts.py:247-262)")
     rec = out["record"]
     ob, mr, dn, wp = (rec[k].cpu().numpy() for k in ("ob", "meta_rew", "done", "waypoint"))
     nexec = rec["n_exec"].cpu().numpy()
@@ -116,6 +121,8 @@ def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30):
             ac = displacement_to_action(wp[e, goal, :n_arm] - wp[e, start, :n_arm], cfg.ac_scale, cfg.omega, cfg.action_range,
                                         cfg.ac_space_type)
             is_planner = bool(np.any(ac < -cfg.omega) or np.any(ac > cfg.omega))
+            if grip_qpos_idx is not None:
+                ac = np.concatenate([ac, [wp[e, goal, grip_qpos_idx] - wp[e, start, grip_qpos_idx]]])
             in_box = bool(np.all(ac >= -1.0) and np.all(ac <= 1.0))
             if not (is_planner and in_box):
                 continue
@@ -662,7 +669,11 @@ class BatchMoPARollout:
         cur_v = torch.where(pv[:, None], self.clip_qpos(cur), safe).contiguous()
         tgt_v = torch.where(pv[:, None], target, safe).contiguous()
         traj_i, tlen, succ, nst = simple_interpolate_batch(self.bp, cur_v, tgt_v, cfg.ac_scale, self.arm, fixed_steps=self._k_interp)
-        self._interp_overflow |= (nst > self._k_interp).any()
+        # a line that needs more than the fixed width (cur outside its limits by more than action_range) is not executed as a
+        # truncated walk: it goes the planner's way; drain() still reports it
+        over = nst > self._k_interp
+        self._interp_overflow |= over.any()
+        succ = succ & ~over
         plan_ok = pv & succ
         self.counters["interpolation"] += plan_ok.to(torch.int64)
         traj_pad = torch.where(plan_ok[:, None, None], traj_i, torch.zeros_like(traj_i))

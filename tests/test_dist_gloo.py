@@ -170,7 +170,9 @@ def _tx_worker(rank, world, port, E, T, q):
     tx = TransitionExchange(hi - lo, od, ad, torch.device("cpu"))
     got = []
     for k, s in enumerate(steps):
-        tx.pack(k, *(torch.from_numpy(np.asarray(s[f], dtype=np.float64)) for f in ("ob", "ac", "rew", "done", "intra_steps", "ob_next")))
+        stepped = torch.from_numpy(((np.arange(lo, hi) + k) % 3 != 0).astype(np.float64))     # some envs "sit out" a call
+        tx.pack(k, *(torch.from_numpy(np.asarray(s[f], dtype=np.float64)) for f in ("ob", "ac", "rew", "done", "intra_steps", "ob_next")),
+                stepped=stepped)
         tx.launch(k)
         if k >= 1:
             got.append({f: v.clone().numpy() for f, v in tx.result(k - 1).items()})   # consume step k-1 while step k is in flight
@@ -198,8 +200,10 @@ def test_transition_all_gather_equals_unsharded(oracle_mod):
         p.join(timeout=60)
         assert p.exitcode == 0
     want, od, ad = _tx_rollout(oracle_mod, "SawyerLiftObstacle-v0", 0, E, E, T)
-    assert nbytes == (E // world) * (2 * od + ad + 3) * 4 and (od, ad) == (35, 8)
+    assert nbytes == (E // world) * (2 * od + ad + 4) * 4 and (od, ad) == (35, 8)
     for k in range(T):
         for f in ("ob", "ac", "rew", "done", "intra_steps", "ob_next"):
             assert np.array_equal(got[k][f], np.asarray(want[k][f], dtype=np.float32)), (k, f)
+        # the `stepped` column travels with the record: a receiving rank can drop the rows of envs that sat the call out
+        assert np.array_equal(got[k]["stepped"], ((np.arange(E) + k) % 3 != 0).astype(np.float32)), k
     assert sum(int(w["done"].sum()) for w in want) > 0

@@ -352,7 +352,7 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20):
 SAC_GRAD_FLOATS = 145678 + 2 * 78337       # actor + two critics for obs 40 / ac 7 (the payload of sync_grads)
 
 
-def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_planner=False, use_ik=False):
+def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_planner=False, use_ik=False, use_graphs=False):
     """End-to-end MoPA rollout step (mopa_rl_amd/rollout.py), SURVEY 8d configs 3 / 4: a SAC actor (stock PyTorch, random-init
     obs-256-256-256-(2 x ac) MLP, f32; a = tanh(mu + sigma * eps)) samples the action from the obs inside the timed loop,
     then per env either a direct env step or target / pull-back / straight-line pre-check / RRT-Connect / densification /
@@ -371,6 +371,8 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         # main stream + planner side streams + RCCL's stream: the HIP runtime runs 4 hardware queues side by side (streams
         # beyond that share one and serialise), so one planner stream less than the single-GPU default
         over.setdefault("planner_streams", 2)
+    if use_graphs:
+        over["use_graphs"] = 1          # the fixed-shape halves of a call replayed from HIP graphs (rollout.py)
     if use_ik:
         over["use_ik_target"] = 1       # MoPA + IK action space (BASELINE config 5): Cartesian displacement + rotation quaternion
     ro = BatchMoPARollout(env, RolloutConfig(async_planner=async_planner, **over))
@@ -438,6 +440,8 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         c = {k: int(t[3 + i].item()) for i, k in enumerate(sorted(c))}
     mode = ("async_planner: RRT-Connect on side streams, envs waiting for a query sit out (each env's transitions are those of the "
             "lock-step run)") if async_planner else "lock-step: every call waits for its slowest RRT-Connect query"
+    if use_graphs:
+        mode += "; HIP graphs: action -> target -> pull-back -> pre-check, and execution + bookkeeping, each replayed as one graph launch"
     if use_ik:
         mode += "; IK action space: the actor's Cartesian displacement + quaternion -> joint displacement through the batched damped-LS IK (K5)"
     return {"config": f"{env_name}, {E} envs per GPU x {world} GPU(s), {agent_steps} calls of agent_step; actions sampled by a random-init SAC actor "
@@ -758,6 +762,7 @@ def main():
         if world == 1:
             ro["rollout"] = rollout_section(torch, ENV, args.envs, device, 3)
             ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 100, async_planner=True)
+            ro["rollout_async_graphs"] = rollout_section(torch, ENV, args.envs, device, 100, async_planner=True, use_graphs=True)
         ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 100, world, async_planner=True)
         # BASELINE config 5: SawyerAssemblyObstacle with the IK action space, 8192 envs per GPU
         ro["rollout_assembly_ik"] = rollout_section(torch, "SawyerAssemblyObstacle-v0", 2 * args.envs, device, 60, world, async_planner=True,

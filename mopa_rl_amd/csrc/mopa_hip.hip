@@ -187,6 +187,16 @@ static hipError_t grow(MopaScene *S, DevBuf &b, size_t bytes) {
     return hipSuccess;
 }
 
+// Zero a few 8-byte words on a stream.  A kernel, not hipMemsetAsync: these launches are also captured into HIP graphs
+// (rollout.py, cfg.use_graphs), and small memset nodes proved unreliable there.
+__global__ void k_zero_words(unsigned long long *p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0ull;
+}
+static hipError_t zero_async(void *p, size_t bytes, hipStream_t st) {
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long *>(p), (int)((bytes + 7) / 8));
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------
@@ -1167,17 +1177,17 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
         dim3 grid((unsigned)blocks);
         // [6 profile words | 2 pad | tile counter] live right behind the slabs of this launch's waves
         double *d_tail = d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride;
-        HIP_TRY(hipMemsetAsync(d_tail + 8, 0, 8, st));
+        HIP_TRY(zero_async(d_tail + 8, 8, st));
 #ifdef MOPA_V2_PROFILE
         unsigned long long *d_prof = (unsigned long long *)d_tail;
-        (void)hipMemsetAsync(d_prof, 0, 6 * 8, st);
+        (void)zero_async(d_prof, 6 * 8, st);
 #endif
         auto kern = min_dist ? k_is_valid_v2<true, false> : k_is_valid_v2<false, false>;   // main lists carry no mesh pair
         long long *mesh_list = nullptr;
         if (S->use_v5 && !S->v5_cen_lds && S->n_mesh_gp > 0) {
             HIP_TRY(grow(S, sc.mesh_list, ((size_t)N + 1) * sizeof(long long)));
             mesh_list = sc.mesh_list.as<long long>();
-            HIP_TRY(hipMemsetAsync(mesh_list, 0, sizeof(long long), st));
+            HIP_TRY(zero_async(mesh_list, sizeof(long long), st));
         }
         // a device-side count stops the main pass at *n_dev; an ungated mesh pass would still walk all N worst-case rows
         // (uninitialised candidates beyond *n_dev): only the gated form (work list built by the main pass) is served
@@ -1197,7 +1207,7 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
                            (long long)samples_per_env, valid, min_dist, d_slab, 0, env_idx, (const long long *)nullptr);
         if (S->n_mesh_gp > 0) {
             // second pass: the mesh pairs only (MESH instantiation), verdict AND-ed / depth min-ed into the first pass's
-            HIP_TRY(hipMemsetAsync(d_tail + 8, 0, 8, st));
+            HIP_TRY(zero_async(d_tail + 8, 8, st));
             auto km = min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>;
             hipLaunchKernelGGL(km, grid, block, S->v2_lds_bytes, st, S->hdr_mesh, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
                                (long long)samples_per_env, valid, min_dist, d_slab, 1, env_idx, (const long long *)mesh_list);

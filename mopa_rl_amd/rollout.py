@@ -81,6 +81,11 @@ class RolloutConfig:
     planner_workgroups: int = 64      # persistent workgroups of an asynchronous launch: a planner wave holds ~370 registers, no
                                       # validity wave (226) fits next to it on a SIMD, so launches that took every CU would stall
                                       # the main stream's kernels for their whole bulk phase
+    use_graphs: bool = False          # async_planner, joint-space actions, record=False: the fixed-shape halves of a call (policy
+                                      # action -> target -> pull-back -> straight-line pre-check; execution + bookkeeping when no
+                                      # planner launch finished in the call) are captured once as HIP graphs and replayed -- ~90
+                                      # launches of host dispatch per call become two.  The returned tensors are then the graphs'
+                                      # static buffers: valid until the next call
     use_ik_target: bool = False
     ik_target: str = "grip_site"
     min_world_size: tuple = (-1.2, -1.2, 0.0)        # env/sawyer/sawyer.py:52-53
@@ -172,6 +177,7 @@ class BatchMoPARollout:
         self.counters: Dict[str, "object"] = {k: torch.zeros(self.E, dtype=torch.int64, device=dev) for k in COUNTERS}
         self.t_env = torch.zeros(self.E, dtype=torch.int64, device=dev)     # agent steps every env has completed
         self._t = 0
+        self._t_dev = torch.zeros((), dtype=torch.int64, device=dev)         # the same counter on the device (captured launches read it)
         self.busy = torch.zeros(self.E, dtype=torch.bool, device=dev)        # env waits for an RRT-Connect query (async_planner)
         self._jobs = []
         # blocked envs waiting for the next RRT-Connect launch: mask + their (clipped) current state and target
@@ -265,6 +271,7 @@ class BatchMoPARollout:
     @t.setter
     def t(self, value: int):
         self._t = int(value)
+        self._t_dev.fill_(int(value))
         self.t_env.fill_(int(value))
 
     def _rrt_launch(self, cur_f, target_f, ids, stream=None, iters=None):
@@ -610,23 +617,94 @@ class BatchMoPARollout:
         complete their step (path execution or the failed-plan step) in the first call after that.  Envs are independent and a
         query's sample stream is keyed by the env's own step count, so each env goes through the same sequence of transitions
         either way; only their interleaving differs.  Rows of the outputs are meaningful where `stepped`."""
+        if self.cfg.use_graphs and not record and getattr(self, "timing", None) is None:
+            return self._agent_step_graphs(ac)
+        bag = self._seg_pre(ac)
+        self._seg_plan(bag)
+        res = self._seg_exec(bag, record)
+        self._t += 1
+        return res
+
+    def _agent_step_graphs(self, ac, warmup: int = 2):
+        """agent_step with the two fixed-shape parts replayed from HIP graphs (cfg.use_graphs).  The first `warmup` calls run
+        eagerly on the stream the graphs are then captured on -- so that every per-stream scratch buffer of the library
+        exists before capture --, the capture itself is the execution of its call (capture, then replay)."""
+        torch = _torch()
+        if self.cfg.use_ik_target or not self.cfg.async_planner:
+            raise _lib.MopaError("use_graphs serves the asynchronous joint-space rollout")
+        G = getattr(self, "_graphs", None)
+        main = torch.cuda.current_stream(self.env.device)
+        if G is None:
+            G = self._graphs = {"calls": 0, "stream": torch.cuda.Stream(device=self.env.device), "pool": torch.cuda.graph_pool_handle(),
+                                "ac": torch.zeros(self.E, ac.shape[1], dtype=torch.float64, device=self.env.device),
+                                "pre": None, "exec": None}
+        st = G["stream"]
+        if G["calls"] < warmup:
+            G["calls"] += 1
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                bag = self._seg_pre(ac)
+                self._seg_plan(bag)
+                res = self._seg_exec(bag, False)
+            for v in res.values():
+                v.record_stream(main)
+            main.wait_stream(st)
+            self._t += 1
+            return res
+        G["ac"].copy_(ac)
+        import os as _os
+        which = _os.environ.get("MOPA_ROLLOUT_GRAPHS", "both")       # pre | exec | both: bisecting knob
+        if which == "exec":
+            bag = self._seg_pre(G["ac"])
+            self._seg_plan(bag)
+            res = self._seg_exec(bag, False)
+            self._t += 1
+            return res
+        if G["pre"] is None:
+            st.wait_stream(main)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=G["pool"], stream=st, capture_error_mode="relaxed"):
+                G["bag"] = self._seg_pre(G["ac"])
+            G["pre"] = g
+        G["pre"].replay()
+        bag = dict(G["bag"])
+        self._seg_plan(bag)
+        if which == "both" and bag["n_finished"] == 0 and bag["traj_pad"] is G["bag"]["traj_pad"]:
+            bag["finished"] = None       # (the all-false mask is then created inside the graph: a static buffer)
+            if G["exec"] is None:
+                st.wait_stream(main)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=G["pool"], stream=st, capture_error_mode="relaxed"):
+                    G["res"] = self._seg_exec(bag, False)
+                G["exec"] = g
+            G["exec"].replay()
+            res = G["res"]
+        else:
+            res = self._seg_exec(bag, False)
+        self._t += 1
+        return res
+
+    def _mark(self, name):
+        tm = getattr(self, "timing", None)     # optional dict: phase -> seconds (each mark synchronises; profiling only)
+        if tm is None:
+            return
+        import time as _time
+        torch = _torch()
+        torch.cuda.current_stream().synchronize()    # the main stream only: planner launches on side streams go on
+        now = _time.perf_counter()
+        last = getattr(self, "_mark_t", None)
+        if last is not None and name is not None:
+            tm[name] = tm.get(name, 0.0) + now - last
+        self._mark_t = now
+
+    # The three parts of a call.  _seg_pre and _seg_exec have fixed shapes, touch persistent state only IN PLACE and read no
+    # Python-side counters, so they can be captured as graphs; _seg_plan is host logic (planner launches, pick-ups).
+    def _seg_pre(self, ac):
+        """policy action -> planner / direct, target, pull-back, straight-line pre-check; blocked envs join the pool"""
         torch = _torch()
         env, cfg, E, n = self.env, self.cfg, self.E, self.n
-        dev = env.device
-        tm = getattr(self, "timing", None)     # optional dict: phase -> seconds (each mark synchronises; profiling only)
-        if tm is not None:
-            import time as _time
-            torch.cuda.current_stream().synchronize()
-            _t = [_time.perf_counter()]
-
-            def mark(name):
-                torch.cuda.current_stream().synchronize()    # the main stream only: planner launches on side streams go on
-                now = _time.perf_counter()
-                tm[name] = tm.get(name, 0.0) + now - _t[0]
-                _t[0] = now
-        else:
-            def mark(name):
-                pass
+        mark = self._mark
+        mark(None)
         busy0 = self.busy.clone()
         active = ~busy0
         prev_ob = torch.where(busy0[:, None], self._pend_ob, env.obs)
@@ -681,13 +759,23 @@ class BatchMoPARollout:
         mark("interpolate")
         # ---- the blocked ones go to RRT-Connect; lock-step waits for it below, async_planner does not ----
         blocked = pv & ~succ
-        self._q_cur = torch.where(blocked[:, None], cur_v, self._q_cur)
-        self._q_tgt = torch.where(blocked[:, None], tgt_v, self._q_tgt)
+        self._q_cur.copy_(torch.where(blocked[:, None], cur_v, self._q_cur))
+        self._q_tgt.copy_(torch.where(blocked[:, None], tgt_v, self._q_tgt))
         self._pool_mask |= blocked
-        self._wait_since = torch.where(blocked, torch.full_like(self._wait_since, self._t), self._wait_since)
+        self._wait_since.copy_(torch.where(blocked, self._t_dev.expand_as(self._wait_since), self._wait_since))
         self.busy |= blocked
-        self._pend_ob = torch.where(blocked[:, None], prev_ob, self._pend_ob)
-        self._pend_ac = torch.where(blocked[:, None], ac_tr, self._pend_ac)
+        self._pend_ob.copy_(torch.where(blocked[:, None], prev_ob, self._pend_ob))
+        self._pend_ac.copy_(torch.where(blocked[:, None], ac_tr, self._pend_ac))
+        return {"active": active, "prev_ob": prev_ob, "ac_tr": ac_tr, "a": a, "extra_ac": extra_ac, "is_pl": is_pl, "plan_ok": plan_ok,
+                "traj_pad": traj_pad, "path_len": path_len, "n_finished": 0}
+
+    def _seg_plan(self, bag):
+        """RRT-Connect launches for the pooled envs, pick-up of the launches that are done (host logic, dynamic shapes)"""
+        torch = _torch()
+        env, cfg, E, n = self.env, self.cfg, self.E, self.n
+        dev = env.device
+        mark = self._mark
+        plan_ok, traj_pad, path_len = bag["plan_ok"], bag["traj_pad"], bag["path_len"]
         # One K3 launch takes about as long for 40 queries as for 4000 (its time is the latency of the slowest query), so the
         # waiting envs of several calls share a launch: a job starts only when a side stream has no job in flight (and only
         # then the waiting envs are listed: the one read-back of this part).
@@ -722,7 +810,8 @@ class BatchMoPARollout:
                 job["retry"] = retry
                 self._jobs.append(job)
         # ---- RRT-Connect jobs that are done (lock-step: all of them) ----
-        finished = torch.zeros(E, dtype=torch.bool, device=dev)
+        finished = torch.zeros(E, dtype=torch.bool, device=dev) if self._jobs else None
+        n_fin = 0
         still = []
         for job in self._jobs:
             if not cfg.async_planner:
@@ -750,6 +839,7 @@ class BatchMoPARollout:
                 jid, s_t = jid[keep], s_t[keep]
                 tr_j, ln_j, v_j, e_j = t(tr_j)[keep], t(ln_j)[keep], t(v_j)[keep], t(e_j)[keep]
             finished[jid] = True
+            n_fin += 1
             plan_ok[jid] = s_t
             self.counters["mp"][jid[s_t]] += 1
             self.counters["mp_fail"][jid[~s_t]] += 1
@@ -759,6 +849,19 @@ class BatchMoPARollout:
             self.busy[jid] = False
         self._jobs = still
         mark("plan")
+        bag.update(plan_ok=plan_ok, traj_pad=traj_pad, path_len=path_len, finished=finished, n_finished=n_fin)
+
+    def _seg_exec(self, bag, record: bool = False):
+        """direct steps, failed-plan steps and waypoint execution; counters and the returned transition"""
+        torch = _torch()
+        env, cfg, E, n = self.env, self.cfg, self.E, self.n
+        dev = env.device
+        mark = self._mark
+        active, is_pl, a, extra_ac = bag["active"], bag["is_pl"], bag["a"], bag["extra_ac"]
+        plan_ok, traj_pad, path_len, prev_ob, ac_tr = bag["plan_ok"], bag["traj_pad"], bag["path_len"], bag["prev_ob"], bag["ac_tr"]
+        finished = bag.get("finished")
+        if finished is None:
+            finished = torch.zeros(E, dtype=torch.bool, device=dev)
         direct = active & ~is_pl
         self.counters["rl"] += direct.to(torch.int64)
         sitting = self.busy & ~finished            # still waiting for their query: nothing of theirs is touched
@@ -792,7 +895,7 @@ class BatchMoPARollout:
         mark("execute")
         env.has_prev.zero_()                                     # env._reset_prev_state()
         self.t_env += stepped.to(torch.int64)
-        self._t += 1
+        self._t_dev += 1
         res = {"ob": prev_ob, "ac": ac_tr, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra,
                "is_planner": is_pl | finished, "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok, "stepped": stepped}
         if rec is not None:

@@ -156,12 +156,13 @@ def test_async_planner_gives_every_env_the_same_transitions(env_name):
     AC[E // 4: 3 * E // 4, 3, 1], AC[E // 4: 3 * E // 4, 3, 3] = 1.0, -1.0
     ACt = torch.tensor(AC, device="cuda")
     runs = {}
-    for mode in ("lockstep", "async"):
+    for mode in ("lockstep", "async", "graphs"):
         env = make_env(env_name, E, seed=12, max_episode_steps=1000)
         env.reset()
-        # (async: a first launch with 60 of the 300 iterations, the queries it does not solve run again with all 300)
-        ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.15, max_nodes=512, max_path=128, num_trials=10, async_planner=(mode == "async"),
-                                                 planner_first_iters=60, planner_min_job=1))
+        # (async: a first launch with 60 of the 300 iterations, the queries it does not solve run again with all 300;
+        #  graphs: the same with the fixed-shape halves of a call replayed from HIP graphs)
+        ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.15, max_nodes=512, max_path=128, num_trials=10, async_planner=(mode != "lockstep"),
+                                                 planner_first_iters=60, planner_min_job=1, use_graphs=(mode == "graphs")))
         seq = [[] for _ in range(E)]
         calls = n_sitting = 0
         while min(len(q) for q in seq) < T:
@@ -179,9 +180,10 @@ def test_async_planner_gives_every_env_the_same_transitions(env_name):
             assert calls < 200
         runs[mode] = (np.array([np.array(q[:T]) for q in seq]), calls, n_sitting, {k: v.clone() for k, v in ro.counters.items()},
                       getattr(ro, "n_retried", 0))
-    a, b = runs["lockstep"], runs["async"]
+    a, b, c = runs["lockstep"], runs["async"], runs["graphs"]
     assert a[2] == 0 and a[1] == T
     assert np.array_equal(_bits(a[0]), _bits(b[0]))
+    assert np.array_equal(_bits(a[0]), _bits(c[0])), "graph replay changes an env's transitions"
     assert int(a[3]["mp"].sum()) > 0                                          # RRT-Connect was exercised ...
     if env_name == ENV:
         assert int(a[3]["mp_fail"].sum()) > 0 and b[4] > 0                    # ... with both outcomes, and second launches

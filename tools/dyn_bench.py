@@ -2,12 +2,14 @@
 import sys
 import time
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from mopa_rl_amd.kinematic_env import make_env
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-for name in ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"]:
-    for dyn in (False, True):
+only = sys.argv[2] if len(sys.argv) > 2 else ""      # "push": the dynamics step of Push only (profiling)
+for name in (["SawyerPushObstacle-v0"] if only == "push" else ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"]):
+    for dyn in ((True,) if only else (False, True)):
         env = make_env(name, E, dynamics=dyn)
         env.reset()
         a = (torch.rand(E, env.action_dim, dtype=torch.float64, device=env.device) * 2 - 1).contiguous()

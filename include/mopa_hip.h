@@ -308,6 +308,27 @@ int mopa_env_exec_batch(MopaEnv *env, int64_t E, double *qpos_dev /*[E,nq] in/ou
  * timestep 0.002 (sawyer_dependencies.xml:11).  NOT modelled: contacts (manipulated objects do not move), the solver's soft
  * joint-limit constraint (an inelastic stop at the range instead).  The tree is passed LUMPED -- one body per dof, bodies
  * welded to it folded into its inertial (mopa_rl_amd/dynamics.py) -- parents before children, at most 9 dofs. */
+/* Stage B (Push): the manipulated object as a free rigid body with PENALTY contacts -- spring-damper normal force and
+ * capped regularised Coulomb friction at the object's feature points found inside a collider (and a moving box collider's
+ * vertices found inside the object); one-way coupling (the robot moves the object; its reaction on the arm is neglected).
+ * NOT MuJoCo's solver (soft convex constraints + elliptic cones + noslip, sawyer_dependencies.xml:11): a labelled stand-in
+ * so that env/sawyer/sawyer_push_obstacle.py's task has an object that can be pushed.  Colliders = the geoms MuJoCo pairs
+ * with the object (candidate-pair list): static ones (body -1, pose in the world) first, then robot geoms sorted by their
+ * dynamic body (pose in that body's frame).  With an object the qvel rows are [nd + 6]: the dofs, then (v, w) world. */
+typedef struct MopaObjDesc {
+    int32_t qadr;                     /* qpos address of the free joint (pos 3, quat 4); COM = body origin */
+    double mass, inertia[3], damping; /* principal inertia in the body frame, free-joint damping */
+    double half[3], rbound;           /* box half extents, bounding radius */
+    int32_t nfeat; const double *feat;   /* [nfeat,3] feature points (body frame), the 8 vertices first */
+    int32_t ncol;
+    const int32_t *co_body, *co_type; /* [ncol] dynamic body (-1 static), mjtGeom type (plane / sphere / capsule / cylinder / box) */
+    const double *co_size, *co_pos, *co_mat, *co_mu, *co_rbound;   /* [n,3] [n,3] [n,9] [n] [n] */
+    double inv_mass, inv_inertia[3];  /* reciprocals (the integrator multiplies) */
+    int32_t precull_every;            /* the full collider scan runs on every precull_every-th sub-step of a call (15) ... */
+    double precull_margin;            /* ... with bounding spheres inflated by this much (0.15 m); other sub-steps visit its survivors */
+    double kn, dn, eps_v, ct_max;     /* normal stiffness, normal damping, friction regularisation, cap of the friction's viscous coefficient */
+} MopaObjDesc;
+
 typedef struct MopaDynDesc {
     int32_t nd;
     const int32_t *parent;            /* [nd] parent dynamic body, -1 = fixed base */
@@ -327,9 +348,11 @@ typedef struct MopaDynDesc {
     double gravity[3];
     double timestep;                  /* 0.002 */
     int32_t nsub;                     /* int(frame_dt / timestep) = 75 */
+    const MopaObjDesc *obj;           /* NULL: stage A (only the robot moves) */
 } MopaDynDesc;
 int mopa_env_attach_dynamics(MopaEnv *env, const MopaDynDesc *desc);
 int mopa_env_dyn_dofs(const MopaEnv *env);      /* nd, or -1 without dynamics */
+int mopa_env_dyn_qvel_width(const MopaEnv *env); /* nd (+ 6 with an object), or -1 */
 /* mj_forward at (qpos, qvel): bias [E,nd] <- qfrc_bias (what the env reads as gravity compensation before its next
  * sub-step; call after a reset / set_state with qvel = 0); M (optional) <- packed lower triangle of the joint-space
  * inertia [E, nd (nd + 1) / 2]; mask (optional): envs with bit 1 set are skipped. */

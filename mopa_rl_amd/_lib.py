@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
-    "mopa_env_attach_dynamics", "mopa_env_dyn_dofs", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
+    "mopa_env_attach_dynamics", "mopa_env_dyn_dofs", "mopa_env_dyn_qvel_width", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch",
     "mopa_paths_unwrap_batch", "mopa_paths_walk_batch", "mopa_paths_assemble_batch", "mopa_interpolate_batch",
 ]
@@ -71,13 +71,24 @@ class MopaEnvDesc(C.Structure):
     ]
 
 
+class MopaObjDesc(C.Structure):
+    _fields_ = [
+        ("qadr", C.c_int32), ("mass", C.c_double), ("inertia", C.c_double * 3), ("damping", C.c_double),
+        ("half", C.c_double * 3), ("rbound", C.c_double), ("nfeat", C.c_int32), ("feat", _dp),
+        ("ncol", C.c_int32), ("co_body", _ip), ("co_type", _ip), ("co_size", _dp), ("co_pos", _dp), ("co_mat", _dp),
+        ("co_mu", _dp), ("co_rbound", _dp), ("inv_mass", C.c_double), ("inv_inertia", C.c_double * 3),
+        ("precull_every", C.c_int32), ("precull_margin", C.c_double),
+        ("kn", C.c_double), ("dn", C.c_double), ("eps_v", C.c_double), ("ct_max", C.c_double),
+    ]
+
+
 class MopaDynDesc(C.Structure):
     _fields_ = [
         ("nd", C.c_int32), ("parent", _ip), ("jtype", _ip), ("qadr", _ip), ("rel_pos", _dp), ("rel_quat", _dp),
         ("axis", _dp), ("jpos", _dp), ("qref", _dp), ("mass", _dp), ("ipos", _dp), ("inertia", _dp),
         ("damping", _dp), ("armature", _dp), ("limited", _ip), ("lo", _dp), ("hi", _dp),
         ("actuated", _ip), ("kp", _dp), ("force_lo", _dp), ("force_hi", _dp), ("gravcomp", _ip),
-        ("gravity", C.c_double * 3), ("timestep", C.c_double), ("nsub", C.c_int32),
+        ("gravity", C.c_double * 3), ("timestep", C.c_double), ("nsub", C.c_int32), ("obj", C.POINTER(MopaObjDesc)),
     ]
 
 
@@ -142,6 +153,7 @@ def lib() -> C.CDLL:
     L.mopa_env_desired_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp, vp]
     L.mopa_env_attach_dynamics.argtypes = [vp, C.POINTER(MopaDynDesc)]
     L.mopa_env_dyn_dofs.argtypes = [vp]
+    L.mopa_env_dyn_qvel_width.argtypes = [vp]
     L.mopa_env_dyn_forward_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]
     L.mopa_env_dyn_substeps_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp]
     L.mopa_env_step_dyn_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]

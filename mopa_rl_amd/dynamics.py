@@ -162,3 +162,112 @@ def dyn_facts(model, facts, frame_dt: float = 0.15) -> DynFacts:
         actuated=actuated, kp=kp, force_lo=flo, force_hi=fhi,
         gravcomp=np.array([1 if int(a) in arm else 0 for a in qadr], dtype=np.int32),
         gravity=np.asarray(m.opt[:3], dtype=np.float64).copy(), timestep=float(m.opt[3]), nsub=nsub)
+
+
+# ---- stage B (Push): the manipulated object as a free body with penalty contacts -------------------------------------
+@dataclass
+class ObjFacts:
+    """What the contact model of `csrc/mopa_dyn.inc` / the test oracle takes for the manipulated object (Push: the cube,
+    env/assets/xml/sawyer_push_obstacle.xml): its free joint, inertial, box shape and feature points, and the colliders --
+    every geom MuJoCo would pair with it (the compiled candidate-pair list), static ones posed in the world, robot geoms in
+    the frame of their (lumped) dynamic body.  The force law is NOT MuJoCo's (penalty spring-damper + capped Coulomb
+    friction, one-way coupling); kn / dn / eps_v / ct_max are its constants."""
+    qadr: int
+    mass: float
+    inertia: np.ndarray        # [3] principal (body frame)
+    damping: float
+    half: np.ndarray           # [3]
+    rbound: float
+    feat: np.ndarray           # [nfeat,3] vertices first
+    co_body: np.ndarray        # [ncol] i32, -1 static
+    co_type: np.ndarray        # [ncol] i32 (mjtGeom)
+    co_size: np.ndarray        # [ncol,3]
+    co_pos: np.ndarray         # [ncol,3]
+    co_mat: np.ndarray         # [ncol,9]
+    co_mu: np.ndarray          # [ncol]
+    co_rbound: np.ndarray      # [ncol]
+    kn: float
+    dn: float
+    eps_v: float
+    ct_max: float
+    inv_mass: float = 0.0
+    inv_inertia: np.ndarray = None
+    precull_every: int = 15       # the full collider scan runs on every 15th sub-step (30 ms) of a call, with the bounding
+    precull_margin: float = 0.15  # spheres inflated by 15 cm; the other sub-steps visit only the colliders that passed it
+
+
+def obj_facts(model, dyn: DynFacts, geom_name: str = "cube", kn: float = 500.0, dn: float = 3.0, eps_v: float = 1e-3) -> ObjFacts:
+    from .mjcf import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_PLANE, GEOM_SPHERE, JNT_FREE
+    m = model
+    cg = int(np.where(m.geom_mjid == m.geom_name2id(geom_name))[0][0])
+    if int(m.geom_type[cg]) != GEOM_BOX:
+        raise ValueError("the contact model takes a box object")
+    ob = int(m.geom_body[cg])
+    j = int(m.body_jntadr[ob])
+    if m.body_jntnum[ob] != 1 or int(m.jnt_type[j]) != JNT_FREE:
+        raise ValueError("the object must hang on a free joint")
+    if np.abs(m.geom_pos[cg]).max() > 0 or np.abs(m.body_ipos[ob]).max() > 1e-12 or np.abs(m.body_inertia[ob][3:]).max() > 1e-15:
+        raise ValueError("object geom / inertial frame must coincide with the body frame")
+    half = np.asarray(m.geom_size[cg], dtype=np.float64).copy()
+    sg = [-1.0, 1.0]
+    verts = [[(x if k & 1 else -x) for k, x in ((i, half[0]), (i >> 1, half[1]), (i >> 2, half[2]))] for i in range(8)]
+    edges = [[a * half[0], b * half[1], 0.0] for a in sg for b in sg] + [[a * half[0], 0.0, b * half[2]] for a in sg for b in sg] + \
+            [[0.0, a * half[1], b * half[2]] for a in sg for b in sg]
+    faces = [[a * half[0], 0.0, 0.0] for a in sg] + [[0.0, a * half[1], 0.0] for a in sg] + [[0.0, 0.0, a * half[2]] for a in sg]
+    feat = np.array(verts + edges + faces, dtype=np.float64)
+    idx = {int(b): i for i, b in enumerate(dyn.body)}
+    nb = len(m.body_names)
+
+    def owner(b):
+        while b > 0 and b not in idx:
+            b = int(m.body_parent[b])
+        return idx.get(b, -1)
+
+    def moving(b):
+        while b > 0:
+            if m.body_jntnum[b] > 0:
+                return True
+            b = int(m.body_parent[b])
+        return False
+
+    def frame_in(b, anc):
+        p, q = np.zeros(3), np.array([1.0, 0.0, 0.0, 0.0])
+        chain = []
+        while b != anc:
+            chain.append(b)
+            b = int(m.body_parent[b])
+        for c in reversed(chain):
+            p, q = _compose(p, q, np.asarray(m.body_pos[c], dtype=np.float64), np.asarray(m.body_quat[c], dtype=np.float64))
+        return p, q
+
+    def rbound(t, s):
+        return {GEOM_SPHERE: s[0], GEOM_CAPSULE: s[0] + s[1], GEOM_CYLINDER: float(np.hypot(s[0], s[1])), GEOM_BOX: float(np.linalg.norm(s)),
+                GEOM_PLANE: 0.0}[t]
+
+    cols = []
+    for a, b in m.pair_geom:
+        if cg not in (int(a), int(b)):
+            continue
+        g = int(b if int(a) == cg else a)
+        t = int(m.geom_type[g])
+        if t not in (GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX):
+            raise ValueError("unsupported collider type")
+        gb = int(m.geom_body[g])
+        own = owner(gb)
+        if own < 0 and moving(gb):
+            continue          # a moving body outside the dynamic tree (nothing of the kind in the Sawyer scenes)
+        anc = int(dyn.body[own]) if own >= 0 else 0
+        bp, bq = frame_in(gb, anc)
+        gp, gq = _compose(bp, bq, np.asarray(m.geom_pos[g], dtype=np.float64), np.asarray(m.geom_quat[g], dtype=np.float64))
+        cols.append((own, t, np.asarray(m.geom_size[g], dtype=np.float64), gp, _quat_to_mat(gq).ravel(),
+                     max(float(m.geom_friction[g]), float(m.geom_friction[cg])), rbound(t, m.geom_size[g])))
+    cols.sort(key=lambda c: (c[0] >= 0, c[0]))        # static ones first, then by dynamic body (stable)
+    mass = float(m.body_mass[ob])
+    return ObjFacts(
+        qadr=int(m.jnt_qposadr[j]), mass=mass, inertia=np.asarray(m.body_inertia[ob][:3], dtype=np.float64).copy(),
+        damping=float(m.jnt_damping[j]), half=half, rbound=float(np.linalg.norm(half)), feat=feat,
+        co_body=np.array([c[0] for c in cols], dtype=np.int32), co_type=np.array([c[1] for c in cols], dtype=np.int32),
+        co_size=np.array([c[2] for c in cols]), co_pos=np.array([c[3] for c in cols]), co_mat=np.array([c[4] for c in cols]),
+        co_mu=np.array([c[5] for c in cols]), co_rbound=np.array([c[6] for c in cols]),
+        kn=float(kn), dn=float(dn), eps_v=float(eps_v), ct_max=mass / (float(dyn.timestep) * 8.0),
+        inv_mass=1.0 / mass, inv_inertia=1.0 / np.asarray(m.body_inertia[ob][:3], dtype=np.float64))

@@ -16,7 +16,12 @@ sim-shaped adapter (tests/golden/ref_py_env_*.npz, tools/gen_ref_py_golden.py) a
 `dynamics=True` (stage A) puts the physics back for a robot that touches nothing: `_do_simulation` becomes
 the reference's 75 sub-steps of force-limited position servos with gravity compensation, on the arm's own tree (K6,
 `csrc/mopa_dyn.inc`, `dynamics.py`): the arm lags `desired_state` as the real one does, the obs carries joint velocities,
-`qvel` / `bias_lag` are carried per env.  Still no contacts: manipulated objects do not move.
+`qvel` / `bias_lag` are carried per env.  Without `contacts` nothing but the robot moves.
+
+`contacts=True` (stage B, Push only) makes the cube a free rigid body with PENALTY contacts against everything MuJoCo
+would pair it with (table, bin, ground, every robot geom): it rests on the table, the gripper can push it, it slides with
+friction and tumbles -- so the Push reward can actually be earned.  This is NOT MuJoCo's constraint solver (spring-damper
+normal force, capped regularised Coulomb friction, one-way coupling robot -> object); it is labelled as such everywhere.
 
 `block_invalid=True` adds the one piece of contact behaviour a kinematic arm can have: a step whose desired state is
 in collision (K1 validity kernel, same rule as the planner) is not executed -- the arm stays where it is.
@@ -157,7 +162,7 @@ class BatchKinematicEnv:
 
     def __init__(self, env_name: str, num_envs: int, device=None, seed: int = 0, max_episode_steps: int = 250,
                  distance_threshold: float = 0.06, success_reward: float = 150.0, ac_scale: Optional[float] = None,
-                 block_invalid: bool = False, model=None, dynamics: bool = False, frame_dt: float = 0.15):
+                 block_invalid: bool = False, model=None, dynamics: bool = False, frame_dt: float = 0.15, contacts: bool = False):
         torch = _torch()
         if env_name not in ENV_KIND:
             raise _lib.MopaError(f"no batched kinematic env for {env_name!r}")
@@ -240,9 +245,31 @@ class BatchKinematicEnv:
             dd.actuated, dd.kp, dd.force_lo, dd.force_hi, dd.gravcomp = ip(df.actuated), dp(df.kp), dp(df.force_lo), dp(df.force_hi), ip(df.gravcomp)
             dd.gravity = (C.c_double * 3)(*[float(x) for x in df.gravity])
             dd.timestep, dd.nsub = float(df.timestep), int(df.nsub)
+            self.obj = None
+            if contacts:
+                if f.kind != KIND_PUSH:
+                    raise _lib.MopaError("contacts=True: the penalty-contact object model is built for the Push cube only")
+                from .dynamics import obj_facts
+                self.obj = of = obj_facts(self.model, df)
+                od = _lib.MopaObjDesc()
+                od.qadr, od.mass, od.damping, od.rbound = int(of.qadr), float(of.mass), float(of.damping), float(of.rbound)
+                od.inertia = (C.c_double * 3)(*[float(x) for x in of.inertia])
+                od.half = (C.c_double * 3)(*[float(x) for x in of.half])
+                od.nfeat, od.feat = len(of.feat), dp(of.feat)
+                od.ncol, od.co_body, od.co_type = len(of.co_body), ip(of.co_body), ip(of.co_type)
+                od.co_size, od.co_pos, od.co_mat, od.co_mu, od.co_rbound = dp(of.co_size), dp(of.co_pos), dp(of.co_mat), dp(of.co_mu), dp(of.co_rbound)
+                od.kn, od.dn, od.eps_v, od.ct_max = float(of.kn), float(of.dn), float(of.eps_v), float(of.ct_max)
+                od.inv_mass = float(of.inv_mass)
+                od.inv_inertia = (C.c_double * 3)(*[float(x) for x in of.inv_inertia])
+                od.precull_every, od.precull_margin = int(of.precull_every), float(of.precull_margin)
+                keep.append(od)
+                dd.obj = C.pointer(od)
             _lib.check(L.mopa_env_attach_dynamics(self._h, C.byref(dd)))
             assert L.mopa_env_dyn_dofs(self._h) == df.nd
-            self.qvel = torch.zeros(self.E, df.nd, dtype=f64, device=dev)        # velocities of the dynamic dofs (arm, gripper)
+            self.nv = int(L.mopa_env_dyn_qvel_width(self._h))
+            assert self.nv == df.nd + (6 if contacts else 0)
+            # velocities of the dynamic dofs (arm, gripper) [+ the object's linear / angular velocity, world frame]
+            self.qvel = torch.zeros(self.E, self.nv, dtype=f64, device=dev)
             self.bias_lag = torch.zeros(self.E, df.nd, dtype=f64, device=dev)    # qfrc_bias of the last mj_forward
         self._desired = torch.zeros(self.E, self.n_arm, dtype=f64, device=dev)
         self._move = torch.zeros(self.E, dtype=torch.uint8, device=dev)

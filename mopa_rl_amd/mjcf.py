@@ -184,6 +184,7 @@ class CompiledModel:
     act_forcelimited: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))  # [nu]
     act_forcerange: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), dtype=np.float64))
     opt: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))             # [4] gravity xyz, timestep
+    geom_friction: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))   # [ngeom] sliding friction of the collidable geoms
     meta: Dict[str, object] = field(default_factory=dict)
 
     # ---- name lookups mirroring the mujoco-py calls the reference makes ----
@@ -218,7 +219,7 @@ class CompiledModel:
     _OPTIONAL = "geom_dataid mesh_vertadr mesh_vertnum mesh_vert".split()   # absent in scenes without collidable meshes
     _ACT = "act_joint act_ctrllimited act_ctrlrange".split()                  # absent in scenes compiled before actuators were kept
     _DYN = ("body_mass body_ipos body_inertia jnt_damping jnt_armature jnt_stiffness act_kind act_gain act_gear act_forcelimited "
-            "act_forcerange opt").split()                                   # absent in scenes compiled before round 3
+            "act_forcerange opt geom_friction").split()                                   # absent in scenes compiled before round 3
     _LISTS = "body_names jnt_names all_geom_names geom_mesh site_names".split()
 
     def to_json(self) -> str:
@@ -553,6 +554,7 @@ class _Builder:
              "pos": pos, "quat": quat, "contype": int(at.get("contype", "1")),
              "conaffinity": int(at.get("conaffinity", "1")), "margin": float(at.get("margin", "0")),
              "mesh": at.get("mesh", ""), "density": float(at.get("density", "1000")),
+             "friction": _floats(at.get("friction", "1 0.005 0.0001"))[0],
              "mass": (float(at["mass"]) if "mass" in at else None)}
         self.geoms.append(g)
 
@@ -762,6 +764,7 @@ class _Builder:
             act_forcelimited=arr(acts, "flimited", np.int32),
             act_forcerange=np.array([a["frange"] for a in acts], dtype=np.float64).reshape(-1, 2),
             opt=np.array([*self.gravity, self.timestep], dtype=np.float64),
+            geom_friction=arr(cg, "friction", np.float64),
             meta={"source": os.path.basename(self.xml_path)},
         )
 

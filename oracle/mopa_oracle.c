@@ -1505,7 +1505,7 @@ static void env_step_impl(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDe
                 for (int k = 0; k < d->n_act; k++)
                     for (int i = 0; i < dyn->nd; i++)
                         if (dyn->qadr[i] == d->act_qpos_idx[k]) dctrl[i] = clampd(ctrl[k], d->act_lo[k], d->act_hi[k]);
-                orc_dyn_step(dyn, qpos, qvel, bias_lag, dctrl, dyn->nsub);
+                orc_dyn_step_obj(dyn, qpos, qvel, bias_lag, dctrl, dyn->nsub, dyn->obj ? qvel + dyn->nd : NULL);
             }
             *has_prev = 1;
         } else {
@@ -1624,7 +1624,7 @@ void orc_env_step_dyn_batch(const OrcScene *s, const OrcEnvDesc *d, const OrcDyn
 #pragma omp parallel for num_threads(nthreads) schedule(static)
 #endif
     for (int64_t e = 0; e < E; e++)
-        env_step_impl(s, d, dyn, qvel + e * dyn->nd, bias_lag + e * dyn->nd, qpos + e * s->nq, prev_state + e * d->n_arm,
+        env_step_impl(s, d, dyn, qvel + e * (dyn->nd + (dyn->obj ? 6 : 0)), bias_lag + e * dyn->nd, qpos + e * s->nq, prev_state + e * d->n_arm,
                       has_prev + e, ep_len + e, action ? action + e * ad : NULL, is_planner, move_mask ? move_mask[e] : 1,
                       obs + e * od, reward + e, done + e, success + e);
 }

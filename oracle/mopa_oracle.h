@@ -125,6 +125,21 @@ void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, doubl
 /* (stage A) contact-free servo dynamics of the actuated kinematic tree -- see mopa_oracle_dyn.inc.
  * The tree is given LUMPED: one body per dof (bodies welded to it folded into its inertia), parents before children. */
 #define ORC_DYN_MAX 12
+/* (stage B, Push) the manipulated object as a free body with penalty contacts -- see mopa_oracle_dyn.inc */
+typedef struct OrcObjDesc {
+    int32_t qadr;                     /* qpos address of the object's free joint (pos 3, quat 4); its COM is the body origin */
+    double mass, inertia[3], damping; /* principal inertia (body frame = principal frame), free-joint damping */
+    double half[3], rbound;           /* box half extents, bounding radius */
+    int32_t nfeat; const double *feat;   /* [nfeat,3] feature points in the body frame; the first 8 are the vertices */
+    int32_t ncol;                     /* colliders: static ones first (body -1, pose in the world), then robot geoms by dynamic body */
+    const int32_t *co_body, *co_type;
+    const double *co_size /*[n,3]*/, *co_pos /*[n,3]*/, *co_mat /*[n,9]*/, *co_mu /*[n]*/, *co_rbound /*[n]*/;
+    double inv_mass, inv_inertia[3];  /* reciprocals, formed once on the host (the integrator multiplies) */
+    int32_t precull_every;            /* the full collider scan runs on every precull_every-th sub-step of a call ... */
+    double precull_margin;            /* ... with the bounding spheres inflated by this much [m] */
+    double kn, dn, eps_v, ct_max;     /* normal stiffness [N/m], normal damping [N s/m], friction regularisation [m/s], cap of the
+                                         friction force's viscous coefficient [N s/m] (explicit-step stability) */
+} OrcObjDesc;
 typedef struct OrcDynDesc {
     int32_t nd;
     const int32_t *parent;                  /* [nd] parent dynamic body, -1 = the fixed base */
@@ -140,12 +155,16 @@ typedef struct OrcDynDesc {
     const int32_t *gravcomp;                /* [nd] qfrc_applied = the qfrc_bias of the previous mj_forward (the env's gravity compensation) */
     double gravity[3], timestep;
     int32_t nsub;                           /* sub-steps per env.step (frame_dt / timestep) */
+    const OrcObjDesc *obj;                  /* NULL: stage A (nothing but the robot moves) */
 } OrcDynDesc;
 /* qfrc_bias [nd] (RNE with qacc = 0, gravity included) and, if M != NULL, the joint-space inertia [nd,nd] (CRB + armature) */
 void orc_dyn_forward(const OrcDynDesc *d, const double *qpos, const double *qvel /*[nd]*/, double *bias, double *M);
 /* n sub-steps of mj_step towards ctrl [nd] (already ctrl-range clamped; entries of unactuated dofs ignored); in place */
 void orc_dyn_step(const OrcDynDesc *d, double *qpos /*[nq]*/, double *qvel /*[nd]*/, double *bias_lag /*[nd]*/,
                   const double *ctrl /*[nd]*/, int n);
+/* the same with the object's velocity state obj_vel [6] = (v world, w world); NULL or d->obj == NULL: the object rests */
+void orc_dyn_step_obj(const OrcDynDesc *d, double *qpos, double *qvel, double *bias_lag, const double *ctrl, int n, double *obj_vel);
+/* qvel rows are [nd (+ 6 when dyn->obj: the object's velocity)] */
 void orc_env_step_dyn(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDesc *dyn, double *qpos, double *qvel, double *bias_lag,
                       double *prev_state, uint8_t *has_prev, int32_t *ep_len, const double *action, int is_planner, int move,
                       double *obs, double *reward, uint8_t *done, uint8_t *success);

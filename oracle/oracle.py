@@ -93,6 +93,8 @@ def lib():
         L.orc_dyn_forward.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp]
         L.orc_dyn_step.restype = None
         L.orc_dyn_step.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp, C.c_int]
+        L.orc_dyn_step_obj.restype = None
+        L.orc_dyn_step_obj.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp, C.c_int, _dp]
         L.orc_env_step_dyn_batch.restype = None
         L.orc_env_step_dyn_batch.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), C.POINTER(OrcDynDesc), C.c_int64, _dp, _dp, _dp,
                                              _dp, _u8p, _ip, _dp, C.c_int, _u8p, _dp, _dp, _u8p, _u8p, C.c_int]
@@ -122,21 +124,34 @@ class OrcEnvDesc(C.Structure):
     ]
 
 
+class OrcObjDesc(C.Structure):
+    _fields_ = [
+        ("qadr", C.c_int32), ("mass", C.c_double), ("inertia", C.c_double * 3), ("damping", C.c_double),
+        ("half", C.c_double * 3), ("rbound", C.c_double), ("nfeat", C.c_int32), ("feat", _dp),
+        ("ncol", C.c_int32), ("co_body", _ip), ("co_type", _ip), ("co_size", _dp), ("co_pos", _dp), ("co_mat", _dp),
+        ("co_mu", _dp), ("co_rbound", _dp), ("inv_mass", C.c_double), ("inv_inertia", C.c_double * 3),
+        ("precull_every", C.c_int32), ("precull_margin", C.c_double),
+        ("kn", C.c_double), ("dn", C.c_double), ("eps_v", C.c_double), ("ct_max", C.c_double),
+    ]
+
+
 class OrcDynDesc(C.Structure):
     _fields_ = [
         ("nd", C.c_int32), ("parent", _ip), ("jtype", _ip), ("qadr", _ip), ("rel_pos", _dp), ("rel_quat", _dp),
         ("axis", _dp), ("jpos", _dp), ("qref", _dp), ("mass", _dp), ("ipos", _dp), ("inertia", _dp),
         ("damping", _dp), ("armature", _dp), ("limited", _ip), ("lo", _dp), ("hi", _dp),
         ("actuated", _ip), ("kp", _dp), ("force_lo", _dp), ("force_hi", _dp), ("gravcomp", _ip),
-        ("gravity", C.c_double * 3), ("timestep", C.c_double), ("nsub", C.c_int32),
+        ("gravity", C.c_double * 3), ("timestep", C.c_double), ("nsub", C.c_int32), ("obj", C.POINTER(OrcObjDesc)),
     ]
 
 
 class OracleDyn:
     """The servo dynamics of mopa_oracle_dyn.inc over a `mopa_rl_amd.dynamics.DynFacts` (plain arrays)."""
 
-    def __init__(self, f):
+    def __init__(self, f, obj=None):
+        """f: DynFacts; obj: ObjFacts (stage B: the manipulated object moves under penalty contacts) or None."""
         self.f, self.nd = f, int(f.nd)
+        self.nv = self.nd + (6 if obj is not None else 0)       # width of a qvel row: the dofs, then the object's (v, w)
         self._keep = []
         d = OrcDynDesc()
 
@@ -155,6 +170,21 @@ class OracleDyn:
         d.actuated, d.kp, d.force_lo, d.force_hi, d.gravcomp = ip(f.actuated), dp(f.kp), dp(f.force_lo), dp(f.force_hi), ip(f.gravcomp)
         d.gravity = (C.c_double * 3)(*[float(x) for x in f.gravity])
         d.timestep, d.nsub = float(f.timestep), int(f.nsub)
+        self.obj = None
+        if obj is not None:
+            o = OrcObjDesc()
+            o.qadr, o.mass, o.damping, o.rbound = int(obj.qadr), float(obj.mass), float(obj.damping), float(obj.rbound)
+            o.inertia = (C.c_double * 3)(*[float(x) for x in obj.inertia])
+            o.half = (C.c_double * 3)(*[float(x) for x in obj.half])
+            o.nfeat, o.feat = len(obj.feat), dp(obj.feat)
+            o.ncol, o.co_body, o.co_type = len(obj.co_body), ip(obj.co_body), ip(obj.co_type)
+            o.co_size, o.co_pos, o.co_mat, o.co_mu, o.co_rbound = dp(obj.co_size), dp(obj.co_pos), dp(obj.co_mat), dp(obj.co_mu), dp(obj.co_rbound)
+            o.kn, o.dn, o.eps_v, o.ct_max = float(obj.kn), float(obj.dn), float(obj.eps_v), float(obj.ct_max)
+            o.inv_mass = float(obj.inv_mass)
+            o.inv_inertia = (C.c_double * 3)(*[float(x) for x in obj.inv_inertia])
+            o.precull_every, o.precull_margin = int(obj.precull_every), float(obj.precull_margin)
+            self.obj = o
+            d.obj = C.pointer(o)
         self.desc = d
 
     def forward(self, qpos, qvel, want_M: bool = True):
@@ -166,10 +196,11 @@ class OracleDyn:
         return bias, M
 
     def step(self, qpos, qvel, bias_lag, ctrl, n: int = 1):
-        """n sub-steps in place on copies; returns (qpos, qvel, bias_lag)."""
+        """n sub-steps in place on copies; returns (qpos, qvel, bias_lag).  qvel: [nd], or [nd + 6] with an object."""
         q, v, lag = (np.array(x, dtype=np.float64, copy=True) for x in (qpos, qvel, bias_lag))
         c, cp = _d(ctrl)
-        lib().orc_dyn_step(C.byref(self.desc), q.ctypes.data_as(_dp), v.ctypes.data_as(_dp), lag.ctypes.data_as(_dp), cp, int(n))
+        ov = v[self.nd:].ctypes.data_as(_dp) if (self.obj is not None and len(v) == self.nd + 6) else None
+        lib().orc_dyn_step_obj(C.byref(self.desc), q.ctypes.data_as(_dp), v.ctypes.data_as(_dp), lag.ctypes.data_as(_dp), cp, int(n), ov)
         return q, v, lag
 
 
@@ -190,9 +221,9 @@ class OracleEnv:
     `facts` is mopa_rl_amd.kinematic_env.EnvFacts (plain name->id data, no product code runs here)."""
 
     def __init__(self, scene: "OracleScene", facts, E: int, ac_scale=0.05, distance_threshold=0.06, success_reward=150.0,
-                 max_episode_steps=250, dyn=None):
+                 max_episode_steps=250, dyn=None, obj=None):
         self.scene, self.E, self.nq = scene, int(E), scene.nq
-        self.dyn = OracleDyn(dyn) if dyn is not None else None     # DynFacts: env.step runs the servo dynamics
+        self.dyn = OracleDyn(dyn, obj) if dyn is not None else None     # DynFacts (+ ObjFacts): env.step runs the servo dynamics
         self._keep = []
         d = OrcEnvDesc()
 
@@ -224,7 +255,7 @@ class OracleEnv:
         self.done = np.zeros(self.E, dtype=np.uint8)
         self.success = np.zeros(self.E, dtype=np.uint8)
         if self.dyn is not None:
-            self.qvel = np.zeros((self.E, self.dyn.nd))
+            self.qvel = np.zeros((self.E, self.dyn.nv))
             self.bias_lag = np.zeros((self.E, self.dyn.nd))
 
     def _call(self, e, action, is_planner, move):
@@ -247,7 +278,7 @@ class OracleEnv:
         if self.dyn is not None:      # reset: at rest, qfrc_bias of the `sim.forward()` that follows set_state
             self.qvel[:] = 0.0
             for e in range(self.E):
-                self.bias_lag[e] = self.dyn.forward(self.qpos[e], self.qvel[e], want_M=False)[0]
+                self.bias_lag[e] = self.dyn.forward(self.qpos[e], self.qvel[e, :self.dyn.nd], want_M=False)[0]
         return self.obs
 
     def step(self, action, is_planner=False, move_mask=None, nthreads: int = 1):

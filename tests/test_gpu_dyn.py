@@ -156,3 +156,94 @@ def test_move_mask_and_partial_reset(oracle_mod, torch_mod):
     qn = env.qpos.cpu().numpy()
     for e in np.where(mk)[0][:10]:
         assert np.array_equal(_bits(lag[e]), _bits(ref.dyn.forward(qn[e], np.zeros(env.dyn.nd), want_M=False)[0]))
+
+
+# ---- stage B: the Push cube as a free body with penalty contacts ----------------------------------------------------
+def _setup_obj(oracle_mod, E, **kw):
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.scene import planner_inputs
+    env_name = "SawyerPushObstacle-v0"
+    pi = planner_inputs(env_name)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    env = make_env(env_name, E, dynamics=True, contacts=True, **kw)
+    ref = oracle_mod.OracleEnv(orc, env.facts, E, ac_scale=env.ac_scale, dyn=env.dyn, obj=env.obj, **kw)
+    return pi, orc, env, ref
+
+
+def _obj_states(env, orc, E, seed):
+    """arm near its initial pose, the cube scattered around the hand (inside, touching, clear of it), on / in / above the
+    table, with random orientation and velocity -- every branch of the contact code sees states"""
+    from mopa_rl_amd.mjcf import _quat_to_mat
+    d, o, f = env.dyn, env.obj, env.facts
+    rng = np.random.default_rng(seed)
+    q = np.tile(env.init_qpos_row, (E, 1))
+    q[:, d.qadr[:7]] += rng.normal(0, 0.25, size=(E, 7))
+    q[:, d.qadr[:7]] = np.clip(q[:, d.qadr[:7]], d.lo[:7], d.hi[:7])
+    v = np.zeros((E, d.nd + 6))
+    v[:, :7] = rng.normal(0, 0.5, size=(E, 7))
+    for e in range(E):
+        xp, xq = orc.fk_bodies(q[e])
+        b = int(f.frame_body[0])
+        hand = xp[b] + _quat_to_mat(xq[b]) @ f.frame_off[0]
+        mode = e % 4
+        if mode == 0:
+            c = hand + rng.normal(0, 0.03, 3)                     # in / at the hand
+        elif mode == 1:
+            c = np.array([0.92, 0.0, 0.8597]) + rng.normal(0, [0.05, 0.05, 0.002])     # resting height on the table
+        elif mode == 2:
+            c = hand + rng.normal(0, 0.08, 3)
+        else:
+            c = np.array([rng.uniform(0.6, 1.3), rng.uniform(-0.5, 0.5), rng.uniform(0.0, 1.0)])      # anywhere: legs, ground, air
+        qq = rng.normal(size=4)
+        q[e, o.qadr:o.qadr + 3] = c
+        q[e, o.qadr + 3:o.qadr + 7] = qq / np.linalg.norm(qq)
+        v[e, d.nd:d.nd + 3] = rng.normal(0, 0.2, 3)
+        v[e, d.nd + 3:] = rng.normal(0, 2.0, 3)
+    return q, v
+
+
+@pytest.mark.parametrize("n", [1, 5, 75])
+def test_object_substeps_bit_exact(oracle_mod, torch_mod, n):
+    torch = torch_mod
+    E = 256
+    pi, orc, env, ref = _setup_obj(oracle_mod, E)
+    d = env.dyn
+    q, v = _obj_states(env, orc, E, seed=n)
+    rng = np.random.default_rng(100 + n)
+    ctrl = q[:, d.qadr] + rng.uniform(-0.2, 0.2, size=(E, d.nd)) * np.where(d.jtype == 3, 1.0, 0.0)
+    env.set_state(torch.tensor(q, device=env.device))
+    env.qvel.copy_(torch.tensor(v, device=env.device))
+    lag0 = env.dyn_forward()[0]
+    env.bias_lag.copy_(lag0)
+    env.dyn_substeps(torch.tensor(ctrl, device=env.device), n)
+    gq, gv = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
+    lag0 = lag0.cpu().numpy()
+    moved = 0
+    for e in range(E):
+        oq, ov, _ = ref.dyn.step(q[e], v[e], lag0[e], ctrl[e], n)
+        assert np.array_equal(_bits(gq[e]), _bits(oq)), f"env {e}: qpos (object pose included) after {n} sub-steps"
+        assert np.array_equal(_bits(gv[e]), _bits(ov)), f"env {e}: qvel (object velocity included)"
+        free_fall = v[e, d.nd:d.nd + 3] + n * d.timestep * d.gravity
+        moved += int(np.abs(ov[d.nd:d.nd + 3] - free_fall).max() > 1e-6)       # a contact force acted
+    assert moved > E // 8
+
+
+def test_object_env_rollout_bit_identical_to_oracle(oracle_mod, torch_mod):
+    torch = torch_mod
+    E = 64
+    pi, orc, env, ref = _setup_obj(oracle_mod, E, max_episode_steps=6)
+    q, v = _obj_states(env, orc, E, seed=11)
+    env.set_state(torch.tensor(q, device=env.device))
+    ref.set_state(q)
+    rng = np.random.default_rng(3)
+    for t in range(6):
+        a = rng.uniform(-1.5, 1.5, size=(E, 7))
+        obs, rew, done, info = env.step(torch.tensor(a, device=env.device))
+        ref.step(a)
+        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(ref.qpos)), f"step {t}: qpos"
+        assert np.array_equal(_bits(env.qvel.cpu().numpy()), _bits(ref.qvel)), f"step {t}: qvel"
+        assert np.array_equal(_bits(obs.cpu().numpy()), _bits(ref.obs)), f"step {t}: obs"
+        assert np.array_equal(_bits(rew.cpu().numpy()), _bits(ref.reward)), f"step {t}: reward"
+        assert np.array_equal(done.cpu().numpy(), ref.done)
+    # the cube moved in the obs (cube_pos slice of the Push layout: 21 + 3 .. + 6)
+    assert np.abs(ref.obs[:, 24:27] - q[:, env.obj.qadr:env.obj.qadr + 3]).max() > 1e-3

@@ -151,3 +151,65 @@ def test_env_step_with_dynamics(env):
         assert np.all(np.abs(ed.qpos[:, f.arm_qpos_idx] - des) < 0.12)
         assert np.abs(ed.qpos[:, f.arm_qpos_idx] - des).max() > 1e-3
         assert np.array_equal(ed.prev_state, ek.prev_state) and np.array_equal(ed.ep_len, ek.ep_len)
+
+
+# ---- stage B: the Push cube as a free body with penalty contacts (labelled: not MuJoCo's solver) ----------------------
+def _setup_obj():
+    from mopa_rl_amd.dynamics import obj_facts
+    m, f, d, od, q0 = _setup("SawyerPushObstacle-v0")
+    o = obj_facts(m, d)
+    return m, f, d, o, O.OracleDyn(d, o), q0
+
+
+def test_object_colliders_are_the_cubes_candidate_pairs():
+    m, f, d, o, od, q0 = _setup_obj()
+    cg = int(np.where(m.geom_mjid == m.geom_name2id("cube"))[0][0])
+    n_pairs = sum(1 for a, b in m.pair_geom if cg in (int(a), int(b)))
+    assert len(o.co_body) == n_pairs == 26
+    assert list(o.co_body) == sorted(o.co_body) and (o.co_body == -1).sum() == 13      # static ones first, then by dynamic body
+    assert o.mass == pytest.approx(0.06 ** 3 * 300) and np.allclose(o.inertia, o.mass * (0.06 ** 2) / 6)
+    assert len(o.feat) == 26 and np.all(np.abs(o.feat[:8]) == 0.03)
+
+
+def test_object_comes_to_rest_on_the_table():
+    m, f, d, o, od, q0 = _setup_obj()
+    lag, _ = od.forward(q0, np.zeros(d.nd), want_M=False)
+    q, v = q0.copy(), np.zeros(od.nv)
+    ctrl = q0[d.qadr].copy()
+    q, v, lag = od.step(q, v, lag, ctrl, n=600)          # 1.2 s: it drops 2 cm and settles
+    z = q[o.qadr + 2]
+    assert 0.85 < z < 0.87 and np.abs(v[d.nd:]).max() < 1e-9
+    q2, v2, _ = od.step(q, v, lag, ctrl, n=600)
+    assert np.abs(q2[o.qadr:o.qadr + 7] - q[o.qadr:o.qadr + 7]).max() < 1e-9       # and stays
+    assert abs(np.linalg.norm(q2[o.qadr + 3:o.qadr + 7]) - 1.0) < 1e-12
+    # static penetration = m g / (4 kn): the support force balances the weight
+    assert np.abs(q2[o.qadr:o.qadr + 2] - q0[o.qadr:o.qadr + 2]).max() < 1e-6
+
+
+def test_gripper_pushes_the_object():
+    """the hand is driven (through the servos) against the cube: the cube moves ahead of it, stays on the table, and stops
+    when the hand stops"""
+    m, f, d, o, od, q0 = _setup_obj()
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs("SawyerPushObstacle-v0", m)
+    orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    jid = [m.joint_name2id(j) for j in ENV_SPECS["SawyerPushObstacle-v0"].robot_joints]
+    sb, off = int(f.frame_body[0]), f.frame_off[0]
+    lag, _ = od.forward(q0, np.zeros(d.nd), want_M=False)
+    q, v = q0.copy(), np.zeros(od.nv)
+    q, v, lag = od.step(q, v, lag, q0[d.qadr].copy(), n=300)
+    cz, x0 = q[o.qadr + 2], q[o.qadr]
+    way = [np.array([0.80, 0.0, cz + 0.10]), np.array([0.80, 0.0, cz + 0.02])] + [np.array([0.80 + 0.01 * k, 0.0, cz + 0.02]) for k in range(1, 9)]
+    for i, tg in enumerate(way):
+        qt, err, steps, ok = orc.ik_solve(q, tg, jid, sb, off, max_steps=200, tol=1e-4)
+        assert ok
+        ctrl = qt[d.qadr].copy()
+        ctrl[7:] = q[d.qadr[7:]]
+        for _ in range(8 if i < 2 else 2):
+            q, v, lag = od.step(q, v, lag, ctrl, n=75)
+        assert np.all(np.isfinite(q)) and np.all(np.isfinite(v))
+    pushed = q[o.qadr] - x0
+    assert 0.02 < pushed < 0.08 and abs(q[o.qadr + 2] - cz) < 2e-3 and abs(q[o.qadr + 1]) < 0.01
+    for _ in range(6):                      # the hand holds still: friction stops the cube
+        q, v, lag = od.step(q, v, lag, ctrl, n=75)
+    assert np.abs(v[d.nd:d.nd + 3]).max() < 1e-3

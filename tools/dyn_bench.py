@@ -8,9 +8,11 @@ from mopa_rl_amd.kinematic_env import make_env
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 only = sys.argv[2] if len(sys.argv) > 2 else ""      # "push": the dynamics step of Push only (profiling)
-for name in (["SawyerPushObstacle-v0"] if only == "push" else ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"]):
-    for dyn in ((True,) if only else (False, True)):
-        env = make_env(name, E, dynamics=dyn)
+for name in (["SawyerPushObstacle-v0"] if only in ("push", "contacts") else ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"]):
+    for dyn in ((("contacts",) if only == "contacts" else (True,)) if only else (False, True, "contacts")):
+        if dyn == "contacts" and "Push" not in name:
+            continue
+        env = make_env(name, E, dynamics=bool(dyn), contacts=(dyn == "contacts"))
         env.reset()
         a = (torch.rand(E, env.action_dim, dtype=torch.float64, device=env.device) * 2 - 1).contiguous()
         for _ in range(3):

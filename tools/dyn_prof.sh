@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/prof_$TAG
 WORK=/tmp/prof_$TAG
 rm -rf $WORK; mkdir -p $OUT $WORK
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/tools/dyn_bench.py 4096 push"
+CMD="python $R/tools/dyn_bench.py 4096 ${2:-push}"
 run() {
   name=$1; shift
   rocprofv3 "$@" --output-format csv -d $WORK/$name -o $name -- $CMD > $OUT/${name}.log 2>&1

@@ -247,3 +247,30 @@ def test_object_env_rollout_bit_identical_to_oracle(oracle_mod, torch_mod):
         assert np.array_equal(done.cpu().numpy(), ref.done)
     # the cube moved in the obs (cube_pos slice of the Push layout: 21 + 3 .. + 6)
     assert np.abs(ref.obs[:, 24:27] - q[:, env.obj.qadr:env.obj.qadr + 3]).max() > 1e-3
+
+
+@pytest.mark.parametrize("contacts", [False, True])
+def test_workgroup_and_single_wave_forms_agree(oracle_mod, torch_mod, contacts, monkeypatch):
+    """K6 has two mappings -- four waves sharing the 64 envs of a workgroup (default) and one wave per 64 envs
+    (MOPA_DYN_KERNEL=wave): same arithmetic per quantity, so the same bits, for ragged batch sizes too."""
+    torch = torch_mod
+    from mopa_rl_amd.kinematic_env import make_env
+    E = 200                # not a multiple of 64: the last workgroup walks with idle lanes
+    outs = {}
+    for form in ("block", "wave"):
+        monkeypatch.setenv("MOPA_DYN_KERNEL", form)
+        env = make_env("SawyerPushObstacle-v0", E, dynamics=True, contacts=contacts, seed=5)
+        env.reset()
+        rng = np.random.default_rng(9)
+        mm = torch.tensor(rng.integers(0, 4, size=E).astype(np.uint8), device=env.device)
+        for t in range(3):
+            a = torch.tensor(rng.uniform(-1.5, 1.5, size=(E, 7)), device=env.device)
+            if t == 1:
+                env._launch(a, True, mm)
+            else:
+                env.step(a, is_planner=bool(t))
+        bias, M = env.dyn_forward(want_M=True)
+        outs[form] = [x.cpu().numpy().copy() for x in (env.qpos, env.qvel, env.bias_lag, env.obs, env.prev_state, bias, M)]
+        env.close()
+    for a, b in zip(outs["block"], outs["wave"]):
+        assert np.array_equal(_bits(a), _bits(b))

@@ -14,14 +14,21 @@ for name in (["SawyerPushObstacle-v0"] if only in ("push", "contacts") else ["Sa
             continue
         env = make_env(name, E, dynamics=bool(dyn), contacts=(dyn == "contacts"))
         env.reset()
-        a = (torch.rand(E, env.action_dim, dtype=torch.float64, device=env.device) * 2 - 1).contiguous()
-        for _ in range(3):
-            env.step(a)
-        torch.cuda.synchronize()
         n = 20
+        # fresh uniform actions every step (a random walk about the reset pose, as bench.py's env section does);
+        # MOPA_DYN_BENCH_ACT=zero: the arm holds still; =const: one action repeated (the arm runs into its joint stops)
+        kind = os.environ.get("MOPA_DYN_BENCH_ACT", "walk")
+        acts = (torch.rand(n + 3, E, env.action_dim, dtype=torch.float64, device=env.device) * 2 - 1).contiguous()
+        if kind == "zero":
+            acts.zero_()
+        elif kind == "const":
+            acts[:] = acts[0]
+        for k in range(3):
+            env.step(acts[k])
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(n):
-            env.step(a)
+        for k in range(n):
+            env.step(acts[3 + k])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
         print(f"{name:28s} E={E} dynamics={dyn!s:5s} {dt * 1e3:8.3f} ms/step  {E / dt / 1e6:8.3f} M env-steps/s"

@@ -277,18 +277,22 @@ def env_step_section(torch, E, device, steps, with_cpu):
                                        "sample": f"the same {steps + 2} x {E} steps through the oracle's orc_env_step_batch "
                                                  "(OpenMP over envs); our C restatement, not MuJoCo"}
         blk["dynamics"] = env_dynamics_block(torch, env_name, E, device, g, with_cpu and tag == "push")
+        if tag == "push":
+            blk["dynamics_contacts"] = env_dynamics_block(torch, env_name, E, device, g, with_cpu, contacts=True)
         out[tag] = blk
     out["steps_per_s"] = out["push"]["steps_per_s"]
     out["steps_per_s_dynamics"] = out["push"]["dynamics"]["steps_per_s"]
+    out["steps_per_s_dynamics_contacts"] = out["push"]["dynamics_contacts"]["steps_per_s"]
     return out
 
 
-def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20):
+def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contacts=False):
     """env.step with `_do_simulation` = the reference's 75 sub-steps of force-limited position servos + gravity compensation
-    on the arm's own tree (K6 `k_env_dyn`, SURVEY.md 8 f4b stage A).  Contact-free: the manipulated object does not move."""
+    on the arm's own tree (K6 `k_env_dyn4`, SURVEY.md 8 f4b stage A); contact-free: the manipulated object does not move.
+    contacts=True (stage B, Push): the cube is a free body with PENALTY contacts (labelled: not MuJoCo's solver)."""
     from mopa_rl_amd.kinematic_env import make_env
     from mopa_rl_amd.scene import planner_inputs
-    env = make_env(env_name, E, device=device, seed=11, dynamics=True, max_episode_steps=1 << 30)
+    env = make_env(env_name, E, device=device, seed=11, dynamics=True, contacts=contacts, max_episode_steps=1 << 30)
     acts = (torch.rand(steps + 2, E, env.action_dim, generator=g, dtype=torch.float64, device=device) * 2 - 1).contiguous()
     env.reset()
     q_init = env.qpos.clone()
@@ -304,21 +308,26 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20):
     dt = time.perf_counter() - t0
     nd, nsub = env.dyn.nd, env.dyn.nsub
     bytes_per_step = 6 * nd * 8 + 2 * env.action_dim * 8 + env.obs_dim * 8 + 18       # q / qvel / lagged bias in+out, action, prev_state, obs, flags
-    blk = {"dynamics": f"servo, contact-free: {nsub} sub-steps of h = {env.dyn.timestep} s per env.step on {nd} dofs (RNE bias + CRB inertia + "
-                       "implicit-damping Euler, kp / forcerange servos, lagged qfrc_bias as gravity compensation); joint limits = inelastic "
-                       "stop; the manipulated object does not move (no contacts) -- labelled, NOT MuJoCo's constraint solver",
+    what = (f"servo + object contacts: as `dynamics`, plus the cube as a free rigid body with PENALTY contacts (spring-damper normal force, capped "
+            f"regularised Coulomb friction at 26 feature points against its {len(env.obj.co_body)} MuJoCo candidate pairs; one-way coupling robot -> "
+            "object) -- a labelled stand-in, NOT MuJoCo's constraint solver") if contacts else (
+           f"servo, contact-free: {nsub} sub-steps of h = {env.dyn.timestep} s per env.step on {nd} dofs (RNE bias + CRB inertia + "
+           "implicit-damping Euler, kp / forcerange servos, lagged qfrc_bias as gravity compensation); joint limits = inelastic "
+           "stop; the manipulated object does not move (no contacts) -- labelled, NOT MuJoCo's constraint solver")
+    blk = {"dynamics": what,
            "config": f"{env_name} env.step with servo dynamics, {E} envs, uniform policy actions in [-1,1]",
            "steps_per_s": E * steps / dt, "ms_per_batch": dt / steps * 1e3, "substeps_per_s": E * steps * nsub / dt,
            "gpu_ms_per_batch": ev0.elapsed_time(ev1) / steps,
            "algorithmic_bytes_per_env_step": bytes_per_step, "achieved_GBps": E * steps * bytes_per_step / dt / 1e9,
-           "bound": "latency of ~5 k dependent FP64 operations per sub-step on one lane per env (64 waves at 4096 envs); not HBM"}
+           "bound": "latency of the serial chain walk + 9 x 9 solve of a sub-step (four waves share 64 envs; one workgroup per CU: 64 of 256 "
+                    "CUs busy at 4096 envs); not HBM"}
     if with_cpu:
         from oracle import oracle as O
         pi = planner_inputs(env_name)
         orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
         n = min(E, 1024)
         k = 4
-        ref = O.OracleEnv(orc, env.facts, n, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn)
+        ref = O.OracleEnv(orc, env.facts, n, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn, obj=env.obj)
         ref.set_state(q_init[:n].cpu().numpy())
         a_host = acts[:, :n].cpu().numpy()
         cores = host_cores()
@@ -327,7 +336,7 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20):
             ref.step(a_host[t], nthreads=cores)
         dt_cpu = time.perf_counter() - t0
         # parity: the GPU envs after the same k steps from the same reset state
-        chk = make_env(env_name, n, device=device, seed=11, dynamics=True, max_episode_steps=1 << 30)
+        chk = make_env(env_name, n, device=device, seed=11, dynamics=True, contacts=contacts, max_episode_steps=1 << 30)
         chk.set_state(q_init[:n].clone())
         for t in range(k):
             chk.step(acts[t, :n].contiguous())
@@ -335,7 +344,7 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20):
         blk["parity_mismatches_vs_oracle"] = int((chk.obs.cpu().numpy().view(np.uint64) != ref.obs.view(np.uint64)).sum()
                                                  + (chk.qvel.cpu().numpy().view(np.uint64) != ref.qvel.view(np.uint64)).sum()
                                                  + (chk.qpos.cpu().numpy().view(np.uint64) != ref.qpos.view(np.uint64)).sum())
-        one = O.OracleEnv(orc, env.facts, 64, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn)
+        one = O.OracleEnv(orc, env.facts, 64, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn, obj=env.obj)
         one.set_state(q_init[:64].cpu().numpy())
         t0 = time.perf_counter()
         one.step(a_host[0][:64], nthreads=1)

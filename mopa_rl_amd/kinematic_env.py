@@ -232,6 +232,7 @@ class BatchKinematicEnv:
         self._scene = None
         self.dynamics = bool(dynamics)
         self.dyn = None
+        self.obj = None
         if self.dynamics:
             from .dynamics import dyn_facts
             self.dyn = df = dyn_facts(self.model, f, frame_dt=frame_dt)

@@ -10,8 +10,8 @@ the SMDP reward `sum_i gamma^i r_i` and `intra_steps` are accumulated (:152-199)
 the current reward (:303-334).  Counters `mp / rl / interpolation / mp_fail / approximate / invalid` are kept per env.
 
 Action spaces: joint-space MoPA-SAC, and MoPA + IK (`use_ik_target`: Cartesian displacement + rotation quaternion of the
-ik_target site, turned into a joint displacement by the batched damped-LS IK -- BASELINE config 5); `discrete_action` is not
-offered.  Envs: the three Sawyer
+ik_target site, turned into a joint displacement by the batched damped-LS IK -- BASELINE config 5), and `discrete_action`
+(the policy's `ac_type` head routes a step, :86-88,106-111,349).  Envs: the three Sawyer
 obstacle envs (no unlimited joints; 7 arm entries per action, Lift adds the gripper entry, which a planner step applies at
 the last waypoint of its path, :163-167).  The `reuse_data` relabelling (:204-300) -- extra transitions between random
 pairs of waypoints of an executed path -- is `reuse_transitions()` below, fed by `agent_step(..., record=True)`.
@@ -81,6 +81,9 @@ class RolloutConfig:
     planner_workgroups: int = 64      # persistent workgroups of an asynchronous launch: a planner wave holds ~370 registers, no
                                       # validity wave (226) fits next to it on a SIMD, so launches that took every CU would stall
                                       # the main stream's kernels for their whole bulk phase
+    discrete_action: bool = False     # --discrete_action (config/__init__.py:110; rl/mopa_rollouts.py:86-88,106-111,349): the policy's
+                                      # `ac_type` head (1 = planner), not the action's magnitude, routes a step; direct actions
+                                      # are then NOT divided by omega
     use_graphs: bool = False          # async_planner, joint-space actions, record=False: the fixed-shape halves of a call (policy
                                       # action -> target -> pull-back -> straight-line pre-check; execution + bookkeeping when no
                                       # planner launch finished in the call) are captured once as HIP graphs and replayed -- ~90
@@ -211,6 +214,8 @@ class BatchMoPARollout:
         self.ac_dim = (7 if self.cfg.use_ik_target else self.n) + (env.action_dim - self.n)
         self._pend_ob = torch.zeros(self.E, env.obs_dim, dtype=f64, device=dev)      # ob / ac of the step a busy env is in
         self._pend_ac = torch.zeros(self.E, self.ac_dim, dtype=f64, device=dev)
+        self._ac_type_in = torch.zeros(self.E, dtype=torch.int64, device=dev)      # discrete_action: this call's ac_type / that of a pending step
+        self._pend_type = torch.zeros(self.E, dtype=torch.int64, device=dev)
 
     # ------------------------------------------------------------------
     def close(self):
@@ -602,7 +607,7 @@ class BatchMoPARollout:
         job.update(starts=starts, ends=ends, count=count, walk=walk, fb=list(np.nonzero(~verdict.all(axis=1))[0]))
 
     # ------------------------------------------------------------------
-    def agent_step(self, ac, record: bool = False):
+    def agent_step(self, ac, record: bool = False, ac_type=None):
         """One agent step for all E envs.  ac: float64 [E, >= self.ac_dim] GPU tensor (policy output in [-1, 1]).
         Returns a dict of GPU tensors: ob [E,obs_dim] (before), ac (the action each transition belongs to), ob_next
         [E,obs_dim], rew [E] (SMDP return of the step), done [E] uint8, intra_steps [E] int64, is_planner [E] bool, success [E]
@@ -617,6 +622,10 @@ class BatchMoPARollout:
         complete their step (path execution or the failed-plan step) in the first call after that.  Envs are independent and a
         query's sample stream is keyed by the env's own step count, so each env goes through the same sequence of transitions
         either way; only their interleaving differs.  Rows of the outputs are meaningful where `stepped`."""
+        if self.cfg.discrete_action:
+            if ac_type is None:
+                raise _lib.MopaError("discrete_action: agent_step needs the policy's ac_type [E] (1 = motion planner, 0 = direct)")
+            self._ac_type_in.copy_(ac_type.reshape(-1))
         if self.cfg.use_graphs and not record and getattr(self, "timing", None) is None:
             return self._agent_step_graphs(ac)
         bag = self._seg_pre(ac)
@@ -718,7 +727,13 @@ class BatchMoPARollout:
         else:
             a = ac[:, :n].contiguous()
             extra_ac = ac_tr[:, n:env.action_dim]
-        is_pl = is_planner_action(a, cfg.omega) & active
+        if cfg.discrete_action:
+            # the discrete head decides (rl/mopa_rollouts.py:86-88,106-111); a busy env's pending step keeps its own type
+            ac_type = torch.where(busy0, self._pend_type, self._ac_type_in)
+            is_pl = (ac_type != 0) & active
+        else:
+            ac_type = None
+            is_pl = is_planner_action(a, cfg.omega) & active
         # Everything below works on all E rows with masks -- no index lists, so no host read-back of how many envs take which
         # branch.  Rows that are not planner actions carry a known-valid dummy state through the validity launches; nothing of
         # theirs is used.
@@ -766,7 +781,9 @@ class BatchMoPARollout:
         self.busy |= blocked
         self._pend_ob.copy_(torch.where(blocked[:, None], prev_ob, self._pend_ob))
         self._pend_ac.copy_(torch.where(blocked[:, None], ac_tr, self._pend_ac))
-        return {"active": active, "prev_ob": prev_ob, "ac_tr": ac_tr, "a": a, "extra_ac": extra_ac, "is_pl": is_pl, "plan_ok": plan_ok,
+        if cfg.discrete_action:
+            self._pend_type.copy_(torch.where(blocked, ac_type, self._pend_type))
+        return {"ac_type": ac_type, "active": active, "prev_ob": prev_ob, "ac_tr": ac_tr, "a": a, "extra_ac": extra_ac, "is_pl": is_pl, "plan_ok": plan_ok,
                 "traj_pad": traj_pad, "path_len": path_len, "n_finished": 0}
 
     def _seg_plan(self, bag):
@@ -867,7 +884,8 @@ class BatchMoPARollout:
         sitting = self.busy & ~finished            # still waiting for their query: nothing of theirs is touched
         stepped = ~sitting
         # ---- direct execution (:336-356) and failed plans (:303-334: reward of the current state, one env step) in one launch
-        act0 = torch.where(direct[:, None], a / torch.full_like(a, cfg.omega), torch.zeros_like(a))
+        # (:349-352: with the discrete head the direct action goes to the env as it is, otherwise rescaled by 1 / omega)
+        act0 = torch.where(direct[:, None], a if cfg.discrete_action else a / torch.full_like(a, cfg.omega), torch.zeros_like(a))
         if env.action_dim > n:          # Lift: the gripper entry is passed through unscaled (:340-343)
             act0 = torch.cat([act0, torch.where(direct[:, None], extra_ac, torch.zeros_like(extra_ac))], dim=1)
         act0 = act0.contiguous()
@@ -898,6 +916,8 @@ class BatchMoPARollout:
         self._t_dev += 1
         res = {"ob": prev_ob, "ac": ac_tr, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra,
                "is_planner": is_pl | finished, "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok, "stepped": stepped}
+        if cfg.discrete_action:
+            res["ac_type"] = bag["ac_type"]
         if rec is not None:
             res["record"] = rec
         return res

@@ -79,6 +79,36 @@ def test_batched_rollout_equals_reference_rollout_runner(env_name, tag):
     assert G["done"].sum() > 0 and G["intra"].max() >= 8
 
 
+def test_discrete_action_rollout_equals_reference_runner():
+    """--discrete_action (rl/mopa_rollouts.py:86-88,106-111,349): the policy's `ac_type` head routes a step to the planner, and
+    direct actions are not rescaled by 1 / omega -- against the reference runner run with config.discrete_action
+    (tests/golden/ref_py_rollout_push_discrete.npz)."""
+    import torch
+    from mopa_rl_amd.rollout import COUNTERS
+    G = np.load(os.path.join(GOLD, "ref_py_rollout_push_discrete.npz"))
+    E, T = G["ac"].shape[:2]
+    env, ro = _make(G, E, ENV, discrete_action=True)
+    for t in range(T):
+        _load_state(env, G["qpos_start"][:, t], G["ep_len_start"][:, t])
+        before = {k: ro.counters[k].clone() for k in COUNTERS}
+        ro.t = t
+        out = ro.agent_step(torch.tensor(G["ac"][:, t], device=env.device), ac_type=torch.tensor(G["ac_type"][:, t], device=env.device))
+        _check_qpos(env.qpos.cpu().numpy(), G["qpos_end"][:, t], G["pulled_back"][:, t], f"step {t}: qpos")
+        assert np.array_equal(out["done"].cpu().numpy().astype(np.int64), G["done"][:, t]), f"step {t}: done"
+        assert np.array_equal(out["intra_steps"].cpu().numpy(), G["intra"][:, t]), f"step {t}: intra_steps"
+        assert np.array_equal(out["ac_type"].cpu().numpy(), G["ac_type"][:, t])
+        got_c = np.stack([(ro.counters[k] - before[k]).cpu().numpy() for k in COUNTERS], axis=1)
+        assert np.array_equal(got_c, G["counters"][:, t]), f"step {t}: counters"
+        np.testing.assert_allclose(out["rew"].cpu().numpy(), G["rew"][:, t], rtol=1e-12, atol=1e-13, err_msg=f"step {t}: reward")
+        np.testing.assert_allclose(out["ob_next"].cpu().numpy(), G["ob_next"][:, t], rtol=0, atol=1e-12, err_msg=f"step {t}: ob_next")
+    tot = dict(zip(COUNTERS, G["counters"].sum(axis=(0, 1))))
+    assert tot["rl"] > 0 and tot["interpolation"] > 0 and tot["mp_fail"] > 0, tot
+    # the head, not the magnitude, decided: small actions that went to the planner and large ones executed directly
+    n = 7
+    big = (np.abs(G["ac"][:, :, :n]) > 0.7).any(axis=2)
+    assert (G["ac_type"].astype(bool) & ~big).any() and (~G["ac_type"].astype(bool) & big).any()
+
+
 def test_ik_action_space_rollout_equals_reference_runner():
     """BASELINE config 5's action space (MoPA + IK, `use_ik_target`): Cartesian displacement + rotation quaternion of the grip site
     -> joint displacement through the batched damped-LS IK (K5, position + orientation target) -> planner / direct decision ->

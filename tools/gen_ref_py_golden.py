@@ -340,12 +340,13 @@ def rollout_actions(E, T, n_ac, rng):
     return ac
 
 
-def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=False, ik=False):
+def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=False, ik=False, discrete=False):
     import util.env as ref_util_env
     from rl.mopa_rollouts import MoPARolloutRunner
     ref_util_env.np = refshim.NumpyCompat()
     P = ROLLOUT_PARAMS
-    cfg = make_config(env_name, timelimit=P["timelimit"], reuse_data=reuse, num_trials=P["num_trials"], use_ik_target=ik)
+    cfg = make_config(env_name, timelimit=P["timelimit"], reuse_data=reuse, num_trials=P["num_trials"], use_ik_target=ik,
+                      discrete_action=discrete)
     n_ac = 8 if env_name == "SawyerLiftObstacle-v0" else 7
     agent, pi = make_agent(env_name, cfg, ac_dim=n_ac)
     st = Streams(agent, E, P["seed"], P["max_nodes"], P["max_path"])
@@ -358,6 +359,8 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
         AC[: E // 4, :, 3:] = rng.uniform(-1, 1, size=(E // 4, T, 4))            # ... and some arbitrary ones
     else:
         AC = rollout_actions(E, T, n_ac, rng)
+    # --discrete_action (rl/mopa_rollouts.py:86-88): the policy's `ac_type` head, not the action's magnitude, picks the planner
+    AC_TYPE = rng.integers(0, 2, size=(E, T)) if discrete else None
     nq = pi.model.nq
     out = dict(ac=AC, qpos_start=np.zeros((E, T, nq)), ep_len_start=np.zeros((E, T), dtype=np.int64), qpos_end=np.zeros((E, T, nq)),
                rew=np.zeros((E, T)), done=np.zeros((E, T), dtype=np.int64), intra=np.zeros((E, T), dtype=np.int64),
@@ -385,7 +388,9 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
             if ik:
                 return OrderedDict([("default", AC[e, t, :3].copy()), ("quat", AC[e, t, 3:].copy())]), None, None
             a = OrderedDict(default=AC[e, t].copy())
-            if agent.is_planner_ac(a):      # will the runner's back-off move this step's target?  (it divides by np.linalg.norm,
+            if discrete:
+                a["ac_type"] = np.array([int(AC_TYPE[e, t])])
+            if (bool(AC_TYPE[e, t]) if discrete else agent.is_planner_ac(a)):      # will the runner's back-off move this step's target?  (it divides by np.linalg.norm,
                 n = len(env.ref_joint_pos_indexes)    # a BLAS dot whose summation order is build-dependent: such steps are compared to round-off)
                 tq = env.sim.data.qpos.copy()
                 tq[env.ref_joint_pos_indexes] += agent.convert2planner_displacement(a["default"][:n], env._ac_scale)
@@ -433,7 +438,9 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
         out.update(x_env=np.array([x[0] for x in extra]), x_t=np.array([x[1] for x in extra]), x_ob=np.array([x[2] for x in extra]),
                    x_ac=np.array([x[3] for x in extra]), x_rew=np.array([x[4] for x in extra]), x_done=np.array([x[5] for x in extra]),
                    x_intra=np.array([x[6] for x in extra]), x_ob_next=np.array([x[7] for x in extra]))
-    save(f"ref_py_rollout_{tag}{'_reuse' if reuse else ''}{'_ik' if ik else ''}.npz",
+    if discrete:
+        out["ac_type"] = AC_TYPE
+    save(f"ref_py_rollout_{tag}{'_reuse' if reuse else ''}{'_ik' if ik else ''}{'_discrete' if discrete else ''}.npz",
          params=np.array([P["timelimit"], P["max_nodes"], P["max_path"], P["seed"], P["max_episode_steps"], P["num_trials"]]), **out)
 
 
@@ -559,6 +566,7 @@ def gen_rollouts():
     gen_rollout("SawyerLiftObstacle-v0", "lift", E=24, T=5)
     gen_rollout("SawyerAssemblyObstacle-v0", "assembly", E=24, T=5)
     gen_rollout("SawyerAssemblyObstacle-v0", "assembly", E=24, T=5, ik=True)
+    gen_rollout(E=24, T=5, discrete=True)
 
 
 SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): kernel-trace stats + PMC passes for bench.py.
 # Small CSV summaries land in gpurun_out/prof_<tag>/ ; copy what you want judged into profiles/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 WORK=/tmp/prof_$TAG

@@ -188,19 +188,21 @@ def _i(a):
     return a, a.ctypes.data_as(_ip)
 
 
-def model_struct(m, keep: list) -> MopaModel:
-    """MopaModel view of a CompiledModel; the numpy buffers it points at are appended to `keep`."""
+def model_struct(m, keep: list, pair_geom=None) -> MopaModel:
+    """MopaModel view of a CompiledModel; the numpy buffers it points at are appended to `keep`.
+    pair_geom: a (reduced) candidate-pair list to hand over instead of the model's."""
     def d(a):
         a, p = _d(a); keep.append(a); return p
 
     def i(a):
         a, p = _i(a); keep.append(a); return p
 
+    pairs = m.pair_geom if pair_geom is None else pair_geom
     return MopaModel(
-        m.nq, len(m.body_names), len(m.jnt_names), len(m.geom_type), len(m.pair_geom),
+        m.nq, len(m.body_names), len(m.jnt_names), len(m.geom_type), len(pairs),
         i(m.body_parent), d(m.body_pos), d(m.body_quat), i(m.body_jntadr), i(m.body_jntnum),
         i(m.jnt_type), i(m.jnt_qposadr), d(m.jnt_axis), d(m.jnt_pos), d(m.jnt_ref), i(m.jnt_limited), d(m.jnt_range),
-        i(m.geom_type), i(m.geom_body), i(m.geom_mjid), d(m.geom_size), d(m.geom_pos), d(m.geom_quat), i(m.pair_geom),
+        i(m.geom_type), i(m.geom_body), i(m.geom_mjid), d(m.geom_size), d(m.geom_pos), d(m.geom_quat), i(pairs),
         len(m.mesh_vertnum), len(m.mesh_vert), i(m.mesh_vertadr), i(m.mesh_vertnum), d(m.mesh_vert), i(m.geom_dataid))
 
 
@@ -208,10 +210,24 @@ class Scene:
     """Owns one MopaScene* (== one KinematicPlanner instance of the reference)."""
 
     def __init__(self, model, passive_joint_idx, ignored_contacts, contact_threshold: float, range_: float = 0.1,
-                 resolution: float = 0.005, seed: int = 0, device: int = -1):
+                 resolution: float = 0.005, seed: int = 0, device: int = -1, prune_pairs: Optional[bool] = None):
+        """prune_pairs (default: on, MOPA_PRUNE_PAIRS=0 turns it off): candidate pairs that the scene's compile-time proof
+        (tools/prove_separated_pairs.py, `meta["never_violating_pairs"]`: a Lipschitz branch-and-bound over the joint ranges)
+        shows can never reach the contact threshold are not handed to the kernels at all.  Verdicts and depths are
+        unchanged for joint values inside their ranges -- the states OMPL samples and the rollouts clip to."""
         L = lib()
         m = model
         keep = []
+        if prune_pairs is None:
+            prune_pairs = os.environ.get("MOPA_PRUNE_PAIRS", "1") != "0"
+        pairs = np.asarray(m.pair_geom, dtype=np.int32).reshape(-1, 2)
+        never = getattr(m, "meta", {}).get("never_violating_pairs") or []
+        self.npair_pruned = 0
+        if prune_pairs and len(never) and float(contact_threshold) <= 0.0:
+            drop = {(int(a), int(b)) for a, b in never} | {(int(b), int(a)) for a, b in never}
+            keep_row = np.array([(int(a), int(b)) not in drop for a, b in pairs], dtype=bool)
+            self.npair_pruned = int((~keep_row).sum())
+            pairs = np.ascontiguousarray(pairs[keep_row])
 
         def d(a):
             a, p = _d(a); keep.append(a); return p
@@ -222,7 +238,7 @@ class Scene:
         ign = np.asarray(list(ignored_contacts), dtype=np.int32).reshape(-1, 2)
         pas = np.asarray(list(passive_joint_idx), dtype=np.int32)
         desc = MopaSceneDesc()
-        desc.model = model_struct(m, keep)
+        desc.model = model_struct(m, keep, pair_geom=pairs)
         desc.n_passive = len(pas)
         desc.passive_qpos_idx = i(pas)
         desc.n_ignored = len(ign)

@@ -40,11 +40,11 @@ def _scene_with_kernel(kernel, *args, **kw):
                 os.environ[k] = v
 
 
-def _mk(env, oracle_mod, kernel=None):
+def _mk(env, oracle_mod, kernel=None, **scene_kw):
     from mopa_rl_amd.scene import planner_inputs
     pi = planner_inputs(env)
     sc = _scene_with_kernel(kernel, pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold,
-                            range_=pi.spec.range, seed=7)
+                            range_=pi.spec.range, seed=7, **scene_kw)
     orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
     return pi, sc, orc
 
@@ -74,7 +74,7 @@ def test_fk_bit_exact(env, oracle_mod):
 
 @pytest.mark.parametrize("env", SUPPORTED_ENVS)
 def test_pair_dist_bit_exact(env, oracle_mod):
-    pi, sc, orc = _mk(env, oracle_mod)
+    pi, sc, orc = _mk(env, oracle_mod, prune_pairs=False)       # per-pair distances: the full candidate list
     ignored = set(pi.ignored_contacts)
     m = pi.model
     ign_mask = np.array([(min(m.geom_mjid[a], m.geom_mjid[b]), max(m.geom_mjid[a], m.geom_mjid[b])) in ignored
@@ -703,3 +703,28 @@ def test_plan_full_size(oracle_mod):
     for e, (st, opath, ochk, _) in zip(sub, res):
         assert st_h[e] == st and plen_h[e] == len(opath) and chk_h[e] == ochk, f"query {e}"
         assert np.array_equal(_bits(path_h[e, :plen_h[e]]), _bits(opath)), f"query {e}: path"
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_pruned_pairs_never_reach_the_threshold(env, oracle_mod):
+    """The compile-time proof behind `Scene(prune_pairs=True)` (tools/prove_separated_pairs.py), cross-checked on sampled
+    states: the oracle's distance of every pruned pair stays above 0 (> the negative contact threshold), and verdicts /
+    depths with and without pruning agree bit for bit; the proof covers joint values inside their ranges."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk(env, oracle_mod)
+    _, sc_full, _ = _mk(env, oracle_mod, prune_pairs=False)
+    m = pi.model
+    never = m.meta.get("never_violating_pairs", [])
+    assert len(never) > 0 and sc.npair_pruned > 0 and sc.npair_checked == sc_full.npair_checked - sc.npair_pruned
+    idx = {(int(a), int(b)): k for k, (a, b) in enumerate(m.pair_geom)}
+    rows_of = [idx[(int(a), int(b))] for a, b in never]
+    qa, rows = sample_states(pi, 4000, 17, "uniform")
+    lo = np.inf
+    for i in range(0, len(qa), 8):
+        lo = min(lo, orc.pair_dist(_full(pi, qa[i], rows[0]))[rows_of].min())
+    assert lo > 0.0
+    tq, tr = torch.tensor(qa, device="cuda"), torch.tensor(rows, device="cuda")
+    a = BatchPlanner(sc).is_valid(tq, tr, samples_per_env=len(qa), want_min_dist=True)
+    b = BatchPlanner(sc_full).is_valid(tq, tr, samples_per_env=len(qa), want_min_dist=True)
+    assert torch.equal(a[0], b[0]) and np.array_equal(_bits(a[1].cpu().numpy()), _bits(b[1].cpu().numpy()))

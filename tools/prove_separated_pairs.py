@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Compile-time pruning of candidate pairs that can NEVER violate the contact threshold (K1).
+
+Some candidate pairs of two robot geoms survive every bounding-sphere test -- the links are neighbours but one -- and
+never collide anywhere in the joint box (l0's sphere / l2's capsule: present in 100 % of the states, minimum distance
+6.7 cm).  This tool PROVES such pairs separated over the whole box of the joints their relative pose depends on, by
+branch and bound with a Lipschitz bound:
+
+    true_dist(q) >= LB(q_c) - sum_j rho_j |q_j - q_c,j|        for every q of a box with centre q_c
+
+  * LB(q_c): a lower bound of the true distance at the centre -- the oracle's closed forms (exact for sphere / capsule /
+    box combinations, a lower bound for separated boxes); a cylinder is replaced by its enclosing capsule (contains it);
+  * rho_j: the largest distance any point of the far-side geom can have from joint j's axis, bounded independently of the
+    configuration by the link offsets along the chain + the geom's offset + its bounding radius (1 for a slide): the true
+    distance is 1-Lipschitz in the relative displacement of the two point sets.
+
+A box is proven when LB(q_c) - sum_j rho_j w_j > margin (> 0 > contact_threshold); otherwise it is split along its widest
+(rho-weighted) side.  Pairs whose relative pose depends on more than 3 joints, on a free joint, or that cannot be proven
+within the evaluation budget stay in the list.  The proof covers joint values INSIDE the joint ranges (what OMPL samples
+and the rollouts clip to).  Output: `never_violating_pairs` (pairs of collidable-geom indices) into the scene JSON's meta,
+which `_lib.Scene` drops from the kernel's pair list (the oracle keeps checking them: the parity sweeps are the cross-check).
+
+    python tools/prove_separated_pairs.py            # all four scenes, rewrites mopa_rl_amd/scenes/*.json meta
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+from mopa_rl_amd.mjcf import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_SPHERE, JNT_FREE, JNT_HINGE, JNT_SLIDE  # noqa: E402
+from mopa_rl_amd.scene import ENV_SPECS, planner_inputs, scene_path  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+MARGIN = 1e-4
+
+
+def chain_joints(m, body, stop):
+    """joints of the bodies on the path body -> ... -> (exclusive) stop, each with the bodies between it and `body`"""
+    out, path = [], []
+    b = body
+    while b != stop and b > 0:
+        path.append(b)
+        for j in range(int(m.body_jntadr[b]), int(m.body_jntadr[b]) + int(m.body_jntnum[b])):
+            out.append((j, list(path)))
+        b = int(m.body_parent[b])
+    return out
+
+
+def lca(m, a, b):
+    anc = set()
+    x = a
+    while x > 0:
+        anc.add(x)
+        x = int(m.body_parent[x])
+    anc.add(0)
+    x = b
+    while x not in anc:
+        x = int(m.body_parent[x])
+    return x
+
+
+def rbound(t, s):
+    return {GEOM_SPHERE: s[0], GEOM_CAPSULE: s[0] + s[1], GEOM_CYLINDER: float(np.hypot(s[0], s[1])), GEOM_BOX: float(np.linalg.norm(s))}[t]
+
+
+def prove_pair(m, orc, q0, a, b, max_evals):
+    ta, tb = int(m.geom_type[a]), int(m.geom_type[b])
+    ok_types = (GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX)
+    if ta not in ok_types or tb not in ok_types:
+        return None, "type"
+    ba, bb = int(m.geom_body[a]), int(m.geom_body[b])
+    top = lca(m, ba, bb)
+    joints = []
+    for g, body in ((a, ba), (b, bb)):
+        for j, path in chain_joints(m, body, top):
+            jt = int(m.jnt_type[j])
+            if jt == JNT_FREE:
+                return None, "free joint"
+            # reach of geom g about joint j: offsets of the bodies between the joint's body and the geom's body, the joint
+            # anchor, the geom's offset and its bounding radius
+            reach = float(np.linalg.norm(m.geom_pos[g])) + rbound(int(m.geom_type[g]), m.geom_size[g]) + float(np.linalg.norm(m.jnt_pos[j]))
+            for pb in path[:-1]:
+                reach += float(np.linalg.norm(m.body_pos[pb]))
+                for jj in range(int(m.body_jntadr[pb]), int(m.body_jntadr[pb]) + int(m.body_jntnum[pb])):
+                    if int(m.jnt_type[jj]) == JNT_SLIDE:      # a slide below the joint lengthens the arm by its travel
+                        reach += float(np.abs(m.jnt_range[jj] - m.jnt_ref[jj]).max())
+            rho = 1.0 if jt == JNT_SLIDE else reach
+            lo, hi = (m.jnt_range[j] if m.jnt_limited[j] else (-np.pi, np.pi))
+            joints.append((int(m.jnt_qposadr[j]), float(lo), float(hi), rho))
+    if not joints:
+        return None, "rigid"
+    if len(joints) > 3:
+        return None, f"{len(joints)} joints"
+
+    def cap(t, s):      # a cylinder inside the capsule of the same axis, radius and half length
+        return (GEOM_CAPSULE, s) if t == GEOM_CYLINDER else (t, s)
+    (t1, s1), (t2, s2) = cap(ta, m.geom_size[a]), cap(tb, m.geom_size[b])
+    ia, ib = (a, b) if t1 <= t2 else (b, a)
+    if t1 > t2:
+        (t1, s1), (t2, s2) = (t2, s2), (t1, s1)
+    adr = [j[0] for j in joints]
+    rho = np.array([j[3] for j in joints])
+    stack = [(np.array([(j[1] + j[2]) / 2 for j in joints]), np.array([(j[2] - j[1]) / 2 for j in joints]))]
+    evals, worst = 0, np.inf
+    q = q0.copy()
+    while stack:
+        c, w = stack.pop()
+        q[adr] = c
+        gp, gm = orc.fk(q)
+        d = O.geom_dist(t1, s1, gp[ia], gm[ia], t2, s2, gp[ib], gm[ib])
+        evals += 1
+        worst = min(worst, d)
+        if d <= MARGIN:
+            return False, f"LB {d:.4f} at {np.round(c, 3)}"
+        if d - float(rho @ w) > MARGIN:
+            continue
+        if evals > max_evals:
+            return None, f"budget ({evals} evals, min LB {worst:.4f})"
+        k = int(np.argmax(rho * w))
+        w2 = w.copy()
+        w2[k] /= 2
+        for sgn in (-1, 1):
+            c2 = c.copy()
+            c2[k] += sgn * w2[k]
+            stack.append((c2, w2))
+    return True, f"{evals} evals, min LB {worst:.4f}, {len(joints)} joints"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--max-evals", type=int, default=400000)
+    ap.add_argument("--dry", action="store_true")
+    args = ap.parse_args()
+    from mopa_rl_amd.mjcf import CompiledModel
+    for env, spec in ENV_SPECS.items():
+        pi = planner_inputs(env)
+        m = pi.model
+        orc = O.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, spec.contact_threshold)
+        ign = set(tuple(p) for p in pi.ignored_contacts)
+        q0 = np.array(m.qpos0, dtype=np.float64)
+        proven = []
+        t0 = time.time()
+        for a, b in m.pair_geom:
+            a, b = int(a), int(b)
+            ia, ib = int(m.geom_mjid[a]), int(m.geom_mjid[b])
+            if (min(ia, ib), max(ia, ib)) in ign:
+                continue
+            res, why = prove_pair(m, orc, q0, a, b, args.max_evals)
+            name = lambda g: (m.all_geom_names[int(m.geom_mjid[g])] or f"g{int(m.geom_mjid[g])}") + "@" + m.body_names[int(m.geom_body[g])]
+            if res:
+                proven.append([a, b])
+                print(f"  {env}: PROVEN separated  {name(a)} / {name(b)}: {why}", flush=True)
+            elif res is None and why not in ("type", "free joint", "rigid") and "joints" not in why:
+                print(f"  {env}: undecided        {name(a)} / {name(b)}: {why}", flush=True)
+        print(f"{env}: {len(proven)} of {len(m.pair_geom)} candidate pairs proven never to violate the threshold ({time.time() - t0:.0f} s)", flush=True)
+        if not args.dry:
+            path = scene_path(spec.scene)
+            cm = CompiledModel.load(path)
+            cm.meta["never_violating_pairs"] = proven
+            cm.meta["never_violating_pairs_note"] = ("tools/prove_separated_pairs.py: branch-and-bound Lipschitz proof over the joint ranges, margin "
+                                                     f"{MARGIN} m; valid for joint values inside their ranges")
+            cm.save(path)
+
+
+if __name__ == "__main__":
+    main()

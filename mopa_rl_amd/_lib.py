@@ -221,7 +221,11 @@ class Scene:
         if prune_pairs is None:
             prune_pairs = os.environ.get("MOPA_PRUNE_PAIRS", "1") != "0"
         pairs = np.asarray(m.pair_geom, dtype=np.int32).reshape(-1, 2)
-        never = getattr(m, "meta", {}).get("never_violating_pairs") or []
+        meta = getattr(m, "meta", {})
+        never = list(meta.get("never_violating_pairs") or [])
+        at = meta.get("never_violating_pairs_thr") or {}
+        if at and float(contact_threshold) <= float(at.get("threshold", -np.inf)):
+            never += list(at.get("pairs") or [])      # may touch, never reach a threshold this negative
         self.npair_pruned = 0
         if prune_pairs and len(never) and float(contact_threshold) <= 0.0:
             drop = {(int(a), int(b)) for a, b in never} | {(int(b), int(a)) for a, b in never}

@@ -316,7 +316,7 @@ class BatchKinematicEnv:
         waypoint of a path (:163-167); the other waypoints carry `form_action`'s gripper difference.  rec: optional dict
         with 'ob' [E,L,obs_dim] f64, 'meta_rew' [E,L] f64, 'done' [E,L] uint8, 'n_exec' [E] int64 filled per executed waypoint."""
         if self.dynamics:
-            raise _lib.MopaError("waypoint execution with dynamics=True is not built yet (each waypoint is 75 dependent sub-steps)")
+            return self._exec_trajectories_dyn(traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec, last_extra, stream)
         L = int(traj.shape[1])
         r = rec or {}
         p = lambda k: _ptr(r[k]) if k in r else None
@@ -327,6 +327,41 @@ class BatchKinematicEnv:
             _ptr(path_len), L, _ptr(disc_pow), _ptr(last_extra) if last_extra is not None else None, _ptr(self.obs), _ptr(self.reward),
             _ptr(self.done), _ptr(self.success), _ptr(smdp_rew), _ptr(smdp_done), _ptr(intra), p("ob"), p("meta_rew"), p("done"),
             p("n_exec"), _stream_handle(stream)))
+
+    def _exec_trajectories_dyn(self, traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec, last_extra, stream):
+        """`exec_trajectories` with the servo dynamics as the physics: a waypoint is a full env.step (75 dependent sub-steps),
+        so the walk is one step launch per waypoint index over the envs still on their paths (the others sit the launch
+        out through the step's move mask), with the SMDP return / done / intra_steps folded between launches by the same
+        arithmetic as the kinematic kernel (`rew = rew + gamma^k r_k`; stop at the first `done`).  One host read-back (the
+        longest path)."""
+        torch = _torch()
+        if stream is not None:
+            raise _lib.MopaError("the dynamics form of exec_trajectories runs on the current stream")
+        E, L = self.E, int(traj.shape[1])
+        if self.action_dim > self.n_arm and last_extra is None:
+            raise _lib.MopaError("this env needs last_extra (the gripper action of the last waypoint)")
+        plen = torch.clamp(path_len, max=L)
+        alive = plen > 0
+        n_walk = int(plen.max().item()) if E else 0
+        g0 = int(self.facts.grip_qpos_idx[0]) if self.action_dim > self.n_arm else None
+        for k in range(n_walk):
+            act = alive & (plen > k)
+            wp = traj[:, k]
+            a = wp[:, self._arm_idx] - self.qpos[:, self._arm_idx]          # env.form_action(waypoint): waypoint - current arm state
+            if g0 is not None:
+                extra = torch.where(plen - 1 == k, last_extra, wp[:, g0] - self.qpos[:, g0])
+                a = torch.cat([a, extra[:, None]], dim=1)
+            flags = torch.where(act, 1, 2).to(torch.uint8).contiguous()
+            self._launch(a.contiguous(), True, flags)
+            smdp_rew.copy_(torch.where(act, smdp_rew + disc_pow[k] * self.reward, smdp_rew))
+            smdp_done.copy_(torch.where(act, self.done, smdp_done))
+            intra.copy_(torch.where(act, torch.full_like(intra, k), intra))
+            if rec:
+                rec["ob"][:, k] = torch.where(act[:, None], self.obs, rec["ob"][:, k])
+                rec["meta_rew"][:, k] = torch.where(act, smdp_rew, rec["meta_rew"][:, k])
+                rec["done"][:, k] = torch.where(act, self.done, rec["done"][:, k])
+                rec["n_exec"].copy_(torch.where(act, torch.full_like(rec["n_exec"], k + 1), rec["n_exec"]))
+            alive = alive & ~(act & self.done.bool())       # `if done or ep_len >= max_step: break`
 
     # ------------------------------------------------------------------
     def reset(self, mask=None):

@@ -274,3 +274,73 @@ def test_workgroup_and_single_wave_forms_agree(oracle_mod, torch_mod, contacts, 
         env.close()
     for a, b in zip(outs["block"], outs["wave"]):
         assert np.array_equal(_bits(a), _bits(b))
+
+
+def test_waypoint_execution_with_dynamics_equals_stepwise_oracle(oracle_mod, torch_mod):
+    """`exec_trajectories` on a dynamics env: every waypoint is a full env.step through the physics; the SMDP return, done,
+    intra_steps and the final state must equal the oracle env stepped waypoint by waypoint with the runner's rules
+    (rl/mopa_rollouts.py:152-199: action = form_action(waypoint), is_planner steps, stop at done)."""
+    torch = torch_mod
+    E, L = 48, 5
+    pi, env, ref = _setup(oracle_mod, "SawyerLiftObstacle-v0", E, max_episode_steps=4)
+    q, _ = _states(env, E, seed=2, spread=0.3)
+    env.set_state(torch.tensor(q, device=env.device))
+    ref.set_state(q)
+    rng = np.random.default_rng(4)
+    arm = list(env.facts.arm_qpos_idx)
+    g0 = int(env.facts.grip_qpos_idx[0])
+    traj = np.repeat(q[:, None, :], L, axis=1)
+    traj[:, :, arm] += np.cumsum(rng.uniform(-0.04, 0.04, size=(E, L, 7)), axis=1)
+    traj[:, :, g0] += rng.uniform(-0.002, 0.002, size=(E, L))
+    plen = rng.integers(0, L + 1, size=E)
+    last_extra = rng.uniform(-0.01, 0.01, size=E)
+    gamma = 0.99
+    disc = np.array([gamma ** k for k in range(L)])
+    dev = env.device
+    smdp_rew = torch.zeros(E, dtype=torch.float64, device=dev)
+    smdp_done = torch.zeros(E, dtype=torch.uint8, device=dev)
+    intra = torch.zeros(E, dtype=torch.int64, device=dev)
+    env.exec_trajectories(torch.tensor(traj, device=dev), torch.tensor(plen, device=dev), torch.tensor(disc, device=dev), smdp_rew, smdp_done, intra,
+                          last_extra=torch.tensor(last_extra, device=dev))
+    # the oracle, waypoint by waypoint
+    o_rew, o_done, o_intra = np.zeros(E), np.zeros(E, dtype=np.uint8), np.zeros(E, dtype=np.int64)
+    alive = plen > 0
+    for k in range(L):
+        act = alive & (plen > k)
+        if not act.any():
+            break
+        a = traj[:, k][:, arm] - ref.qpos[:, arm]
+        extra = np.where(plen - 1 == k, last_extra, traj[:, k, g0] - ref.qpos[:, g0])
+        a = np.concatenate([a, extra[:, None]], axis=1)
+        ref.step(a, is_planner=True, move_mask=np.where(act, 1, 2).astype(np.uint8))
+        o_rew = np.where(act, o_rew + disc[k] * ref.reward, o_rew)
+        o_done = np.where(act, ref.done, o_done)
+        o_intra = np.where(act, k, o_intra)
+        alive = alive & ~(act & (ref.done != 0))
+    assert np.array_equal(_bits(smdp_rew.cpu().numpy()), _bits(o_rew))
+    assert np.array_equal(smdp_done.cpu().numpy(), o_done) and np.array_equal(intra.cpu().numpy(), o_intra)
+    assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(ref.qpos)) and np.array_equal(_bits(env.qvel.cpu().numpy()), _bits(ref.qvel))
+    assert o_done.any() and (o_intra > 1).any()
+
+
+def test_rollout_runs_on_the_dynamics_env(torch_mod):
+    """BatchMoPARollout over an env whose physics is the servo dynamics + the cube's contacts: the planner / direct routing is
+    unchanged (it reads qpos), paths are executed through the physics, counters move, nothing goes non-finite."""
+    torch = torch_mod
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    E = 128
+    env = make_env("SawyerPushObstacle-v0", E, dynamics=True, contacts=True, seed=3)
+    env.reset()
+    ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.1, max_nodes=512, max_path=128, num_trials=10))
+    g = torch.Generator(device=env.device)
+    g.manual_seed(1)
+    n_pl = 0
+    for t in range(4):
+        ac = (torch.rand(E, 7, generator=g, dtype=torch.float64, device=env.device) * 2 - 1).contiguous()
+        out = ro.agent_step(ac)
+        assert bool(torch.isfinite(out["ob_next"]).all()) and bool(torch.isfinite(out["rew"]).all())
+        n_pl += int(out["is_planner"].sum())
+        env.reset(out["done"].bool())
+    assert n_pl > 0 and int(ro.counters["rl"].sum()) > 0 and int(ro.counters["interpolation"].sum()) > 0
+    assert float(env.qvel.abs().max()) > 1e-3

@@ -8,14 +8,15 @@ import numpy as np, collections
 from conftest import sample_states
 from mopa_rl_amd.scene import planner_inputs
 from oracle import oracle as O
-env = sys.argv[1] if len(sys.argv)>1 else "SawyerPushObstacle-v0"
+env = [a for a in sys.argv[1:] if not a.startswith("--")][0] if [a for a in sys.argv[1:] if not a.startswith("--")] else "SawyerPushObstacle-v0"
 pi = planner_inputs(env); m = pi.model
 orc = O.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
 N=4000
 qu,row = sample_states(pi,N//2,1,"uniform"); qn,_=sample_states(pi,N//2,2,"near")
 qa=np.concatenate([qu,qn]); thr=pi.spec.contact_threshold
 ign=set(tuple(p) for p in pi.ignored_contacts)
-pairs=[(int(a),int(b)) for a,b in m.pair_geom if (min(int(m.geom_mjid[a]),int(m.geom_mjid[b])),max(int(m.geom_mjid[a]),int(m.geom_mjid[b]))) not in ign]
+never=set((int(a),int(b)) for a,b in m.meta.get('never_violating_pairs',[])) if '--pruned' in sys.argv else set()
+pairs=[(int(a),int(b)) for a,b in m.pair_geom if (min(int(m.geom_mjid[a]),int(m.geom_mjid[b])),max(int(m.geom_mjid[a]),int(m.geom_mjid[b]))) not in ign and (int(a),int(b)) not in never]
 T=m.geom_type; S=m.geom_size
 # static geoms: body has no joint on path to world
 def moving(b):

@@ -36,6 +36,7 @@ from mopa_rl_amd.scene import ENV_SPECS, planner_inputs, scene_path  # noqa: E40
 from oracle import oracle as O  # noqa: E402
 
 MARGIN = 1e-4
+MAX_JOINTS = 3
 
 
 def chain_joints(m, body, stop):
@@ -67,7 +68,10 @@ def rbound(t, s):
     return {GEOM_SPHERE: s[0], GEOM_CAPSULE: s[0] + s[1], GEOM_CYLINDER: float(np.hypot(s[0], s[1])), GEOM_BOX: float(np.linalg.norm(s))}[t]
 
 
-def prove_pair(m, orc, q0, a, b, max_evals):
+def prove_pair(m, orc, q0, a, b, max_evals, floor=MARGIN):
+    """floor: the proof shows dist > floor everywhere.  MARGIN (> 0: never even touching) is valid for every pair type;
+    a negative floor (contact_threshold + MARGIN: touching allowed, the threshold never reached) only where the oracle's
+    distance is the exact signed distance -- no cylinder (portal refinement may over-estimate a depth) in the pair."""
     ta, tb = int(m.geom_type[a]), int(m.geom_type[b])
     ok_types = (GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX)
     if ta not in ok_types or tb not in ok_types:
@@ -93,7 +97,7 @@ def prove_pair(m, orc, q0, a, b, max_evals):
             joints.append((int(m.jnt_qposadr[j]), float(lo), float(hi), rho))
     if not joints:
         return None, "rigid"
-    if len(joints) > 3:
+    if len(joints) > MAX_JOINTS:
         return None, f"{len(joints)} joints"
 
     def cap(t, s):      # a cylinder inside the capsule of the same axis, radius and half length
@@ -114,9 +118,9 @@ def prove_pair(m, orc, q0, a, b, max_evals):
         d = O.geom_dist(t1, s1, gp[ia], gm[ia], t2, s2, gp[ib], gm[ib])
         evals += 1
         worst = min(worst, d)
-        if d <= MARGIN:
+        if d <= floor:
             return False, f"LB {d:.4f} at {np.round(c, 3)}"
-        if d - float(rho @ w) > MARGIN:
+        if d - float(rho @ w) > floor:
             continue
         if evals > max_evals:
             return None, f"budget ({evals} evals, min LB {worst:.4f})"
@@ -134,7 +138,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--max-evals", type=int, default=400000)
     ap.add_argument("--dry", action="store_true")
+    ap.add_argument("--max-joints", type=int, default=3)
     args = ap.parse_args()
+    global MAX_JOINTS
+    MAX_JOINTS = args.max_joints
     from mopa_rl_amd.mjcf import CompiledModel
     for env, spec in ENV_SPECS.items():
         pi = planner_inputs(env)
@@ -142,7 +149,7 @@ def main():
         orc = O.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, spec.contact_threshold)
         ign = set(tuple(p) for p in pi.ignored_contacts)
         q0 = np.array(m.qpos0, dtype=np.float64)
-        proven = []
+        proven, proven_thr = [], []
         t0 = time.time()
         for a, b in m.pair_geom:
             a, b = int(a), int(b)
@@ -150,17 +157,26 @@ def main():
             if (min(ia, ib), max(ia, ib)) in ign:
                 continue
             res, why = prove_pair(m, orc, q0, a, b, args.max_evals)
+            if res is False and GEOM_CYLINDER not in (int(m.geom_type[a]), int(m.geom_type[b])):
+                # they can touch; can they reach the (negative) threshold?
+                res, why = prove_pair(m, orc, q0, a, b, args.max_evals, floor=spec.contact_threshold + MARGIN)
+                if res:
+                    proven_thr.append([a, b])
+                    print(f"  {env}: PROVEN above the threshold  {(m.all_geom_names[int(m.geom_mjid[a])] or a)} / {(m.all_geom_names[int(m.geom_mjid[b])] or b)}: {why}", flush=True)
+                    continue
             name = lambda g: (m.all_geom_names[int(m.geom_mjid[g])] or f"g{int(m.geom_mjid[g])}") + "@" + m.body_names[int(m.geom_body[g])]
             if res:
                 proven.append([a, b])
                 print(f"  {env}: PROVEN separated  {name(a)} / {name(b)}: {why}", flush=True)
             elif res is None and why not in ("type", "free joint", "rigid") and "joints" not in why:
                 print(f"  {env}: undecided        {name(a)} / {name(b)}: {why}", flush=True)
-        print(f"{env}: {len(proven)} of {len(m.pair_geom)} candidate pairs proven never to violate the threshold ({time.time() - t0:.0f} s)", flush=True)
+        print(f"{env}: {len(proven)} (+ {len(proven_thr)} that may touch) of {len(m.pair_geom)} candidate pairs proven never to violate the threshold ({time.time() - t0:.0f} s)", flush=True)
         if not args.dry:
             path = scene_path(spec.scene)
             cm = CompiledModel.load(path)
             cm.meta["never_violating_pairs"] = proven
+            # pairs that may touch but provably stay above contact_threshold: pruned only by scenes whose threshold is <= this one
+            cm.meta["never_violating_pairs_thr"] = {"threshold": spec.contact_threshold, "pairs": proven_thr}
             cm.meta["never_violating_pairs_note"] = ("tools/prove_separated_pairs.py: branch-and-bound Lipschitz proof over the joint ranges, margin "
                                                      f"{MARGIN} m; valid for joint values inside their ranges")
             cm.save(path)

@@ -168,7 +168,7 @@ def test_lift_can_mesh_pairs_decide(kernel, oracle_mod):
     from mopa_rl_amd.batch import BatchPlanner
     from mopa_rl_amd.mjcf import GEOM_MESH
     env = "SawyerLiftObstacle-v0"
-    pi, sc, orc = _mk(env, oracle_mod, kernel)
+    pi, sc, orc = _mk(env, oracle_mod, kernel, prune_pairs=False)      # (per-pair distances below: the full candidate list)
     m = pi.model
     bp = BatchPlanner(sc)
     E, S = 24, 128

@@ -5,7 +5,7 @@
 
 A "step" is one pass of the hot path over one batch of synthetic planner
 states: E envs x S states/env per GPU, SawyerPushObstacle-v0 (7-DoF arm, 27
-collidable primitives, 241 non-ignored candidate pairs).  Inputs are resident
+collidable primitives, 241 non-ignored candidate pairs of which 86 are proven unreachable at scene compile time and dropped).  Inputs are resident
 in HBM before the timed region.  One process per GPU; envs are sharded across
 ranks (weak scaling: per-GPU work is fixed) and every step ends with an RCCL
 all-gather of the uint8 validity masks, the only exchange the path has.
@@ -382,6 +382,10 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         over.setdefault("planner_streams", 2)
     if use_graphs:
         over["use_graphs"] = 1          # the fixed-shape halves of a call replayed from HIP graphs (rollout.py)
+        # (with replayed calls the host submits faster than three 64-workgroup planner streams drain: 2 x 128 measured steadier,
+        #  tools/rollout_knobs3.sh)
+        over.setdefault("planner_streams", 2)
+        over.setdefault("planner_workgroups", 128)
     if use_ik:
         over["use_ik_target"] = 1       # MoPA + IK action space (BASELINE config 5): Cartesian displacement + rotation quaternion
     ro = BatchMoPARollout(env, RolloutConfig(async_planner=async_planner, **over))

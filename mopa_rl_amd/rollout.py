@@ -389,12 +389,14 @@ class BatchMoPARollout:
         import contextlib
         torch = _torch()
         cfg = self.cfg
+        just_enqueued = False
         if job["stage"] == "rrt":
             if job["event"] is not None:
                 if wait:
                     job["event"].synchronize()
                 elif not job["event"].query():
                     return False
+            just_enqueued = True
             ctx = torch.cuda.stream(job["stream"]) if job["stream"] is not None else contextlib.nullcontext()
             with ctx:
                 from .batch import postprocess_paths
@@ -412,9 +414,11 @@ class BatchMoPARollout:
                     job["event"] = torch.cuda.Event()
                     job["event"].record(job["stream"])
             job["stage"] = "device"
-        # stage "device": the launches above (and the sub-job, if any) have to be finished
+        # stage "device": the launches above (and the sub-job, if any) have to be finished.  Right after the post-processing
+        # was enqueued what is left of it is one small assemble launch (its read-backs already waited for the rest): waiting
+        # those microseconds out here saves the job -- and the envs that wait for it -- a whole call
         if job["event"] is not None:
-            if wait:
+            if wait or (just_enqueued and "sub" not in job):
                 job["event"].synchronize()
             elif not job["event"].query():
                 return False

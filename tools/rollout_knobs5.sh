@@ -1,0 +1,8 @@
+for fi in 100 200 300 600; do
+    out=""
+    for r in 1 2; do
+      v=$(env ONLY_EAGER=1 MOPA_BENCH_ROLLOUT=planner_first_iters=$fi python tools/rollout_graphs_ab.py 4096 200 2>&1 | grep "^graphs" | sed -e "s/.*agent_steps_per_s': \([0-9.]*\).*envs_stepping_per_call': \([0-9.]*\).*/\1 \2/" | awk '{printf "%d(%d)", $1, $2}')
+      out="$out $v"
+    done
+    echo "first_iters=$fi:$out"
+done

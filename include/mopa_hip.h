@@ -113,6 +113,9 @@ typedef struct MopaSceneDesc {
     double resolution;                 /* validity checking resolution; the reference hard-codes 0.005 (:87) */
     uint64_t seed;                     /* KinematicPlanner.cpp:95 */
     int32_t device;                    /* HIP device ordinal, -1 = current */
+    const double *pair_cull_radius;    /* nullable, [model.npair]: > 0 = the pair can only reach contact_threshold while its two geom
+                                          centres are within this distance (a compile-time bound, tools/prove_separated_pairs.py);
+                                          the FP32 broad phase then culls with min(bounding-sphere sum, this).  0 = no bound */
 } MopaSceneDesc;
 
 typedef struct MopaScene MopaScene;

@@ -55,7 +55,7 @@ class MopaSceneDesc(C.Structure):
     _fields_ = [
         ("model", MopaModel), ("n_passive", C.c_int32), ("passive_qpos_idx", _ip), ("n_ignored", C.c_int32),
         ("ignored_pairs", _ip), ("contact_threshold", C.c_double), ("range", C.c_double), ("resolution", C.c_double),
-        ("seed", C.c_uint64), ("device", C.c_int32),
+        ("seed", C.c_uint64), ("device", C.c_int32), ("pair_cull_radius", _dp),
     ]
 
 
@@ -243,6 +243,16 @@ class Scene:
         pas = np.asarray(list(passive_joint_idx), dtype=np.int32)
         desc = MopaSceneDesc()
         desc.model = model_struct(m, keep, pair_geom=pairs)
+        # per-pair bound on the centre distance at which the pair can reach the threshold (same proof machinery): the FP32
+        # broad phase culls with it instead of the bounding-sphere sum (closed gripper fingers: 9 mm instead of 10 cm)
+        cr = meta.get("pair_cull_radius") or {}
+        self.npair_tightened = 0
+        if prune_pairs and cr and float(contact_threshold) <= float(cr.get("threshold", -np.inf)):
+            rad = {(int(a), int(b)): float(r) for a, b, r in cr.get("pairs") or []}
+            arr = np.array([rad.get((int(a), int(b)), rad.get((int(b), int(a)), 0.0)) for a, b in pairs], dtype=np.float64)
+            if (arr > 0).any():
+                self.npair_tightened = int((arr > 0).sum())
+                desc.pair_cull_radius = d(arr)
         desc.n_passive = len(pas)
         desc.passive_qpos_idx = i(pas)
         desc.n_ignored = len(ign)

@@ -763,6 +763,112 @@ MOPA_HD int pair_code(int t1, int t2) {
     return -1;
 }
 
+// Second pre-test before the portal refinement, for what the enclosing capsules let through: separating axes that are exact
+// for these shapes -- the axis of shape 1 (capsule or cylinder) and the axis / the three face normals of shape 2 (cylinder /
+// box).  Extent of a cylinder (r, h) with axis a along a unit direction n: h |a.n| + r sqrt(1 - (a.n)^2); of a capsule:
+// h |a.n| + r; of a box along its own normal i: s_i, along n: sum |u_i.n| s_i.  The wrist and gripper discs (radius 5.5 /
+// 3.5 cm, half height 2.5 / 1.5 cm) hover over the table inside their enclosing capsules -- which reach a radius, not a half
+// height, beyond the flat faces -- for most of a Push / Assembly episode.  A gap of more than 1e-9 along any of the axes =>
+// the shapes are disjoint => what MPR reports for disjoint shapes (same rule, same margin as the capsule pre-test; the
+// oracle has the identical function and a switch that turns it off: tests/test_oracle_primitives.py).
+MOPA_HD bool convex_axes_separate(const double *A, int ta, const double *B, int tb) {
+    const V3 d = sub3(ld3(B + GO_POS), ld3(A + GO_POS));
+    const V3 a = col3(A + GO_MAT, 2);
+    const double ra = A[GO_SIZE], ha = A[GO_SIZE + 1];
+    const bool cap = ta == G_CAPSULE;
+    const double ea = cap ? ha + ra : ha;                 // shape 1 along its own axis
+    const double da = fabs(dot3(d, a));
+    if (tb == G_BOX) {
+        const V3 s = ld3(B + GO_SIZE);
+        const V3 u0 = col3(B + GO_MAT, 0), u1 = col3(B + GO_MAT, 1), u2 = col3(B + GO_MAT, 2);
+        const double c0 = dot3(a, u0), c1 = dot3(a, u1), c2 = dot3(a, u2);
+        if (da - ea - fma(fabs(c2), s.z, fma(fabs(c1), s.y, fabs(c0) * s.x)) > 1e-9) return true;
+        const double n0 = fma(-c0, c0, 1.0), n1 = fma(-c1, c1, 1.0), n2 = fma(-c2, c2, 1.0);
+        const double w0 = cap ? ra : ra * sqrt(n0 > 0.0 ? n0 : 0.0);
+        const double w1 = cap ? ra : ra * sqrt(n1 > 0.0 ? n1 : 0.0);
+        const double w2 = cap ? ra : ra * sqrt(n2 > 0.0 ? n2 : 0.0);
+        if (fabs(dot3(d, u0)) - s.x - fma(ha, fabs(c0), w0) > 1e-9) return true;
+        if (fabs(dot3(d, u1)) - s.y - fma(ha, fabs(c1), w1) > 1e-9) return true;
+        if (fabs(dot3(d, u2)) - s.z - fma(ha, fabs(c2), w2) > 1e-9) return true;
+        return false;
+    }
+    const V3 b = col3(B + GO_MAT, 2);                     // shape 2 is a cylinder
+    const double rb = B[GO_SIZE], hb = B[GO_SIZE + 1];
+    const double c = dot3(a, b), n = fma(-c, c, 1.0), sn = sqrt(n > 0.0 ? n : 0.0), ac = fabs(c);
+    if (da - ea - fma(hb, ac, rb * sn) > 1e-9) return true;
+    if (fabs(dot3(d, b)) - hb - fma(ha, ac, cap ? ra : ra * sn) > 1e-9) return true;
+    return false;
+}
+
+// Verdict-only shortcut on the other side: the shapes overlap DEEPER than `delta`, so the portal refinement -- whose depth is
+// never less than the true penetration depth minus its 1e-6 tolerance -- would report a distance <= -delta + 1e-6.  Shown by a
+// witness: a point whose delta-ball lies inside both shapes, i.e. a common point of the two shapes shrunk by delta (cylinder
+// (r, h) -> (r - delta, h - delta); capsule -> radius r - delta; box -> half extents s - delta).  Two candidates: the point of
+// shape 2's core closest to shape 1's centre, and the point of shape 1's core closest to shape 2's centre.  The wrist disc
+// pushed through a bin wall -- the planner's most frequent reason to enter the refinement -- is decided here.  Callers pass
+// delta = max(-threshold, 0) + 1e-4 and use the result only for the verdict (the distance itself still needs the refinement).
+MOPA_HD bool convex_overlap_deeper_than(const double *A, int ta, const double *B, int tb, double delta) {
+    const V3 ca = ld3(A + GO_POS), cb = ld3(B + GO_POS);
+    const V3 a = col3(A + GO_MAT, 2);
+    const bool cap = ta == G_CAPSULE;
+    const double Ra = A[GO_SIZE] - delta, Ha = cap ? A[GO_SIZE + 1] : A[GO_SIZE + 1] - delta;
+    if (!(Ra > 0.0) || !(Ha > 0.0)) return false;
+    const V3 dab = sub3(cb, ca);                          // centre of 2 seen from centre of 1
+    // P2: the point of core 1 closest to centre 2 (for a capsule core: the point of its segment; radius left as slack)
+    const double ta2 = dot3(dab, a);
+    const double tc = ta2 > Ha ? Ha : (ta2 < -Ha ? -Ha : ta2);
+    V3 w{fma(-ta2, a.x, dab.x), fma(-ta2, a.y, dab.y), fma(-ta2, a.z, dab.z)};      // radial part of dab
+    const double rho2 = dot3(w, w);
+    if (!cap && rho2 > Ra * Ra) { const double k = Ra / sqrt(rho2); w = V3{w.x * k, w.y * k, w.z * k}; }
+    if (cap) w = V3{0.0, 0.0, 0.0};
+    const V3 p2{fma(tc, a.x, w.x), fma(tc, a.y, w.y), fma(tc, a.z, w.z)};          // relative to ca
+    if (tb == G_BOX) {
+        const V3 s{B[GO_SIZE] - delta, B[GO_SIZE + 1] - delta, B[GO_SIZE + 2] - delta};
+        if (!(s.x > 0.0) || !(s.y > 0.0) || !(s.z > 0.0)) return false;
+        // is P2 in the shrunk box?
+        const V3 l2 = matT_vec(B + GO_MAT, sub3(p2, dab));
+        if (fabs(l2.x) <= s.x && fabs(l2.y) <= s.y && fabs(l2.z) <= s.z) return true;
+        // P1: the point of the shrunk box closest to centre 1; is it in core 1?
+        const V3 l1 = matT_vec(B + GO_MAT, V3{-dab.x, -dab.y, -dab.z});
+        const V3 c1{l1.x > s.x ? s.x : (l1.x < -s.x ? -s.x : l1.x), l1.y > s.y ? s.y : (l1.y < -s.y ? -s.y : l1.y),
+                    l1.z > s.z ? s.z : (l1.z < -s.z ? -s.z : l1.z)};
+        const V3 p1 = add3(dab, mat_vec(B + GO_MAT, c1));                           // relative to ca
+        const double t1 = dot3(p1, a);
+        const double tq = cap ? (t1 > Ha ? Ha : (t1 < -Ha ? -Ha : t1)) : t1;
+        const V3 r1{fma(-tq, a.x, p1.x), fma(-tq, a.y, p1.y), fma(-tq, a.z, p1.z)};
+        return fabs(t1) <= (cap ? 1.0e30 : Ha) && dot3(r1, r1) <= Ra * Ra;
+    }
+    const V3 b = col3(B + GO_MAT, 2);                     // shape 2 is a cylinder
+    const double Rb = B[GO_SIZE] - delta, Hb = B[GO_SIZE + 1] - delta;
+    if (!(Rb > 0.0) || !(Hb > 0.0)) return false;
+    {   // is P2 in core 2?
+        const V3 q = sub3(p2, dab);
+        const double tq = dot3(q, b);
+        const V3 r{fma(-tq, b.x, q.x), fma(-tq, b.y, q.y), fma(-tq, b.z, q.z)};
+        if (fabs(tq) <= Hb && dot3(r, r) <= Rb * Rb) return true;
+    }
+    // P1: the point of core 2 closest to centre 1; is it in core 1?
+    const double tb1 = -dot3(dab, b);
+    const double tbc = tb1 > Hb ? Hb : (tb1 < -Hb ? -Hb : tb1);
+    V3 wb{fma(-tb1, b.x, -dab.x), fma(-tb1, b.y, -dab.y), fma(-tb1, b.z, -dab.z)};
+    const double rb2 = dot3(wb, wb);
+    if (rb2 > Rb * Rb) { const double k = Rb / sqrt(rb2); wb = V3{wb.x * k, wb.y * k, wb.z * k}; }
+    const V3 p1{dab.x + fma(tbc, b.x, wb.x), dab.y + fma(tbc, b.y, wb.y), dab.z + fma(tbc, b.z, wb.z)};
+    const double t1 = dot3(p1, a);
+    const double tq = cap ? (t1 > Ha ? Ha : (t1 < -Ha ? -Ha : t1)) : t1;
+    const V3 r1{fma(-tq, a.x, p1.x), fma(-tq, a.y, p1.y), fma(-tq, a.z, p1.z)};
+    return fabs(t1) <= (cap ? 1.0e30 : Ha) && dot3(r1, r1) <= Ra * Ra;
+}
+MOPA_HD double convex_deep_delta(double thr) { return (thr < 0.0 ? -thr : 0.0) + 1e-4; }
+// verdict of a PC_CONVEX pair (distance <= thr) without the distance: pre-tests on both sides, then the refinement
+MOPA_HD bool convex_pair_bad(const double *A, int ta, const double *B, int tb, double thr) {
+    const double pre = (tb == G_BOX) ? d_capsule_box(A, B) : d_capsule_capsule(A, B);
+    if (pre > 1e-9) return false;
+    if (convex_axes_separate(A, ta, B, tb)) return false;
+    if (convex_overlap_deeper_than(A, ta, B, tb, convex_deep_delta(thr))) return true;
+    return d_convex<false>(A, ta, B, tb) <= thr;
+}
+
 // `aux`: the scene's double blob (mesh hull vertices live in it); only the *_MESH codes read it, and only the
 // MESH = true instantiation contains them: scenes without a collidable mesh keep running exactly the code (and
 // register budget) they had before mesh support existed.
@@ -787,6 +893,7 @@ MOPA_HD double geom_dist(int code, const double *A, int ta, const double *B, int
             // Enclosures apart by more than 1e-9  =>  the shapes are disjoint  =>  what MPR would report.
             const double pre = (tb == G_BOX) ? d_capsule_box(A, B) : d_capsule_capsule(A, B);
             if (pre > 1e-9) return kFar;
+            if (convex_axes_separate(A, ta, B, tb)) return kFar;
             return d_convex<false>(A, ta, B, tb);
         }
         case PC_PLANE_MESH: return MESH ? d_plane_mesh<G>(A, B, aux) : kFar;

@@ -270,63 +270,69 @@ MOPA_D bool pair_culled(const SceneHdr &h, const LdsView &v, int g1, int g2, con
 // as a parent-first sweep over the body tree) and writes the posed geom.
 // fk_one_geom: the per-lane work for moving geom `lane` of the state in v.qbuf -> v.grec.
 MOPA_D void fk_one_geom(const SceneHdr &h, const LdsView &v, int lane) {
-    {
-        const double *D = v.dbl;
-        const int *I = v.ints;
-        int g = I[h.o_mg_geom + lane];
-        int b = I[h.o_g_mb + g];
-        int cadr = I[h.o_chain_adr + b], clen = I[h.o_chain_len + b];
-        V3 pos{0.0, 0.0, 0.0};
-        Q4 quat{1.0, 0.0, 0.0, 0.0};
-        double mat[9];
-        for (int k = 0; k < clen; k++) {
-            int body = I[h.o_chain_items + cadr + k];
-            int ja = I[h.o_mb_jntadr + body], jn = I[h.o_mb_jntnum + body];
-            if (jn == 1 && I[h.o_mj_type + ja] == J_FREE) {
-                const double *qp = v.qbuf + I[h.o_mj_qsrc + ja];
-                pos = V3{qp[0], qp[1], qp[2]};
-                quat = quat_normalize(Q4{qp[3], qp[4], qp[5], qp[6]});
+    // Reads the PACKED per-body records (ints o_mbr: jn, jntadr, -, static-frame id, -, -, -, joint-0 word; doubles o_mbd:
+    // pos[3] quat[4] axis[3] jpos[3] ref) -- two levels of dependent LDS reads per body (chain item -> record -> joint value)
+    // where the separate tables needed six; the arithmetic and its order are unchanged.
+    const double *D = v.dbl;
+    const int *I = v.ints;
+    const int g = I[h.o_mg_geom + lane];
+    const int b = I[h.o_g_mb + g];
+    const int cadr = I[h.o_chain_adr + b], clen = I[h.o_chain_len + b];
+    V3 pos{0.0, 0.0, 0.0};
+    Q4 quat{1.0, 0.0, 0.0, 0.0};
+    double mat[9];
+    for (int k = 0; k < clen; k++) {
+        const int body = I[h.o_chain_items + cadr + k];
+        const int *r = I + h.o_mbr + 8 * body;
+        const int jn = r[0], ja = r[1], w7 = r[7];
+        const double *bd = D + h.o_mbd + 16 * body;
+        const int jt0 = w7 & 0x7f, qsrc0 = w7 >> 8;
+        if (jn == 1 && jt0 == J_FREE) {
+            const double *qp = v.qbuf + qsrc0;
+            pos = V3{qp[0], qp[1], qp[2]};
+            quat = quat_normalize(Q4{qp[3], qp[4], qp[5], qp[6]});
+        } else {
+            V3 ppos;
+            Q4 pquat;
+            if (k == 0) {
+                const int sf = r[3];
+                ppos = ld3(D + h.o_sf_pos + 3 * sf);
+                const double *sq = D + h.o_sf_quat + 4 * sf;
+                pquat = Q4{sq[0], sq[1], sq[2], sq[3]};
+                const double *sm = D + h.o_sf_mat + 9 * sf;
+#pragma unroll
+                for (int i = 0; i < 9; i++) mat[i] = sm[i];
             } else {
-                V3 ppos;
-                Q4 pquat;
-                if (k == 0) {
-                    int sf = -(I[h.o_mb_parent + body] + 1);
-                    ppos = ld3(D + h.o_sf_pos + 3 * sf);
-                    const double *sq = D + h.o_sf_quat + 4 * sf;
-                    pquat = Q4{sq[0], sq[1], sq[2], sq[3]};
-                    const double *sm = D + h.o_sf_mat + 9 * sf;
-#pragma unroll
-                    for (int i = 0; i < 9; i++) mat[i] = sm[i];
-                } else {
-                    ppos = pos;
-                    pquat = quat;
-                }
-                V3 vv = mat_vec(mat, ld3(D + h.o_mb_pos + 3 * body));
-                pos = add3(ppos, vv);
-                const double *bq = D + h.o_mb_quat + 4 * body;
-                quat = quat_mul(pquat, Q4{bq[0], bq[1], bq[2], bq[3]});
-                for (int j = ja; j < ja + jn; j++) {
-                    V3 ax = ld3(D + h.o_mj_axis + 3 * j), jp = ld3(D + h.o_mj_pos + 3 * j);
-                    double dq = v.qbuf[I[h.o_mj_qsrc + j]] - D[h.o_mj_ref + j];
-                    apply_joint_sc(I[h.o_mj_type + j], ax, jp, is_zero3(jp), dq, v.sc[2 * j], v.sc[2 * j + 1], pos, quat);
-                }
-                quat = quat_normalize(quat);
+                ppos = pos;
+                pquat = quat;
             }
-            quat2mat(mat, quat);
+            pos = add3(ppos, mat_vec(mat, ld3(bd)));
+            quat = quat_mul(pquat, Q4{bd[3], bd[4], bd[5], bd[6]});
+            if (jn > 0) {
+                const double dq = v.qbuf[qsrc0] - bd[13];
+                apply_joint_sc(jt0, ld3(bd + 7), ld3(bd + 10), (w7 & 0x80) != 0, dq, v.sc[2 * ja], v.sc[2 * ja + 1], pos, quat);
+            }
+            for (int j = ja + 1; j < ja + jn; j++) {       // bodies with more than one joint: the separate joint tables
+                V3 ax = ld3(D + h.o_mj_axis + 3 * j), jp = ld3(D + h.o_mj_pos + 3 * j);
+                double dq = v.qbuf[I[h.o_mj_qsrc + j]] - D[h.o_mj_ref + j];
+                apply_joint_sc(I[h.o_mj_type + j], ax, jp, is_zero3(jp), dq, v.sc[2 * j], v.sc[2 * j + 1], pos, quat);
+            }
+            quat = quat_normalize(quat);
         }
-        double *rec = v.grec + lane * kGeomStride;
-        V3 gp = add3(pos, mat_vec(mat, ld3(D + h.o_g_lpos + 3 * g)));
-        const double *lq = D + h.o_g_lquat + 4 * g;
-        Q4 gq = quat_mul(quat, Q4{lq[0], lq[1], lq[2], lq[3]});
-        double gm[9];
-        quat2mat(gm, gq);
-        st3(rec + GO_POS, gp);
-#pragma unroll
-        for (int i = 0; i < 9; i++) rec[GO_MAT + i] = gm[i];
-        // size is constant: copied from the shared record
-        const double *srec = D + h.o_g_rec + g * kGeomStride;
-        rec[GO_SIZE] = srec[GO_SIZE]; rec[GO_SIZE + 1] = srec[GO_SIZE + 1]; rec[GO_SIZE + 2] = srec[GO_SIZE + 2];
+        quat2mat(mat, quat);
     }
+    double *rec = v.grec + lane * kGeomStride;
+    const double *gd = D + h.o_mgd + 8 * lane;               // lpos[3] lquat[4] rbound of moving geom `lane`
+    V3 gp = add3(pos, mat_vec(mat, ld3(gd)));
+    Q4 gq = quat_mul(quat, Q4{gd[3], gd[4], gd[5], gd[6]});
+    double gm[9];
+    quat2mat(gm, gq);
+    st3(rec + GO_POS, gp);
+#pragma unroll
+    for (int i = 0; i < 9; i++) rec[GO_MAT + i] = gm[i];
+    // size is constant: copied from the shared record
+    const double *srec = D + h.o_g_rec + g * kGeomStride;
+    rec[GO_SIZE] = srec[GO_SIZE]; rec[GO_SIZE + 1] = srec[GO_SIZE + 1]; rec[GO_SIZE + 2] = srec[GO_SIZE + 2];
 }
 MOPA_D void wave_fk(const SceneHdr &h, const LdsView &v, int lane) {
     if (lane < h.nmg) fk_one_geom(h, v, lane);
@@ -367,9 +373,13 @@ MOPA_D bool wave_collide(const SceneHdr &h, const LdsView &v, int lane, double &
             int pk = I[h.o_pairs + v.wl[i]];
             int g1 = pk & 0xff, g2 = (pk >> 8) & 0xff, code = (pk >> 16) & 0xff;
             const double *A = geom_rec(h, v, g1), *B = geom_rec(h, v, g2);
-            double d = geom_dist<MESH>(code, A, I[h.o_g_type + g1], B, I[h.o_g_type + g2], v.dbl);
-            if (d < md) md = d;
-            if (d <= h.thr) bad = true;
+            if (!WANT_MD && code == PC_CONVEX) {       // verdict only: the deep-overlap shortcut may stand in for the refinement
+                if (convex_pair_bad(A, I[h.o_g_type + g1], B, I[h.o_g_type + g2], h.thr)) bad = true;
+            } else {
+                double d = geom_dist<MESH>(code, A, I[h.o_g_type + g1], B, I[h.o_g_type + g2], v.dbl);
+                if (d < md) md = d;
+                if (d <= h.thr) bad = true;
+            }
         }
         if (!WANT_MD && wave_any(bad)) break;
     }
@@ -406,6 +416,14 @@ MOPA_D void wave_load_state(const SceneHdr &h, const LdsView &v, int lane, const
 // K1: state validity, one wave per state
 // ---------------------------------------------------------------------------
 template <bool WANT_MD, bool MESH>
+// Kernels that call the planner's non-inlined validity routines (K2 motion checks, K3, pull-back).  MOPA_PLAN_WAVES=2 (A/B
+// builds only) caps their register budget for two waves per SIMD; the attribute is kernel-only and propagates to the routines
+// only when every caller carries it.
+#ifdef MOPA_PLAN_WAVES
+#define MOPA_PLAN_KERNEL __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MOPA_PLAN_WAVES, MOPA_PLAN_WAVES)))
+#else
+#define MOPA_PLAN_KERNEL __global__ __launch_bounds__(kBlock)
+#endif
 __global__ __launch_bounds__(kBlock) void k_is_valid(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
                                                       const double *__restrict__ q_active, const double *__restrict__ qpos_env,
                                                       long long N, long long samples_per_env, unsigned char *__restrict__ valid,
@@ -459,7 +477,7 @@ MOPA_D int valid_segment_count(const SceneHdr &h, const LdsView &v, const double
 __device__ __noinline__ bool plan_state_valid_impl(const SceneHdr *hp, const double *dbl, const int *ints, double *grec,
                                                    double *qbuf, unsigned short *wl, int lane, const double *qa, const double *row);
 
-__global__ __launch_bounds__(kBlock) void k_check_motion(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
+MOPA_PLAN_KERNEL void k_check_motion(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
                                                          const double *__restrict__ qa_all, const double *__restrict__ qb_all,
                                                          const double *__restrict__ qpos_env, long long N, long long samples_per_env,
                                                          unsigned char *__restrict__ valid, int hdr_lds_off) {
@@ -887,7 +905,16 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
                     // arithmetic here = what the kernel would do per pair and state
                     const float rg = (float)g_rbound[mg_geom[mslot]] + kCullEps;
                     auto ff2i = [](float f) { int32_t i; std::memcpy(&i, &f, 4); return i; };
-                    const float rs = rg + (float)g_rbound[pg];
+                    float rs = rg + (float)g_rbound[pg];
+                    if (desc->pair_cull_radius) {
+                        // a proven bound on the centre distance at which this pair can reach the threshold at all
+                        const int own = mg_geom[mslot];
+                        for (int pp = 0; pp < m.npair; pp++) {
+                            const int a = m.pair_geom[2 * pp], b = m.pair_geom[2 * pp + 1];
+                            if (((a == own && b == pg) || (a == pg && b == own)) && desc->pair_cull_radius[pp] > 0.0)
+                                rs = std::min(rs, std::nextafter((float)desc->pair_cull_radius[pp], 1.0e30f) + kCullEps);
+                        }
+                    }
                     te[3] = ff2i(rs * rs);
                     int flags = w & 0x3fffff;    // gp_word already carries the slot in bits 14..21
                     if (!pmov) {

@@ -1004,9 +1004,48 @@ static double d_convex(const Geom *A, const Geom *B) {
 /* {capsule,cylinder}-cylinder and cylinder-box: closed-form pre-test on the enclosing capsules (a cylinder lies inside
  * the capsule of the same axis, radius and half length) before the portal refinement; enclosures apart by more
  * than 1e-9 => disjoint => what MPR reports for disjoint shapes.  Same rule in the kernels. */
+/* Second pre-test for what the enclosing capsules let through: separating axes that are exact for these shapes -- the axis
+ * of shape 1 (capsule or cylinder) and the axis / the three face normals of shape 2 (cylinder / box).  Extents along a unit
+ * direction n: cylinder h |a.n| + r sqrt(1 - (a.n)^2), capsule h |a.n| + r, box sum |u_i.n| s_i.  A gap of more than 1e-9
+ * => disjoint => ORC_FAR, which is what the portal refinement reports for disjoint shapes.  This is an accelerator, not part
+ * of [3P]: orc_set_convex_axes_pretest(0) turns it off, and tests/test_oracle_primitives.py checks that no distance changes. */
+static int g_convex_axes_pretest = 1;
+void orc_set_convex_axes_pretest(int on) { g_convex_axes_pretest = on; }
+static int convex_axes_separate(const Geom *A, const Geom *B) {
+    double d[3], a[3];
+    sub3(d, B->pos, A->pos);
+    col3(a, A->mat, 2);
+    const double ra = A->size[0], ha = A->size[1];
+    const int cap = A->type == G_CAPSULE;
+    const double ea = cap ? ha + ra : ha;
+    const double da = fabs(dot3(d, a));
+    if (B->type == G_BOX) {
+        const double *s = B->size;
+        double u0[3], u1[3], u2[3];
+        col3(u0, B->mat, 0); col3(u1, B->mat, 1); col3(u2, B->mat, 2);
+        const double c0 = dot3(a, u0), c1 = dot3(a, u1), c2 = dot3(a, u2);
+        if (da - ea - fma(fabs(c2), s[2], fma(fabs(c1), s[1], fabs(c0) * s[0])) > 1e-9) return 1;
+        const double n0 = fma(-c0, c0, 1.0), n1 = fma(-c1, c1, 1.0), n2 = fma(-c2, c2, 1.0);
+        const double w0 = cap ? ra : ra * sqrt(n0 > 0.0 ? n0 : 0.0);
+        const double w1 = cap ? ra : ra * sqrt(n1 > 0.0 ? n1 : 0.0);
+        const double w2 = cap ? ra : ra * sqrt(n2 > 0.0 ? n2 : 0.0);
+        if (fabs(dot3(d, u0)) - s[0] - fma(ha, fabs(c0), w0) > 1e-9) return 1;
+        if (fabs(dot3(d, u1)) - s[1] - fma(ha, fabs(c1), w1) > 1e-9) return 1;
+        if (fabs(dot3(d, u2)) - s[2] - fma(ha, fabs(c2), w2) > 1e-9) return 1;
+        return 0;
+    }
+    double b[3];
+    col3(b, B->mat, 2);
+    const double rb = B->size[0], hb = B->size[1];
+    const double c = dot3(a, b), n = fma(-c, c, 1.0), sn = sqrt(n > 0.0 ? n : 0.0), ac = fabs(c);
+    if (da - ea - fma(hb, ac, rb * sn) > 1e-9) return 1;
+    if (fabs(dot3(d, b)) - hb - fma(ha, ac, cap ? ra : ra * sn) > 1e-9) return 1;
+    return 0;
+}
 static double d_convex_cyl(const Geom *A, const Geom *B) {
     const double pre = (B->type == G_BOX) ? d_capsule_box(A, B) : d_capsule_capsule(A, B);
     if (pre > 1e-9) return ORC_FAR;
+    if (g_convex_axes_pretest && convex_axes_separate(A, B)) return ORC_FAR;
     return d_convex(A, B);
 }
 

@@ -57,6 +57,8 @@ void orc_fk(const OrcScene *s, const double *qpos, double *geom_xpos /*[ngeom,3]
 void orc_fk_bodies(const OrcScene *s, const double *qpos, double *xpos, double *xquat);
 
 /* signed distance of two posed primitives (types ordered t1<=t2) */
+/* the separating-axis pre-test of the cylinder classes (an accelerator, on by default): 0 = every such pair goes to MPR */
+void orc_set_convex_axes_pretest(int on);
 double orc_geom_dist(int t1, const double *size1, const double *pos1, const double *mat1,
                      int t2, const double *size2, const double *pos2, const double *mat2);
 

@@ -48,6 +48,8 @@ def lib():
         L.orc_num_active.restype = C.c_int
         L.orc_active_idx.argtypes = [C.c_void_p, _ip]
         L.orc_sincos.argtypes = [C.c_double, _dp, _dp]
+        L.orc_set_convex_axes_pretest.argtypes = [C.c_int]
+        L.orc_set_convex_axes_pretest.restype = None
         L.orc_fk.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.orc_fk_bodies.argtypes = [C.c_void_p, _dp, _dp, _dp]
         L.orc_geom_dist.restype = C.c_double
@@ -308,6 +310,11 @@ def sincos(x: float) -> Tuple[float, float]:
     s, c = C.c_double(), C.c_double()
     lib().orc_sincos(float(x), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+def set_convex_axes_pretest(on: bool) -> None:
+    """The cylinder classes' separating-axis pre-test (on by default; an accelerator that must never change a distance)."""
+    lib().orc_set_convex_axes_pretest(1 if on else 0)
 
 
 def geom_dist(t1, size1, pos1, mat1, t2, size2, pos2, mat2) -> float:

@@ -178,3 +178,58 @@ def test_rigid_motion_invariance(gd):
             assert d1 == FAR
         else:
             assert d1 == pytest.approx(d0, abs=5e-6 if (t1, t2) == (CYLINDER, BOX) else 1e-12)
+
+
+@pytest.mark.parametrize("t1,t2", [(CAPSULE, CYLINDER), (CYLINDER, CYLINDER), (CYLINDER, BOX)])
+def test_convex_axes_pretest_never_changes_a_distance(oracle_mod, gd, t1, t2):
+    """The separating-axis pre-test of the cylinder classes is an accelerator: with it switched off every such pair goes to
+    the portal refinement, and the distance (FAR or the penetration depth) must come out the same -- sampled where the
+    pre-test matters: flat discs and long posts a few millimetres to a few centimetres apart, and in contact."""
+    rng = np.random.default_rng(100 * t1 + t2)
+    n_culled, n_pen = 0, 0
+    try:
+        for k in range(3000):
+            flat = k % 2 == 0
+            s1 = np.array([rng.uniform(0.02, 0.06), rng.uniform(0.01, 0.03) if flat else rng.uniform(0.05, 0.4), 0.0])
+            s2 = (rng.uniform(0.01, 0.4, 3) if t2 == BOX else
+                  np.array([rng.uniform(0.02, 0.06), rng.uniform(0.01, 0.03) if k % 4 < 2 else rng.uniform(0.1, 0.4), 0.0]))
+            m1, m2 = rand_rot(rng), (rand_rot(rng) if k % 3 else I3)
+            p1 = rng.uniform(-0.2, 0.2, 3)
+            # place shape 1 near the surface of shape 2: along a random direction, at a distance around the sum of extents
+            u = rng.normal(size=3); u /= np.linalg.norm(u)
+            reach = np.linalg.norm(s2) if t2 == BOX else np.hypot(s2[0], s2[1])
+            p2 = p1 + u * rng.uniform(0.0, 1.2) * (reach + np.hypot(s1[0], s1[1]))
+            oracle_mod.set_convex_axes_pretest(True)
+            with_pre = gd(t1, s1, p1, m1, t2, s2, p2, m2)
+            oracle_mod.set_convex_axes_pretest(False)
+            without = gd(t1, s1, p1, m1, t2, s2, p2, m2)
+            assert with_pre == without, (k, with_pre, without)
+            n_pen += without != FAR
+            # how often the pre-test is what decides: enclosing capsules overlap, shapes disjoint
+            enc = gd(CAPSULE, s1, p1, m1, CAPSULE if t2 == CYLINDER else BOX, s2, p2, m2)
+            n_culled += (enc <= 1e-9) and without == FAR
+    finally:
+        oracle_mod.set_convex_axes_pretest(True)
+    assert n_pen > 100 and n_culled > 30
+
+
+def test_convex_axes_pretest_scene_distances_unchanged(oracle_mod):
+    """... and on the scenes: every pair distance of sampled states (near-contact and uniform) is the same with and without."""
+    from conftest import SUPPORTED_ENVS, sample_states
+    from mopa_rl_amd.scene import planner_inputs
+    try:
+        for env in SUPPORTED_ENVS:
+            pi = planner_inputs(env)
+            orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+            for mode in ("near", "uniform"):
+                qa, rows = sample_states(pi, 300, 3, mode)
+                for i in range(len(qa)):
+                    q = rows[0].copy()
+                    q[pi.ref_joint_pos_indexes] = qa[i]
+                    oracle_mod.set_convex_axes_pretest(True)
+                    a = orc.pair_dist(q)
+                    oracle_mod.set_convex_axes_pretest(False)
+                    b = orc.pair_dist(q)
+                    assert np.array_equal(a, b), (env, mode, i)
+    finally:
+        oracle_mod.set_convex_axes_pretest(True)

@@ -6,6 +6,11 @@ import pytest
 from conftest import SUPPORTED_ENVS, sample_states
 
 
+def _rbound(t, s):
+    """bounding radius about the geom's origin (mjcf.GEOM_*: 2 sphere, 3 capsule, 5 cylinder, 6 box)"""
+    return {2: s[0], 3: s[0] + s[1], 5: float(np.hypot(s[0], s[1])), 6: float(np.linalg.norm(s))}[t]
+
+
 @pytest.mark.parametrize("env", SUPPORTED_ENVS)
 def test_committed_never_violating_pairs_hold_on_samples(env, oracle_mod):
     from mopa_rl_amd.scene import planner_inputs
@@ -33,3 +38,42 @@ def test_committed_never_violating_pairs_hold_on_samples(env, oracle_mod):
                     q[j] = rng.uniform(*m.jnt_range[jid[0]])
             lo = min(lo, orc.pair_dist(q)[rows_of].min())
     assert lo > 1e-4
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_committed_cull_radii_hold_on_samples(env, oracle_mod):
+    """`pair_cull_radius` (the tightened broad-phase radius of a pair): whenever the oracle sees the pair at or below the
+    contact threshold, the two geom centres are no further apart than the committed radius -- so culling the pair beyond
+    it never changes a verdict.  Sampled where it matters: the joints between the two geoms swept over their ranges."""
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(env)
+    m = pi.model
+    cr = m.meta.get("pair_cull_radius")
+    assert cr is not None and cr["threshold"] <= pi.spec.contact_threshold + 1e-12
+    if not cr["pairs"]:
+        return                                                 # (Lift: no pair gains 10 % over its bounding spheres)
+    idx = {(int(a), int(b)): k for k, (a, b) in enumerate(m.pair_geom)}
+    orc = oracle_mod.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    rows_of = np.array([idx[(int(a), int(b))] for a, b, _ in cr["pairs"]])
+    ga = np.array([int(a) for a, _, _ in cr["pairs"]])
+    gb = np.array([int(b) for _, b, _ in cr["pairs"]])
+    rad = np.array([float(r) for _, _, r in cr["pairs"]])
+    rb = lambda gs: np.array([_rbound(int(m.geom_type[g]), m.geom_size[g]) for g in gs])
+    assert np.all(rad < rb(ga) + rb(gb))                       # tightened means tighter than the bounding spheres
+    rng = np.random.default_rng(1)
+    lim = np.array([m.jnt_range[k] if m.jnt_limited[k] else (-np.pi, np.pi) for k in range(len(m.jnt_names))])
+    adr = np.array([int(a) for a in m.jnt_qposadr])
+    hs = [k for k in range(len(m.jnt_names)) if int(m.jnt_type[k]) in (2, 3)]
+    qa, rows = sample_states(pi, 4, 3, "uniform")
+    hits = 0
+    for i in range(3000):
+        q = rows[0].copy()
+        for k in hs:
+            q[adr[k]] = rng.uniform(*lim[k])
+        d = orc.pair_dist(q)[rows_of]
+        gp, _ = orc.fk(q)
+        cd = np.linalg.norm(gp[ga] - gp[gb], axis=1)
+        viol = d <= pi.spec.contact_threshold
+        hits += int(viol.sum())
+        assert np.all(cd[viol] <= rad[viol]), (env, i)
+    assert hits > 0                                            # the property was exercised

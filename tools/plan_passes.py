@@ -21,7 +21,7 @@ for e in f: print(e, chk[e], npass[e], nst[e], n0[e], n1[e])
 import ctypes
 lib = _lib.lib()
 if hasattr(lib, "mopa_debug_plan_times"):
-    buf = (ctypes.c_ulonglong * 40)()
+    buf = (ctypes.c_ulonglong * 48)()
     lib.mopa_debug_plan_times(buf, 1)
     fi = torch.nonzero(torch.tensor(st != 0)).flatten().to(start.device)
     bp.plan(start[fi].contiguous(), goal[fi].contiguous(), max_iters=2000, max_nodes=4096, max_path=256, seed=7, env_ids=fi.contiguous())
@@ -29,8 +29,23 @@ if hasattr(lib, "mopa_debug_plan_times"):
     t = list(buf); n = len(fi)
     print("failing envs only: per env, 100 MHz ticks -> us: pose+fk %.0f broad %.0f narrow %.0f | survivors/pass %.1f states/pass %.2f passes %d" % (
         t[0] / n / 100, t[1] / n / 100, t[2] / n / 100, t[3] / max(t[4], 1), t[5] / max(t[4], 1), t[4] / n))
+    if t[40]:
+        print("  narrow phase split (cumulative from the start of the collision sweep): after broad %.0f, after closed forms %.0f, after refinement %.0f us per env" % (t[1] / n / 100, t[40] / n / 100, t[2] / n / 100))
     print("  own nearest-neighbour %.0f us, speculation (memo lookup + fused NN + steering) %.0f us per env" % (t[6] / n / 100, t[7] / n / 100))
     print("  speculation split: fused NN %.0f us, two steer+push %.0f us, connect-chain %.0f us per env" % (t[22] / n / 100, t[23] / n / 100, t[38] / n / 100))
     names = "PLANE_SPHERE PLANE_CAPSULE PLANE_CYLINDER PLANE_BOX SPHERE_SPHERE SPHERE_CAPSULE SPHERE_CYLINDER SPHERE_BOX CAPSULE_CAPSULE CAPSULE_BOX BOX_BOX CONVEX PLANE_MESH CONVEX_MESH".split()
     for k, nm in enumerate(names):
         if t[24 + k]: print("  class %-16s rounds/pass %.2f  us/round %.2f  us/pass %.2f" % (nm, t[24 + k] / t[4], t[8 + k] / t[24 + k] / 100, t[8 + k] / t[4] / 100))
+
+if hasattr(lib, "mopa_debug_plan_mpr_pairs"):
+    pb = (ctypes.c_uint * 8192)()
+    lib.mopa_debug_plan_mpr_pairs(pb, 1)
+    c = np.array(list(pb)).reshape(2, 64, 64)
+    m = pi.model
+    print("  portal refinement entries per pass %.2f; by pair:" % (c.sum() / max(t[4], 1)))
+    nm = lambda g: "g%d(%s)@%s" % (g, ["plane", "", "sphere", "capsule", "", "cylinder", "box", "mesh"][int(m.geom_type[g])], m.body_names[int(m.geom_body[g])])
+    both = c[0] + c[1]
+    for k in np.argsort(-both.ravel())[:16]:
+        g1, g2 = divmod(int(k), 64)
+        if both[g1, g2] == 0: break
+        print("   %-34s %-34s disjoint %.3f  penetrating %.3f per pass" % (nm(g1), nm(g2), c[0, g1, g2] / t[4], c[1, g1, g2] / t[4]))

@@ -68,6 +68,80 @@ def rbound(t, s):
     return {GEOM_SPHERE: s[0], GEOM_CAPSULE: s[0] + s[1], GEOM_CYLINDER: float(np.hypot(s[0], s[1])), GEOM_BOX: float(np.linalg.norm(s))}[t]
 
 
+def cull_radius(m, orc, q0, a, b, max_evals, floor, leaf=5e-4):
+    """The largest distance the two geoms' CENTRES can have in any configuration in which the pair (possibly) violates
+    `floor`: a pair whose centres are further apart than that is separated, whatever the bounding spheres say (the closed
+    gripper fingers: bounding spheres of 5 cm each, touching only when their centres are 8 mm apart).  Same branch and
+    bound: boxes proven violation-free are dropped, the others are split down to `leaf` metres of reach and contribute
+    |c_a - c_b|(q_c) + sum_j rho_j w_j (the centres move no further than that inside the box).  Returns (radius, evals) or
+    None."""
+    setup = pair_setup(m, a, b)
+    if setup is None:
+        return None
+    joints, (t1, s1), (t2, s2), ia, ib = setup
+    adr = [j[0] for j in joints]
+    rho = np.array([j[3] for j in joints])
+    stack = [(np.array([(j[1] + j[2]) / 2 for j in joints]), np.array([(j[2] - j[1]) / 2 for j in joints]))]
+    evals, radius = 0, 0.0
+    q = q0.copy()
+    while stack:
+        c, w = stack.pop()
+        q[adr] = c
+        gp, gm = orc.fk(q)
+        d = O.geom_dist(t1, s1, gp[ia], gm[ia], t2, s2, gp[ib], gm[ib])
+        evals += 1
+        slack = float(rho @ w)
+        if d - slack > floor:
+            continue
+        if float((rho * w).max()) <= leaf or evals > max_evals:
+            radius = max(radius, float(np.linalg.norm(gp[ia] - gp[ib])) + slack)
+            continue
+        k = int(np.argmax(rho * w))
+        w2 = w.copy()
+        w2[k] /= 2
+        for sgn in (-1, 1):
+            c2 = c.copy()
+            c2[k] += sgn * w2[k]
+            stack.append((c2, w2))
+    return radius, evals
+
+
+def pair_setup(m, a, b):
+    """(joints [(qadr, lo, hi, rho)], (type1, size1), (type2, size2), geom of shape 1, geom of shape 2) or None"""
+    ta, tb = int(m.geom_type[a]), int(m.geom_type[b])
+    ok_types = (GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX)
+    if ta not in ok_types or tb not in ok_types:
+        return None
+    ba, bb = int(m.geom_body[a]), int(m.geom_body[b])
+    top = lca(m, ba, bb)
+    joints = []
+    for g, body in ((a, ba), (b, bb)):
+        for j, path in chain_joints(m, body, top):
+            jt = int(m.jnt_type[j])
+            if jt == JNT_FREE:
+                return None
+            reach = float(np.linalg.norm(m.geom_pos[g])) + rbound(int(m.geom_type[g]), m.geom_size[g]) + float(np.linalg.norm(m.jnt_pos[j]))
+            for pb in path[:-1]:
+                reach += float(np.linalg.norm(m.body_pos[pb]))
+                for jj in range(int(m.body_jntadr[pb]), int(m.body_jntadr[pb]) + int(m.body_jntnum[pb])):
+                    if int(m.jnt_type[jj]) == JNT_SLIDE:
+                        reach += float(np.abs(m.jnt_range[jj] - m.jnt_ref[jj]).max())
+            rho = 1.0 if jt == JNT_SLIDE else reach
+            lo, hi = (m.jnt_range[j] if m.jnt_limited[j] else (-np.pi, np.pi))
+            joints.append((int(m.jnt_qposadr[j]), float(lo), float(hi), rho))
+    if not joints or len(joints) > MAX_JOINTS:
+        return None
+
+    def cap(t, s):
+        return (GEOM_CAPSULE, s) if t == GEOM_CYLINDER else (t, s)
+    (t1, s1), (t2, s2) = cap(ta, m.geom_size[a]), cap(tb, m.geom_size[b])
+    ia, ib = (a, b)
+    if t1 > t2:
+        (t1, s1), (t2, s2) = (t2, s2), (t1, s1)
+        ia, ib = b, a
+    return joints, (t1, s1), (t2, s2), ia, ib
+
+
 def prove_pair(m, orc, q0, a, b, max_evals, floor=MARGIN):
     """floor: the proof shows dist > floor everywhere.  MARGIN (> 0: never even touching) is valid for every pair type;
     a negative floor (contact_threshold + MARGIN: touching allowed, the threshold never reached) only where the oracle's
@@ -149,7 +223,7 @@ def main():
         orc = O.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, spec.contact_threshold)
         ign = set(tuple(p) for p in pi.ignored_contacts)
         q0 = np.array(m.qpos0, dtype=np.float64)
-        proven, proven_thr = [], []
+        proven, proven_thr, radii = [], [], []
         t0 = time.time()
         for a, b in m.pair_geom:
             a, b = int(a), int(b)
@@ -165,18 +239,30 @@ def main():
                     print(f"  {env}: PROVEN above the threshold  {(m.all_geom_names[int(m.geom_mjid[a])] or a)} / {(m.all_geom_names[int(m.geom_mjid[b])] or b)}: {why}", flush=True)
                     continue
             name = lambda g: (m.all_geom_names[int(m.geom_mjid[g])] or f"g{int(m.geom_mjid[g])}") + "@" + m.body_names[int(m.geom_body[g])]
+            if not res:
+                # not prunable: is the bounding-sphere cull at least loose for it?
+                has_cyl = GEOM_CYLINDER in (int(m.geom_type[a]), int(m.geom_type[b]))
+                cr = cull_radius(m, orc, q0, a, b, args.max_evals // 4, MARGIN if has_cyl else spec.contact_threshold + MARGIN)
+                if cr is not None:
+                    rsum = rbound(int(m.geom_type[a]), m.geom_size[a]) + rbound(int(m.geom_type[b]), m.geom_size[b])
+                    if cr[0] + 1e-3 < 0.9 * rsum:
+                        radii.append([a, b, cr[0] + 1e-3])
+                        print(f"  {env}: cull radius  {name(a)} / {name(b)}: centres within {cr[0] + 1e-3:.4f} m whenever the threshold is reached "
+                              f"(bounding spheres: {rsum:.4f}); {cr[1]} evals", flush=True)
             if res:
                 proven.append([a, b])
                 print(f"  {env}: PROVEN separated  {name(a)} / {name(b)}: {why}", flush=True)
             elif res is None and why not in ("type", "free joint", "rigid") and "joints" not in why:
                 print(f"  {env}: undecided        {name(a)} / {name(b)}: {why}", flush=True)
-        print(f"{env}: {len(proven)} (+ {len(proven_thr)} that may touch) of {len(m.pair_geom)} candidate pairs proven never to violate the threshold ({time.time() - t0:.0f} s)", flush=True)
+        print(f"{env}: {len(radii)} tightened cull radii; {len(proven)} (+ {len(proven_thr)} that may touch) of {len(m.pair_geom)} candidate pairs proven never to violate the threshold ({time.time() - t0:.0f} s)", flush=True)
         if not args.dry:
             path = scene_path(spec.scene)
             cm = CompiledModel.load(path)
             cm.meta["never_violating_pairs"] = proven
             # pairs that may touch but provably stay above contact_threshold: pruned only by scenes whose threshold is <= this one
             cm.meta["never_violating_pairs_thr"] = {"threshold": spec.contact_threshold, "pairs": proven_thr}
+            # [geom a, geom b, radius]: the pair can only reach `threshold` while its geom centres are within `radius`
+            cm.meta["pair_cull_radius"] = {"threshold": spec.contact_threshold, "pairs": radii}
             cm.meta["never_violating_pairs_note"] = ("tools/prove_separated_pairs.py: branch-and-bound Lipschitz proof over the joint ranges, margin "
                                                      f"{MARGIN} m; valid for joint values inside their ranges")
             cm.save(path)

@@ -728,3 +728,44 @@ def test_pruned_pairs_never_reach_the_threshold(env, oracle_mod):
     a = BatchPlanner(sc).is_valid(tq, tr, samples_per_env=len(qa), want_min_dist=True)
     b = BatchPlanner(sc_full).is_valid(tq, tr, samples_per_env=len(qa), want_min_dist=True)
     assert torch.equal(a[0], b[0]) and np.array_equal(_bits(a[1].cpu().numpy()), _bits(b[1].cpu().numpy()))
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+@pytest.mark.parametrize("kernel", ["v1", "v5"])
+def test_verdicts_at_the_threshold(env, kernel, oracle_mod):
+    """Adversarial states for everything that decides a pair WITHOUT its exact distance (FP32 broad phase, per-pair cull radii,
+    enclosing-capsule / separating-axis pre-tests, the deep-overlap shortcut of the verdict-only kernels): segments from a valid
+    to an invalid state are bisected (on the oracle's verdict) down to two neighbouring states that straddle the contact
+    threshold, and the kernels must agree with the oracle on those and on states a few micrometres to millimetres either side."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk(env, oracle_mod, kernel)
+    bp = BatchPlanner(sc)
+    qa, row = sample_states(pi, 1200, 23, "uniform")
+    ov, _ = orc.is_valid_batch(qa, row, samples_per_env=len(qa), nthreads=0)
+    good, bad = qa[ov.astype(bool)], qa[~ov.astype(bool)]
+    n = min(len(good), len(bad), 150)
+    assert n >= 40
+    states = []
+    for a, b in zip(good[:n], bad[:n]):
+        lo, hi = 0.0, 1.0
+        for _ in range(44):
+            mid = 0.5 * (lo + hi)
+            ok, _ = orc.is_valid(_full(pi, a + mid * (b - a), row[0]))
+            lo, hi = (mid, hi) if ok else (lo, mid)
+        for t in (lo, hi):
+            for dt in (0.0, 1e-9, -1e-9, 1e-6, -1e-6, 1e-4, -1e-4, 3e-3, -3e-3):
+                states.append(a + min(max(t + dt, 0.0), 1.0) * (b - a))
+    qs = np.ascontiguousarray(np.array(states))
+    ov, omd = orc.is_valid_batch(qs, row, samples_per_env=len(qs), nthreads=0)
+    assert 0.2 < ov.mean() < 0.8
+    tq, tr = torch.from_numpy(qs).cuda(), torch.from_numpy(row).cuda()
+    v, md = bp.is_valid(tq, tr, samples_per_env=len(qs), want_min_dist=True)
+    v2 = bp.is_valid(tq, tr, samples_per_env=len(qs))
+    torch.cuda.synchronize()
+    assert np.array_equal(v2.cpu().numpy(), ov), "verdict-only kernel"
+    assert np.array_equal(v.cpu().numpy(), ov), "kernel with depths"
+    assert np.array_equal(_bits(md.cpu().numpy()), _bits(omd))
+    # the deepest penetration of the states just past the boundary sits at the threshold (that is what was bisected)
+    thr = pi.spec.contact_threshold
+    assert np.median(np.abs(omd[9::18] - thr)) < 1e-6          # (state 9 of a segment's 18: the first invalid one)

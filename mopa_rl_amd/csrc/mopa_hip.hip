@@ -916,6 +916,26 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
                         }
                     }
                     te[3] = ff2i(rs * rs);
+                    if (pmov) {
+                        // [0] (moving partners only; their centre comes from the tile's table): the square of the centre distance
+                        // below which the two geoms' INSCRIBED balls (radius r of a sphere / capsule, min(r, h) of a cylinder,
+                        // the smallest half extent of a box, centred where the geom is) overlap by more than the threshold
+                        // + 0.1 mm -- then the pair's distance is <= the threshold whatever its class computes (closed forms
+                        // are exact, SAT reports the true depth, the portal refinement never less than the true depth - 1e-6):
+                        // the verdict-only kernels call such a state invalid in the broad phase and drop all its entries
+                        auto r_in = [&](int g) -> double {
+                            const double *sz = &g_rec[(size_t)kGeomStride * g + GO_SIZE];
+                            switch (m.geom_type[g]) {
+                                case G_SPHERE: case G_CAPSULE: return sz[0];
+                                case G_CYLINDER: return std::min(sz[0], sz[1]);
+                                case G_BOX: return std::min(sz[0], std::min(sz[1], sz[2]));
+                                default: return 0.0;
+                            }
+                        };
+                        const double ra = r_in(mg_geom[mslot]), rb = r_in(pg);
+                        const double reach = ra + rb - (std::max(0.0, -desc->contact_threshold) + 1e-4) - 4.0 * kCullEps;
+                        te[0] = ff2i((ra > 0.0 && rb > 0.0 && reach > 0.0) ? (float)(reach * reach) * (1.0f - 1e-6f) : 0.0f);
+                    }
                     int flags = w & 0x3fffff;    // gp_word already carries the slot in bits 14..21
                     if (!pmov) {
                         const double *rec = &g_rec[(size_t)kGeomStride * pg];

@@ -130,9 +130,11 @@ typedef struct MopaPlanParams {
                                       lets a caller plan for a compacted subset of its envs with the streams of the full set */
     const uint64_t *seeds_dev;     /* mopa_plan_batch only, nullable: explicit seed per query (device pointer, [E]) instead of
                                       `seed` -- queries of envs that are at different steps of their own rollouts in one launch */
-    int32_t max_workgroups;        /* mopa_plan_batch only: cap on the persistent workgroups of the launch (0 = as many as the chip
-                                      holds).  A planner workgroup keeps ~70 KB of LDS for as long as queries are left; a launch that
-                                      shares the GPU with other streams' kernels (asynchronous rollouts) leaves them room this way */
+    int32_t max_workgroups;        /* mopa_plan_batch only: persistent workgroups of the launch.  0 = one per CU (a lone launch ends
+                                      with its slowest query, and two budget-exhausting queries on one SIMD slow each other down);
+                                      < 0 = as many as the chip holds at once (two per CU: throughput, for launches that overlap
+                                      others -- the iteration ladder); > 0 = an explicit cap (asynchronous rollouts leave the main
+                                      stream's kernels room this way: a workgroup keeps ~70 KB of LDS while queries are left) */
 } MopaPlanParams;
 
 const char *mopa_last_error(void);

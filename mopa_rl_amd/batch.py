@@ -74,7 +74,9 @@ class BatchPlanner:
              env_id_base: int = 0, stream=None, env_ids=None, seeds=None, max_workgroups: int = 0) -> Tuple["object", "object", "object", "object"]:
         """E independent RRT-Connect queries.  Returns (path[E,max_path,nq], path_len[E], status[E], n_checks[E]).
         env_ids (int64 [E] GPU tensor, optional): the sample-stream id of every query (default env_id_base + index).
-        seeds (int64 [E] GPU tensor, optional): a seed per query instead of `seed`."""
+        seeds (int64 [E] GPU tensor, optional): a seed per query instead of `seed`.
+        max_workgroups: 0 = one persistent workgroup per CU (shortest lone launch), < 0 = as many as the chip holds (throughput:
+        launches that overlap others), > 0 = explicit cap (include/mopa_hip.h)."""
         torch = _torch()
         _check_f64(start, "start", self.nq)
         _check_f64(goal, "goal", self.nq)
@@ -97,7 +99,7 @@ class BatchPlanner:
         return path, plen, status, nchk
 
     def plan_laddered(self, batches, max_iters: int = 2000, first_iters: int = 300, max_nodes: int = 1024, max_path: int = 256,
-                      retry_streams=None, first_stream=None, max_workgroups_first: int = 0, retry_min: int = 512):
+                      retry_streams=None, first_stream=None, max_workgroups_first: int = -1, retry_min: int = 512):
         """A stream of query batches through RRT-Connect with an iteration ladder.  `batches`: list of dicts with `start`,
         `goal` ([E, nq] tensors), `seed` and optionally `env_ids` / `seeds` as for `plan`.  Every batch first runs with
         `first_iters`; the queries that come back "no exact solution" (a few %: the ones that would have kept the whole
@@ -128,7 +130,7 @@ class BatchPlanner:
             with torch.cuda.stream(sb):
                 cat = lambda k: torch.cat([w[k] for w in wait]).contiguous()
                 r2 = self.plan(cat("start"), cat("goal"), max_iters=max_iters, max_nodes=max_nodes, max_path=max_path, seed=0,
-                               env_ids=cat("ids"), seeds=cat("seeds"), stream=sb)
+                               env_ids=cat("ids"), seeds=cat("seeds"), stream=sb, max_workgroups=-1)
             # the pooled slices were allocated on `sa` and are read by the cat on `sb`: tell the caching allocator, or the
             # next first launch on `sa` may be handed their blocks while `sb` still waits behind an earlier retry
             for w in wait:

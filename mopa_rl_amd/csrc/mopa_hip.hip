@@ -235,7 +235,9 @@ MOPA_D LdsView make_view(const SceneHdr &h, unsigned char *smem) {
     double *s_dbl = reinterpret_cast<double *>(smem);
     int *s_int = reinterpret_cast<int *>(s_dbl + h.n_dbl);
     int int_pad = (h.n_int + 1) & ~1;
-    unsigned char *wave_base = reinterpret_cast<unsigned char *>(s_int + int_pad) + (threadIdx.x >> 6) * h.wave_bytes;
+    // (readfirstlane: the wave index is wave-uniform, but derived from threadIdx the compiler keeps it -- and every pointer
+    //  computed from it -- in vector registers: two VGPRs per pointer held across the planner's non-inlined validity calls)
+    unsigned char *wave_base = reinterpret_cast<unsigned char *>(s_int + int_pad) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * h.wave_bytes;
     v.dbl = s_dbl;
     v.ints = s_int;
     v.grec = reinterpret_cast<double *>(wave_base);
@@ -416,14 +418,6 @@ MOPA_D void wave_load_state(const SceneHdr &h, const LdsView &v, int lane, const
 // K1: state validity, one wave per state
 // ---------------------------------------------------------------------------
 template <bool WANT_MD, bool MESH>
-// Kernels that call the planner's non-inlined validity routines (K2 motion checks, K3, pull-back).  MOPA_PLAN_WAVES=2 (A/B
-// builds only) caps their register budget for two waves per SIMD; the attribute is kernel-only and propagates to the routines
-// only when every caller carries it.
-#ifdef MOPA_PLAN_WAVES
-#define MOPA_PLAN_KERNEL __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MOPA_PLAN_WAVES, MOPA_PLAN_WAVES)))
-#else
-#define MOPA_PLAN_KERNEL __global__ __launch_bounds__(kBlock)
-#endif
 __global__ __launch_bounds__(kBlock) void k_is_valid(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
                                                       const double *__restrict__ q_active, const double *__restrict__ qpos_env,
                                                       long long N, long long samples_per_env, unsigned char *__restrict__ valid,
@@ -431,7 +425,7 @@ __global__ __launch_bounds__(kBlock) void k_is_valid(SceneHdr h, const double *_
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsView v = make_view(h, smem);
     stage_scene(h, g_dbl, g_int, const_cast<double *>(v.dbl), const_cast<int *>(v.ints));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long stride = (long long)gridDim.x * kWavesPerBlock;
     for (long long s = (long long)blockIdx.x * kWavesPerBlock + wave; s < N; s += stride) {
         long long env = s / samples_per_env;
@@ -477,7 +471,7 @@ MOPA_D int valid_segment_count(const SceneHdr &h, const LdsView &v, const double
 __device__ __noinline__ bool plan_state_valid_impl(const SceneHdr *hp, const double *dbl, const int *ints, double *grec,
                                                    double *qbuf, unsigned short *wl, int lane, const double *qa, const double *row);
 
-MOPA_PLAN_KERNEL void k_check_motion(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
+__global__ __launch_bounds__(kBlock) void k_check_motion(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
                                                          const double *__restrict__ qa_all, const double *__restrict__ qb_all,
                                                          const double *__restrict__ qpos_env, long long N, long long samples_per_env,
                                                          unsigned char *__restrict__ valid, int hdr_lds_off) {
@@ -489,7 +483,7 @@ MOPA_PLAN_KERNEL void k_check_motion(SceneHdr h, const double *__restrict__ g_db
     for (int i = threadIdx.x; i < (int)(sizeof(SceneHdr) / 4); i += blockDim.x)
         reinterpret_cast<int *>(lh)[i] = reinterpret_cast<const int *>(&h)[i];
     stage_scene(h, g_dbl, g_int, const_cast<double *>(v.dbl), const_cast<int *>(v.ints));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long stride = (long long)gridDim.x * kWavesPerBlock;
     for (long long s = (long long)blockIdx.x * kWavesPerBlock + wave; s < N; s += stride) {
         const double *qa = qa_all + s * h.na, *qb = qb_all + s * h.na;
@@ -520,7 +514,7 @@ __global__ __launch_bounds__(kBlock) void k_debug_state(SceneHdr h, const double
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsView v = make_view(h, smem);
     stage_scene(h, g_dbl, g_int, const_cast<double *>(v.dbl), const_cast<int *>(v.ints));
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (wave != 0) return;
     wave_load_state(h, v, lane, q_active, qpos_row);
     wave_fk(h, v, lane);

@@ -78,9 +78,10 @@ class RolloutConfig:
     device_paths: bool = True         # planner rows -> trajectories (un-wrap, densification) on the device (batch.postprocess_paths);
                                       # False: the array-operation form on the host (also serves the rare queries whose
                                       # densification needs the fallback planners)
-    planner_workgroups: int = 64      # persistent workgroups of an asynchronous launch: a planner wave holds ~370 registers, no
-                                      # validity wave (226) fits next to it on a SIMD, so launches that took every CU would stall
-                                      # the main stream's kernels for their whole bulk phase
+    planner_workgroups: int = 128     # persistent workgroups of an asynchronous launch.  A planner wave holds 256 registers (two
+                                      # per SIMD): launches that took every slot would stall the main stream's kernels for their
+                                      # whole bulk phase.  3 streams x 128 measured best on Push (tools/rollout_w2.sh: 1.03 M agent
+                                      # steps/s; 3 x 64: 0.79 M, 2 x 256: 0.93 M)
     discrete_action: bool = False     # --discrete_action (config/__init__.py:110; rl/mopa_rollouts.py:86-88,106-111,349): the policy's
                                       # `ac_type` head (1 = planner), not the action's magnitude, routes a step; direct actions
                                       # are then NOT divided by omega

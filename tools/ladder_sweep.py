@@ -40,6 +40,11 @@ if QUICK:       # one full launch, then the default ladder over a long stream
     bp.plan(start, goal, seed=7, **prm)
     torch.cuda.synchronize()
     print(f"one full launch: {(time.perf_counter()-t0)*1e3:.2f} ms per 4096 queries")
+    for wg in (256, 512):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        bp.plan(start, goal, seed=7, max_workgroups=wg, **prm)
+        torch.cuda.synchronize()
+        print(f"one full launch, at most {wg} workgroups: {(time.perf_counter()-t0)*1e3:.2f} ms per 4096 queries")
 for nb in ((32,) if QUICK else (8, 16, 32)):
     for first in ((200,) if QUICK else (100, 200, 400)):
         for rmin, nret in (((512, 2), (512, 4), (1024, 4)) if QUICK else ((512, 2), (256, 3), (1024, 2))):

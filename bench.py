@@ -163,7 +163,7 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
         for i, st in enumerate(streams):
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
-                bp.plan(start, goal, **dict(prm, seed=7 + 13 * i), stream=st, max_workgroups=max(1, 2 * torch.cuda.get_device_properties(device).multi_processor_count // nl))
+                bp.plan(start, goal, **dict(prm, seed=7 + 13 * i), stream=st, max_workgroups=max(1, torch.cuda.get_device_properties(device).multi_processor_count // nl))
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
     burst()
@@ -173,7 +173,7 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
     torch.cuda.synchronize()
     dtc = _t.perf_counter() - t0
     out["concurrent"] = {"launches": nl, "queries": nl * E, "ms_total": dtc * 1e3, "plans_per_s": nl * E / dtc,
-                         "note": f"{nl} launches of {E} queries on {nl} streams, each capped to 1/{nl} of the workgroup slots (two per CU)"}
+                         "note": f"{nl} launches of {E} queries on {nl} streams, each capped to 1/{nl} of the CUs (one workgroup per CU in total: the burst ends with its slowest queries)"}
     # ... and a stream of batches through the iteration ladder (BatchPlanner.plan_laddered): 200 iterations first, the ~3 % it
     # does not solve again with all 2000 on other streams while the next batches' first launches run -- results identical
     # to full-budget launches (tests/test_gpu_parity.py::test_laddered_planning_equals_one_full_launch)

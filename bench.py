@@ -163,7 +163,7 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
         for i, st in enumerate(streams):
             st.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(st):
-                bp.plan(start, goal, **dict(prm, seed=7 + 13 * i), stream=st, max_workgroups=max(1, torch.cuda.get_device_properties(device).multi_processor_count // nl))
+                bp.plan(start, goal, **dict(prm, seed=7 + 13 * i), stream=st, max_workgroups=max(1, torch.cuda.get_device_properties(device).multi_processor_count // nl), exclusive=True)
         for st in streams:
             torch.cuda.current_stream().wait_stream(st)
     burst()
@@ -181,7 +181,7 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
     batches = [dict(start=start, goal=goal, seed=7 + 13 * i) for i in range(nb)]
     lad_kw = dict(max_iters=prm["max_iters"], first_iters=200, max_nodes=prm["max_nodes"], max_path=prm["max_path"],
                   first_stream=streams[0], retry_streams=streams[1:3])
-    bp.plan_laddered(batches[:2], **lad_kw)
+    bp.plan_laddered(batches, **lad_kw)        # untimed: per-stream scratch (trees of the pooled retry launches) grows to its final size
     torch.cuda.synchronize()
     t0 = _t.perf_counter()
     lad = bp.plan_laddered(batches, **lad_kw)

@@ -135,6 +135,9 @@ typedef struct MopaPlanParams {
                                       < 0 = as many as the chip holds at once (two per CU: throughput, for launches that overlap
                                       others -- the iteration ladder); > 0 = an explicit cap (asynchronous rollouts leave the main
                                       stream's kernels room this way: a workgroup keeps ~70 KB of LDS while queries are left) */
+    int32_t exclusive_cu;          /* mopa_plan_batch only: nonzero = the launch asks for more than half a CU's LDS, so that no other
+                                      planner workgroup (of this or of an overlapping launch) shares its CUs -- for a burst of capped
+                                      launches that together want one workgroup per CU.  Implied by max_workgroups == 0 */
 } MopaPlanParams;
 
 const char *mopa_last_error(void);

@@ -99,7 +99,7 @@ class MopaIkDesc(C.Structure):
 
 class MopaPlanParams(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("max_nodes", C.c_int32), ("max_path", C.c_int32), ("seed", C.c_uint64),
-                ("env_id_base", C.c_uint64), ("env_ids_dev", C.c_void_p), ("seeds_dev", C.c_void_p), ("max_workgroups", C.c_int32)]
+                ("env_id_base", C.c_uint64), ("env_ids_dev", C.c_void_p), ("seeds_dev", C.c_void_p), ("max_workgroups", C.c_int32), ("exclusive_cu", C.c_int32)]
 
 
 _lib: Optional[C.CDLL] = None

@@ -71,12 +71,13 @@ class BatchPlanner:
         return valid
 
     def plan(self, start, goal, max_iters: int = 2000, max_nodes: int = 1024, max_path: int = 256, seed: int = 0,
-             env_id_base: int = 0, stream=None, env_ids=None, seeds=None, max_workgroups: int = 0) -> Tuple["object", "object", "object", "object"]:
+             env_id_base: int = 0, stream=None, env_ids=None, seeds=None, max_workgroups: int = 0, exclusive: bool = False) -> Tuple["object", "object", "object", "object"]:
         """E independent RRT-Connect queries.  Returns (path[E,max_path,nq], path_len[E], status[E], n_checks[E]).
         env_ids (int64 [E] GPU tensor, optional): the sample-stream id of every query (default env_id_base + index).
         seeds (int64 [E] GPU tensor, optional): a seed per query instead of `seed`.
         max_workgroups: 0 = one persistent workgroup per CU (shortest lone launch), < 0 = as many as the chip holds (throughput:
-        launches that overlap others), > 0 = explicit cap (include/mopa_hip.h)."""
+        launches that overlap others), > 0 = explicit cap; exclusive: no other planner workgroup shares this launch's CUs
+        (include/mopa_hip.h)."""
         torch = _torch()
         _check_f64(start, "start", self.nq)
         _check_f64(goal, "goal", self.nq)
@@ -93,7 +94,7 @@ class BatchPlanner:
             raise _lib.MopaError("seeds must be a contiguous int64 GPU tensor of shape [E]")
         prm = _lib.MopaPlanParams(int(max_iters), int(max_nodes), int(max_path), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                   int(env_id_base), _ptr(env_ids) if env_ids is not None else None,
-                                  _ptr(seeds) if seeds is not None else None, int(max_workgroups))
+                                  _ptr(seeds) if seeds is not None else None, int(max_workgroups), 1 if exclusive else 0)
         _lib.check(_lib.lib().mopa_plan_batch(self.scene.handle, _ptr(start), _ptr(goal), E, C.byref(prm), _ptr(path),
                                               _ptr(plen), _ptr(status), _ptr(nchk), _stream_handle(stream)))
         return path, plen, status, nchk

@@ -362,6 +362,9 @@ def test_plan_results_do_not_depend_on_launch_shape(oracle_mod):
     ids = torch.arange(E, device="cuda", dtype=torch.int64)
     base = [t.cpu().numpy() for t in bp.plan(s, g, seed=5, env_ids=ids, **prm)]
     capped = [t.cpu().numpy() for t in bp.plan(s, g, seed=5, env_ids=ids, max_workgroups=3, **prm)]
+    # all resident workgroup slots (two per CU) / a capped launch that keeps other planner workgroups off its CUs
+    wide = [t.cpu().numpy() for t in bp.plan(s, g, seed=5, env_ids=ids, max_workgroups=-1, **prm)]
+    excl = [t.cpu().numpy() for t in bp.plan(s, g, seed=5, env_ids=ids, max_workgroups=8, exclusive=True, **prm)]
     seeds = torch.full((E,), 5, device="cuda", dtype=torch.int64)
     seeded = [t.cpu().numpy() for t in bp.plan(s, g, seed=999, env_ids=ids, seeds=seeds, **prm)]
     sub = torch.arange(0, E, 3, device="cuda", dtype=torch.int64)
@@ -375,6 +378,8 @@ def test_plan_results_do_not_depend_on_launch_shape(oracle_mod):
         for e in range(len(x[1])):
             assert np.array_equal(x[0][e, :x[1][e]].view(np.uint64), y[0][e, :y[1][e]].view(np.uint64))
     same(base, capped)
+    same(base, wide)
+    same(base, excl)
     same(base, seeded)
     same([np.ascontiguousarray(a[::3]) for a in base], part)
 

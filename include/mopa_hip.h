@@ -138,6 +138,21 @@ typedef struct MopaPlanParams {
     int32_t exclusive_cu;          /* mopa_plan_batch only: nonzero = the launch asks for more than half a CU's LDS, so that no other
                                       planner workgroup (of this or of an overlapping launch) shares its CUs -- for a burst of capped
                                       launches that together want one workgroup per CU.  Implied by max_workgroups == 0 */
+    /* mopa_plan_batch only, all nullable (device pointers): continuing queries across launches.  A query's outcome is a
+       function of its endpoints and sample stream only and the iteration budget merely ends the loop, so a launch with a
+       small budget can leave its unsolved queries where a later launch with a larger budget picks them up -- the result is
+       that of one launch with the larger budget, without retracing the first iterations (the iteration ladder).
+       Saving: tree_q_dev [E][2][max_nodes][na] doubles (+ 8 of padding), tree_p_dev [E][2][max_nodes] int32 hold the trees
+       instead of the library's scratch; state_dev [E][4] int64 receives (iterations done | -1 = the outcome does not depend
+       on the budget, start-tree size, goal-tree size, consumed checks).
+       Continuing: resume_tree_q / resume_tree_p / resume_state = those buffers (rows gathered to this launch's query order,
+       same max_nodes, same seeds / stream ids as the first launch). */
+    double *tree_q_dev;
+    int32_t *tree_p_dev;
+    int64_t *state_dev;
+    const double *resume_tree_q;
+    const int32_t *resume_tree_p;
+    const int64_t *resume_state;
 } MopaPlanParams;
 
 const char *mopa_last_error(void);

@@ -99,7 +99,9 @@ class MopaIkDesc(C.Structure):
 
 class MopaPlanParams(C.Structure):
     _fields_ = [("max_iters", C.c_int32), ("max_nodes", C.c_int32), ("max_path", C.c_int32), ("seed", C.c_uint64),
-                ("env_id_base", C.c_uint64), ("env_ids_dev", C.c_void_p), ("seeds_dev", C.c_void_p), ("max_workgroups", C.c_int32), ("exclusive_cu", C.c_int32)]
+                ("env_id_base", C.c_uint64), ("env_ids_dev", C.c_void_p), ("seeds_dev", C.c_void_p), ("max_workgroups", C.c_int32), ("exclusive_cu", C.c_int32),
+                ("tree_q_dev", C.c_void_p), ("tree_p_dev", C.c_void_p), ("state_dev", C.c_void_p),
+                ("resume_tree_q", C.c_void_p), ("resume_tree_p", C.c_void_p), ("resume_state", C.c_void_p)]
 
 
 _lib: Optional[C.CDLL] = None

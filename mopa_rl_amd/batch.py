@@ -34,6 +34,37 @@ def _stream_handle(stream) -> C.c_void_p:
     return C.c_void_p(s.cuda_stream)
 
 
+class PlanState:
+    """Trees, iteration and check counts a planner launch left behind for its queries (`BatchPlanner.plan(keep_state=True)`)."""
+
+    def __init__(self, tree_q, tree_p, state, max_nodes: int, na: int):
+        self.tree_q, self.tree_p, self.state, self.max_nodes, self.na = tree_q, tree_p, state, int(max_nodes), int(na)
+
+    def rows(self, idx):
+        """the state of the queries `idx` (int64 tensor), in that order -- what a continuing launch of those queries takes"""
+        torch = _torch()
+        E = self.state.shape[0]
+        w = 2 * self.max_nodes * self.na
+        tq = torch.empty(len(idx) * w + 8, dtype=torch.float64, device=self.tree_q.device)
+        tq[:len(idx) * w].view(len(idx), w).copy_(self.tree_q[:E * w].view(E, w)[idx])
+        return PlanState(tq, self.tree_p.view(E, 2 * self.max_nodes)[idx].contiguous().view(-1), self.state[idx].contiguous(),
+                         self.max_nodes, self.na)
+
+    @staticmethod
+    def cat(parts):
+        torch = _torch()
+        p0 = parts[0]
+        w = 2 * p0.max_nodes * p0.na
+        n = sum(p.state.shape[0] for p in parts)
+        tq = torch.empty(n * w + 8, dtype=torch.float64, device=p0.tree_q.device)
+        o = 0
+        for p in parts:
+            k = p.state.shape[0] * w
+            tq[o:o + k].copy_(p.tree_q[:k])
+            o += k
+        return PlanState(tq, torch.cat([p.tree_p for p in parts]), torch.cat([p.state for p in parts]), p0.max_nodes, p0.na)
+
+
 class BatchPlanner:
     """N-state validity / motion checks and E-env RRT-Connect on one GPU."""
 
@@ -71,18 +102,31 @@ class BatchPlanner:
         return valid
 
     def plan(self, start, goal, max_iters: int = 2000, max_nodes: int = 1024, max_path: int = 256, seed: int = 0,
-             env_id_base: int = 0, stream=None, env_ids=None, seeds=None, max_workgroups: int = 0, exclusive: bool = False) -> Tuple["object", "object", "object", "object"]:
+             env_id_base: int = 0, stream=None, env_ids=None, seeds=None, max_workgroups: int = 0, exclusive: bool = False,
+             keep_state: bool = False, resume=None) -> Tuple["object", "object", "object", "object"]:
         """E independent RRT-Connect queries.  Returns (path[E,max_path,nq], path_len[E], status[E], n_checks[E]).
         env_ids (int64 [E] GPU tensor, optional): the sample-stream id of every query (default env_id_base + index).
         seeds (int64 [E] GPU tensor, optional): a seed per query instead of `seed`.
         max_workgroups: 0 = one persistent workgroup per CU (shortest lone launch), < 0 = as many as the chip holds (throughput:
         launches that overlap others), > 0 = explicit cap; exclusive: no other planner workgroup shares this launch's CUs
-        (include/mopa_hip.h)."""
+        (include/mopa_hip.h).
+        keep_state: the launch keeps its trees in tensors of its own and returns a fifth element, a `PlanState` (tree_q, tree_p,
+        state, max_nodes), from which a later launch with a larger `max_iters` continues the unsolved queries: `resume=` a
+        PlanState whose rows are in this launch's query order (`PlanState.rows(idx)` gathers; same max_nodes, same seeds / ids).
+        The continued run gives what one launch with the larger budget gives, without retracing the first iterations."""
         torch = _torch()
         _check_f64(start, "start", self.nq)
         _check_f64(goal, "goal", self.nq)
         E = start.shape[0]
         dev = start.device
+        ps = None
+        if keep_state:
+            na = self.scene.na
+            ps = PlanState(torch.empty(E * 2 * max_nodes * na + 8, dtype=torch.float64, device=dev),
+                           torch.empty(E * 2 * max_nodes, dtype=torch.int32, device=dev),
+                           torch.zeros(E, 4, dtype=torch.int64, device=dev), int(max_nodes), na)
+        if resume is not None and (resume.max_nodes != int(max_nodes) or resume.state.shape[0] != E):
+            raise _lib.MopaError("resume: a PlanState of this launch's queries (same order, same max_nodes) is needed")
         path = torch.zeros(E, max_path, self.nq, dtype=torch.float64, device=dev)
         plen = torch.zeros(E, dtype=torch.int32, device=dev)
         status = torch.zeros(E, dtype=torch.int32, device=dev)
@@ -94,19 +138,26 @@ class BatchPlanner:
             raise _lib.MopaError("seeds must be a contiguous int64 GPU tensor of shape [E]")
         prm = _lib.MopaPlanParams(int(max_iters), int(max_nodes), int(max_path), int(seed) & 0xFFFFFFFFFFFFFFFF,
                                   int(env_id_base), _ptr(env_ids) if env_ids is not None else None,
-                                  _ptr(seeds) if seeds is not None else None, int(max_workgroups), 1 if exclusive else 0)
+                                  _ptr(seeds) if seeds is not None else None, int(max_workgroups), 1 if exclusive else 0,
+                                  _ptr(ps.tree_q) if ps else None, _ptr(ps.tree_p) if ps else None, _ptr(ps.state) if ps else None,
+                                  _ptr(resume.tree_q) if resume is not None else None, _ptr(resume.tree_p) if resume is not None else None,
+                                  _ptr(resume.state) if resume is not None else None)
         _lib.check(_lib.lib().mopa_plan_batch(self.scene.handle, _ptr(start), _ptr(goal), E, C.byref(prm), _ptr(path),
                                               _ptr(plen), _ptr(status), _ptr(nchk), _stream_handle(stream)))
-        return path, plen, status, nchk
+        if resume is not None and stream is not None:
+            for t in (resume.tree_q, resume.tree_p, resume.state):
+                t.record_stream(stream)
+        return (path, plen, status, nchk, ps) if keep_state else (path, plen, status, nchk)
 
     def plan_laddered(self, batches, max_iters: int = 2000, first_iters: int = 300, max_nodes: int = 1024, max_path: int = 256,
-                      retry_streams=None, first_stream=None, max_workgroups_first: int = -1, retry_min: int = 512):
+                      retry_streams=None, first_stream=None, max_workgroups_first: int = -1, retry_min: int = 512, resume: bool = True):
         """A stream of query batches through RRT-Connect with an iteration ladder.  `batches`: list of dicts with `start`,
         `goal` ([E, nq] tensors), `seed` and optionally `env_ids` / `seeds` as for `plan`.  Every batch first runs with
         `first_iters`; the queries that come back "no exact solution" (a few %: the ones that would have kept the whole
         launch waiting for their 2000 iterations) run again with `max_iters` -- pooled over batches until `retry_min` of them
         wait -- on other streams, next to the following batches' first launches.  A query's outcome depends on its endpoints and sample stream only and the budget merely
-        ends the loop, so the second run retraces the first and continues: each batch's (path, path_len, status, n_checks)
+        ends the loop, so the second run continues where the first stopped (`resume`: from its trees and counters; False: it retraces
+        the first iterations): each batch's (path, path_len, status, n_checks)
         are those of `plan(..., max_iters=max_iters)`, bit for bit.  Returns the list of those tuples (after all launches
         have finished).  One host read-back per batch (which queries go again)."""
         torch = _torch()
@@ -131,12 +182,16 @@ class BatchPlanner:
             with torch.cuda.stream(sb):
                 cat = lambda k: torch.cat([w[k] for w in wait]).contiguous()
                 r2 = self.plan(cat("start"), cat("goal"), max_iters=max_iters, max_nodes=max_nodes, max_path=max_path, seed=0,
-                               env_ids=cat("ids"), seeds=cat("seeds"), stream=sb, max_workgroups=-1)
+                               env_ids=cat("ids"), seeds=cat("seeds"), stream=sb, max_workgroups=-1,
+                               resume=PlanState.cat([w["state"] for w in wait]) if resume else None)
             # the pooled slices were allocated on `sa` and are read by the cat on `sb`: tell the caching allocator, or the
             # next first launch on `sa` may be handed their blocks while `sb` still waits behind an earlier retry
             for w in wait:
                 for k in ("start", "goal", "ids", "seeds", "rows"):
                     w[k].record_stream(sb)
+                if resume:
+                    for t in (w["state"].tree_q, w["state"].tree_p, w["state"].state):
+                        t.record_stream(sb)
             pend.append(([(w["batch"], w["rows"]) for w in wait], r2, sb))
             wait, n_wait = [], 0
 
@@ -147,12 +202,15 @@ class BatchPlanner:
                 ids = torch.arange(E, device=dev, dtype=torch.int64)
             with torch.cuda.stream(sa):
                 res = self.plan(b["start"], b["goal"], max_iters=first_iters, max_nodes=max_nodes, max_path=max_path, seed=b.get("seed", 0),
-                                env_ids=ids, seeds=b.get("seeds"), stream=sa, max_workgroups=max_workgroups_first)
+                                env_ids=ids, seeds=b.get("seeds"), stream=sa, max_workgroups=max_workgroups_first, keep_state=resume)
+                kept = res[4] if resume else None
+                res = res[:4]
                 again = torch.nonzero(res[2] == _lib.PLAN_NO_EXACT).flatten()       # (waits for this launch: the one read-back)
                 if len(again):
                     seeds = (b["seeds"][again] if b.get("seeds") is not None
                              else torch.full((len(again),), int(b.get("seed", 0)), dtype=torch.int64, device=dev))
-                    wait.append(dict(start=b["start"][again], goal=b["goal"][again], ids=ids[again], seeds=seeds, batch=i, rows=again))
+                    wait.append(dict(start=b["start"][again], goal=b["goal"][again], ids=ids[again], seeds=seeds, batch=i, rows=again,
+                                     state=kept.rows(again) if resume else None))
                     n_wait += len(again)
             out.append(list(res))
             if n_wait >= retry_min:

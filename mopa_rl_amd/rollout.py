@@ -186,6 +186,7 @@ class BatchMoPARollout:
         self._jobs = []
         # blocked envs waiting for the next RRT-Connect launch: mask + their (clipped) current state and target
         self._pool_mask = torch.zeros(self.E, dtype=torch.bool, device=dev)
+        self._res = None      # per-env parking buffers of planner state between a first-phase launch and its retry (_park_state)
         self._retry_mask = torch.zeros(self.E, dtype=torch.bool, device=dev)     # ... and those whose first, short launch ran out
         self._wait_since = torch.zeros(self.E, dtype=torch.int64, device=dev)    # call in which an env started to wait
         self.n_retried = torch.zeros((), dtype=torch.int64, device=dev)
@@ -280,7 +281,7 @@ class BatchMoPARollout:
         self._t_dev.fill_(int(value))
         self.t_env.fill_(int(value))
 
-    def _rrt_launch(self, cur_f, target_f, ids, stream=None, iters=None):
+    def _rrt_launch(self, cur_f, target_f, ids, stream=None, iters=None, keep=False, resume=None):
         """RRT-Connect (K3) for the envs `ids` whose straight line is blocked (:205-209): asynchronous, optionally on a side
         stream.  The sample stream of a query is keyed by (cfg.seed + the env's own step count, env id), so an env's plans do
         not depend on which other envs are planned with it or when."""
@@ -296,9 +297,12 @@ class BatchMoPARollout:
         else:
             stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):
-                job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=iters, max_nodes=cfg.max_nodes,
-                                                                          max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds,
-                                                                          stream=stream, max_workgroups=cfg.planner_workgroups)
+                res = self.bp.plan(cur_f, target_f, max_iters=iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path, seed=cfg.seed,
+                                   env_ids=ids, seeds=seeds, stream=stream, max_workgroups=cfg.planner_workgroups,
+                                   keep_state=keep, resume=resume)
+                job["path"], job["plen"], job["status"] = res[0], res[1], res[2]
+                if keep:
+                    job["pstate"] = res[4]      # trees + counters of the queries this budget leaves unsolved (see _seg_plan)
                 for t in (cur_f, target_f, ids, seeds):
                     t.record_stream(stream)
                 job["event"] = torch.cuda.Event()
@@ -791,6 +795,26 @@ class BatchMoPARollout:
         return {"ac_type": ac_type, "active": active, "prev_ob": prev_ob, "ac_tr": ac_tr, "a": a, "extra_ac": extra_ac, "is_pl": is_pl, "plan_ok": plan_ok,
                 "traj_pad": traj_pad, "path_len": path_len, "n_finished": 0}
 
+    def _park_state(self, ps, jid, again):
+        """the planner state (trees, counters) of a first-phase launch's unsolved queries -> the per-env parking buffers"""
+        torch = _torch()
+        from .batch import PlanState
+        E, w = self.E, 2 * ps.max_nodes * ps.na
+        if self._res is None:
+            dev = ps.state.device
+            self._res = PlanState(torch.empty(E * w + 8, dtype=torch.float64, device=dev), torch.empty(E * 2 * ps.max_nodes, dtype=torch.int32, device=dev),
+                                  torch.zeros(E, 4, dtype=torch.int64, device=dev), ps.max_nodes, ps.na)
+        rows = torch.nonzero(again).flatten()
+        if len(rows) == 0:
+            return
+        env_rows = jid[rows]
+        n = ps.state.shape[0]
+        self._res.tree_q[:E * w].view(E, w)[env_rows] = ps.tree_q[:n * w].view(n, w)[rows]
+        self._res.tree_p.view(E, 2 * ps.max_nodes)[env_rows] = ps.tree_p.view(n, 2 * ps.max_nodes)[rows]
+        self._res.state[env_rows] = ps.state[rows]
+        for x in (ps.tree_q, ps.tree_p, ps.state):
+            x.record_stream(torch.cuda.current_stream())
+
     def _seg_plan(self, bag):
         """RRT-Connect launches for the pooled envs, pick-up of the launches that are done (host logic, dynamic shapes)"""
         torch = _torch()
@@ -828,7 +852,14 @@ class BatchMoPARollout:
                 bi = bi.contiguous()
                 mask[bi] = False
                 iters = cfg.planner_first_iters if (two_phase and not retry) else self.main_iters
-                job = self._rrt_launch(self._q_cur[bi].contiguous(), self._q_tgt[bi].contiguous(), bi, side, iters=iters)
+                # a first-phase launch keeps its trees; the retry launch of its unsolved queries continues from them (parked per
+                # env in between) instead of retracing the first iterations
+                res_in = None
+                if retry and self._res is not None:
+                    from .batch import PlanState
+                    res_in = PlanState(self._res.tree_q, self._res.tree_p, self._res.state, cfg.max_nodes, self._res.na).rows(bi)
+                job = self._rrt_launch(self._q_cur[bi].contiguous(), self._q_tgt[bi].contiguous(), bi, side, iters=iters,
+                                       keep=two_phase and not retry and side is not None, resume=res_in)
                 job["retry"] = retry
                 self._jobs.append(job)
         # ---- RRT-Connect jobs that are done (lock-step: all of them) ----
@@ -856,6 +887,8 @@ class BatchMoPARollout:
                 # again with the full budget (their envs stay busy); everything else is final
                 again = ~s_t & ~t(e_j)
                 self._retry_mask[jid[again]] = True
+                if "pstate" in job:
+                    self._park_state(job["pstate"], jid, again)
                 self.n_retried = self.n_retried + again.sum()
                 keep = ~again
                 jid, s_t = jid[keep], s_t[keep]

@@ -774,3 +774,52 @@ def test_verdicts_at_the_threshold(env, kernel, oracle_mod):
     # the deepest penetration of the states just past the boundary sits at the threshold (that is what was bisected)
     thr = pi.spec.contact_threshold
     assert np.median(np.abs(omd[9::18] - thr)) < 1e-6          # (state 9 of a segment's 18: the first invalid one)
+
+
+def test_continued_planning_equals_one_full_launch(oracle_mod):
+    """`keep_state` / `resume`: a launch with a small budget leaves its unsolved queries' trees and counters behind, a later
+    launch continues them (in any order, alone or pooled) -- status, path, and consumed-check count are those of ONE launch
+    with the full budget, which in turn equals the oracle (test_plan_matches_oracle).  Two continuations in a row as well."""
+    import torch
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.batch import BatchPlanner, PlanState
+    pi, sc, orc = _mk("SawyerPushObstacle-v0", oracle_mod)
+    bp = BatchPlanner(sc)
+    E = 256
+    qa, row = sample_states(pi, 8000, 47, "near")
+    ov, _ = orc.is_valid_batch(qa, row, samples_per_env=len(qa))
+    good = qa[ov == 1]
+    starts = np.repeat(row, E, axis=0)
+    goals = starts.copy()
+    starts[:, pi.ref_joint_pos_indexes] = good[:E]
+    goals[:, pi.ref_joint_pos_indexes] = good[E:2 * E]
+    goals[:8] = starts[:8]                                      # trivial queries
+    goals[8:12, pi.ref_joint_pos_indexes] = qa[ov == 0][:4]     # invalid goals: final whatever the budget
+    s, g = torch.from_numpy(starts).cuda(), torch.from_numpy(goals).cuda()
+    prm = dict(max_nodes=512, max_path=32, seed=11)             # (a short max_path: some solved queries end as "path too long")
+    ids = torch.arange(E, device="cuda", dtype=torch.int64)
+    full = [t.cpu().numpy() for t in bp.plan(s, g, max_iters=600, env_ids=ids, **prm)]
+    p1 = bp.plan(s, g, max_iters=40, env_ids=ids, keep_state=True, **prm)
+    again = torch.nonzero(p1[2] == _lib.PLAN_NO_EXACT).flatten()
+    assert 10 < len(again) < E
+    perm = again[torch.randperm(len(again), device="cuda")]    # continued in another order ...
+    half = len(perm) // 2
+    parts = [perm[:half].contiguous(), perm[half:].contiguous()]
+    out = [t.clone() for t in p1[:4]]
+    # ... the first half in two steps (40 -> 150 -> 600 iterations), the second half pooled from gathered + concatenated states
+    a = parts[0]
+    q1 = bp.plan(s[a].contiguous(), g[a].contiguous(), max_iters=150, env_ids=a, resume=p1[4].rows(a), keep_state=True, **prm)
+    q2 = bp.plan(s[a].contiguous(), g[a].contiguous(), max_iters=600, env_ids=a, resume=q1[4], **prm)
+    b = parts[1]
+    b1, b2 = b[:len(b) // 2].contiguous(), b[len(b) // 2:].contiguous()
+    r2 = bp.plan(s[b].contiguous(), g[b].contiguous(), max_iters=600, env_ids=b, resume=PlanState.cat([p1[4].rows(b1), p1[4].rows(b2)]), **prm)
+    torch.cuda.synchronize()
+    for k in range(4):
+        out[k][a] = q2[k]
+        out[k][b] = r2[k]
+    out = [t.cpu().numpy() for t in out]
+    for k in (1, 2, 3):
+        assert np.array_equal(out[k], full[k]), ("path_len", "status", "n_checks")[k - 1]
+    for e in range(E):
+        assert np.array_equal(out[0][e, :out[1][e]].view(np.uint64), full[0][e, :full[1][e]].view(np.uint64))
+    assert (full[2] == 0).sum() > E // 4 and (full[2] == _lib.PLAN_NO_EXACT).sum() > 4 and (full[2] == _lib.PLAN_INVALID_GOAL).sum() == 4

@@ -46,7 +46,7 @@ if QUICK:       # one full launch, then the default ladder over a long stream
         torch.cuda.synchronize()
         print(f"one full launch, at most {wg} workgroups: {(time.perf_counter()-t0)*1e3:.2f} ms per 4096 queries")
 for nb in ((32,) if QUICK else (8, 16, 32)):
-    for first in ((200,) if QUICK else (100, 200, 400)):
+    for first in ((100, 200, 400) if os.environ.get("MOPA_LADDER_FIRST") else (200,) if QUICK else (100, 200, 400)):
         for rmin, nret in (((512, 2), (512, 4), (1024, 4)) if QUICK else ((512, 2), (256, 3), (1024, 2))):
             dt = run(nb, first, rmin, nret)
             print(f"batches {nb:3d} first_iters {first:4d} retry_min {rmin:5d} retry_streams {nret}: {dt*1e3:8.1f} ms  {dt*1e3/nb:6.2f} ms/batch  {nb*E/dt/1e3:7.1f} k plans/s", flush=True)

@@ -774,11 +774,11 @@ def main():
     if not args.no_rollout:
         if world == 1:
             ro["rollout"] = rollout_section(torch, ENV, args.envs, device, 3)
-            ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 100, async_planner=True)
-            ro["rollout_async_graphs"] = rollout_section(torch, ENV, args.envs, device, 100, async_planner=True, use_graphs=True)
-        ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 100, world, async_planner=True)
+            ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True)     # (a retry launch lives ~25 calls: 300 calls = 12 of its cycles)
+            ro["rollout_async_graphs"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True, use_graphs=True)
+        ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 300, world, async_planner=True)
         # BASELINE config 5: SawyerAssemblyObstacle with the IK action space, 8192 envs per GPU
-        ro["rollout_assembly_ik"] = rollout_section(torch, "SawyerAssemblyObstacle-v0", 2 * args.envs, device, 60, world, async_planner=True,
+        ro["rollout_assembly_ik"] = rollout_section(torch, "SawyerAssemblyObstacle-v0", 2 * args.envs, device, 120, world, async_planner=True,
                                                     use_ik=True)
     if rank == 0:
         out.update(ro)

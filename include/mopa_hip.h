@@ -143,10 +143,11 @@ typedef struct MopaPlanParams {
        small budget can leave its unsolved queries where a later launch with a larger budget picks them up -- the result is
        that of one launch with the larger budget, without retracing the first iterations (the iteration ladder).
        Saving: tree_q_dev [E][2][max_nodes][na] doubles (+ 8 of padding), tree_p_dev [E][2][max_nodes] int32 hold the trees
-       instead of the library's scratch; state_dev [E][4] int64 receives (iterations done | -1 = the outcome does not depend
-       on the budget, start-tree size, goal-tree size, consumed checks).
+       instead of the library's scratch; state_dev [E][4] int64 receives (iterations done | -1 = "no exact solution"
+       whatever the budget | -2 = settled: solved or invalid goal; start-tree size, goal-tree size, consumed checks).
        Continuing: resume_tree_q / resume_tree_p / resume_state = those buffers (rows gathered to this launch's query order,
-       same max_nodes, same seeds / stream ids as the first launch). */
+       same max_nodes, same seeds / stream ids as the first launch); a query whose state says -2 is skipped, its outputs are
+       not written -- so a launch's whole query list can be continued right behind it on the same stream, no host in between. */
     double *tree_q_dev;
     int32_t *tree_p_dev;
     int64_t *state_dev;

@@ -78,6 +78,10 @@ class RolloutConfig:
     device_paths: bool = True         # planner rows -> trajectories (un-wrap, densification) on the device (batch.postprocess_paths);
                                       # False: the array-operation form on the host (also serves the rare queries whose
                                       # densification needs the fallback planners)
+    planner_chain: int = 1            # a first-phase launch is followed, on the same stream and with no host in between, by the
+                                      # launch that continues its unsolved queries with the full budget (the kernel skips the
+                                      # settled ones): the quick queries are picked up at an event between the two, the
+                                      # budget-exhausting ones never wait in a retry pool.  0: pooled retry launches (round 2's form)
     planner_workgroups: int = 128     # persistent workgroups of an asynchronous launch.  A planner wave holds 256 registers (two
                                       # per SIMD): launches that took every slot would stall the main stream's kernels for their
                                       # whole bulk phase.  3 streams x 128 measured best on Push (tools/rollout_w2.sh: 1.03 M agent
@@ -281,7 +285,7 @@ class BatchMoPARollout:
         self._t_dev.fill_(int(value))
         self.t_env.fill_(int(value))
 
-    def _rrt_launch(self, cur_f, target_f, ids, stream=None, iters=None, keep=False, resume=None):
+    def _rrt_launch(self, cur_f, target_f, ids, stream=None, iters=None, keep=False, resume=None, chain=False):
         """RRT-Connect (K3) for the envs `ids` whose straight line is blocked (:205-209): asynchronous, optionally on a side
         stream.  The sample stream of a query is keyed by (cfg.seed + the env's own step count, env id), so an env's plans do
         not depend on which other envs are planned with it or when."""
@@ -303,6 +307,20 @@ class BatchMoPARollout:
                 job["path"], job["plen"], job["status"] = res[0], res[1], res[2]
                 if keep:
                     job["pstate"] = res[4]      # trees + counters of the queries this budget leaves unsolved (see _seg_plan)
+                if chain:
+                    # the quick queries' results are complete HERE; what follows on this stream is the continuation of the rest
+                    job["event"] = torch.cuda.Event()
+                    job["event"].record(stream)
+                    rb = self.bp.plan(cur_f, target_f, max_iters=self.main_iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path,
+                                      seed=cfg.seed, env_ids=ids, seeds=seeds, stream=stream, max_workgroups=cfg.planner_workgroups,
+                                      resume=res[4])
+                    ev_b = torch.cuda.Event()
+                    ev_b.record(stream)
+                    job["chain"] = {"path": rb[0], "plen": rb[1], "status": rb[2], "event": ev_b}
+                    job["post_on_main"] = True      # this stream is busy with the continuation: post-process on the caller's
+                    for t in (cur_f, target_f, ids, seeds):
+                        t.record_stream(stream)
+                    return job
                 for t in (cur_f, target_f, ids, seeds):
                     t.record_stream(stream)
                 job["event"] = torch.cuda.Event()
@@ -402,22 +420,32 @@ class BatchMoPARollout:
                 elif not job["event"].query():
                     return False
             just_enqueued = True
-            ctx = torch.cuda.stream(job["stream"]) if job["stream"] is not None else contextlib.nullcontext()
+            if "lazy" in job:        # continuation half of a chained launch: its rows of the continuation's outputs
+                src, rows = job.pop("lazy")
+                with (torch.cuda.stream(job["stream"]) if job["stream"] is not None else contextlib.nullcontext()):
+                    job["path"], job["plen"], job["status"] = src["path"][rows], src["plen"][rows], src["status"][rows]
+            pstream = None if job.get("post_on_main") else job["stream"]
+            if job.get("post_on_main"):
+                for x in (job["path"], job["plen"], job["status"], job["cur"]):
+                    x.record_stream(torch.cuda.current_stream())
+            ctx = torch.cuda.stream(pstream) if pstream is not None else contextlib.nullcontext()
             with ctx:
                 from .batch import postprocess_paths
                 out, ln, need = postprocess_paths(job["path"], job["plen"], job["status"], job["cur"], self.n, cfg.ac_scale,
-                                                  cfg.interpolation, self.limits, self._valid, stream=job["stream"])
+                                                  cfg.interpolation, self.limits, self._valid, stream=pstream)
                 st = job["status"]
                 ok = st == 0           # sentinel rows (sampling_based_planner.py:64-69): -5 goal invalid, -4 no exact solution
                 job["dev"] = [out, ln, ok, st != _lib.PLAN_INVALID_GOAL, st != _lib.PLAN_NO_EXACT]
                 rows = torch.nonzero(need).flatten()
                 if len(rows):
                     sub = {k: job[k][rows].contiguous() for k in ("ids", "cur", "target", "steps", "plen", "status")}
-                    sub.update(path=job["path"][rows].contiguous(), event=None, stage="rrt", stream=job["stream"], unwrapped=True)
+                    sub.update(path=job["path"][rows].contiguous(), event=None, stage="rrt", stream=pstream, unwrapped=True)
                     job["sub"], job["sub_rows"] = sub, rows
-                if job["stream"] is not None:
+                if pstream is not None:
                     job["event"] = torch.cuda.Event()
-                    job["event"].record(job["stream"])
+                    job["event"].record(pstream)
+                else:
+                    job["event"] = None
             job["stage"] = "device"
         # stage "device": the launches above (and the sub-job, if any) have to be finished.  Right after the post-processing
         # was enqueued what is left of it is one small assemble launch (its read-backs already waited for the rest): waiting
@@ -858,8 +886,9 @@ class BatchMoPARollout:
                 if retry and self._res is not None:
                     from .batch import PlanState
                     res_in = PlanState(self._res.tree_q, self._res.tree_p, self._res.state, cfg.max_nodes, self._res.na).rows(bi)
+                chain = bool(cfg.planner_chain) and two_phase and not retry and side is not None and cfg.device_paths and self.nq <= 64
                 job = self._rrt_launch(self._q_cur[bi].contiguous(), self._q_tgt[bi].contiguous(), bi, side, iters=iters,
-                                       keep=two_phase and not retry and side is not None, resume=res_in)
+                                       keep=two_phase and not retry and side is not None, resume=res_in, chain=chain)
                 job["retry"] = retry
                 self._jobs.append(job)
         # ---- RRT-Connect jobs that are done (lock-step: all of them) ----
@@ -886,9 +915,18 @@ class BatchMoPARollout:
                 # first-phase launch: "no exact solution" may only mean that the short budget ran out -- those queries run
                 # again with the full budget (their envs stay busy); everything else is final
                 again = ~s_t & ~t(e_j)
-                self._retry_mask[jid[again]] = True
-                if "pstate" in job:
-                    self._park_state(job["pstate"], jid, again)
+                if "chain" in job:
+                    # their continuation is already running behind this launch on its stream: a job of its own, finished at
+                    # the second event
+                    rows = torch.nonzero(again).flatten()
+                    if len(rows):
+                        still.append({"ids": jid[rows], "cur": job["cur"][rows], "target": job["target"][rows], "steps": job["steps"][rows],
+                                      "event": job["chain"]["event"], "stage": "rrt", "stream": job["stream"], "iters": self.main_iters,
+                                      "retry": True, "lazy": (job["chain"], rows)})
+                else:
+                    self._retry_mask[jid[again]] = True
+                    if "pstate" in job:
+                        self._park_state(job["pstate"], jid, again)
                 self.n_retried = self.n_retried + again.sum()
                 keep = ~again
                 jid, s_t = jid[keep], s_t[keep]

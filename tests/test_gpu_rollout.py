@@ -186,13 +186,15 @@ def test_async_planner_gives_every_env_the_same_transitions(env_name):
     AC[E // 4: 3 * E // 4, 3, 1], AC[E // 4: 3 * E // 4, 3, 3] = 1.0, -1.0
     ACt = torch.tensor(AC, device="cuda")
     runs = {}
-    for mode in ("lockstep", "async", "graphs"):
+    for mode in ("lockstep", "async", "graphs", "pooled"):
         env = make_env(env_name, E, seed=12, max_episode_steps=1000)
         env.reset()
-        # (async: a first launch with 60 of the 300 iterations, the queries it does not solve run again with all 300;
-        #  graphs: the same with the fixed-shape halves of a call replayed from HIP graphs)
+        # (async: a first launch with 60 of the 300 iterations, the continuation of its unsolved queries chained right behind
+        #  it on the same stream; graphs: the same with the fixed-shape halves of a call replayed from HIP graphs; pooled: the
+        #  unsolved queries wait in a retry pool, their trees parked per env, and continue in a launch of their own)
         ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.15, max_nodes=512, max_path=128, num_trials=10, async_planner=(mode != "lockstep"),
-                                                 planner_first_iters=60, planner_min_job=1, use_graphs=(mode == "graphs")))
+                                                 planner_first_iters=60, planner_min_job=1, use_graphs=(mode == "graphs"),
+                                                 planner_chain=0 if mode == "pooled" else 1))
         seq = [[] for _ in range(E)]
         calls = n_sitting = 0
         while min(len(q) for q in seq) < T:
@@ -210,13 +212,14 @@ def test_async_planner_gives_every_env_the_same_transitions(env_name):
             assert calls < 200
         runs[mode] = (np.array([np.array(q[:T]) for q in seq]), calls, n_sitting, {k: v.clone() for k, v in ro.counters.items()},
                       getattr(ro, "n_retried", 0))
-    a, b, c = runs["lockstep"], runs["async"], runs["graphs"]
+    a, b, c, d = runs["lockstep"], runs["async"], runs["graphs"], runs["pooled"]
     assert a[2] == 0 and a[1] == T
     assert np.array_equal(_bits(a[0]), _bits(b[0]))
     assert np.array_equal(_bits(a[0]), _bits(c[0])), "graph replay changes an env's transitions"
+    assert np.array_equal(_bits(a[0]), _bits(d[0])), "pooled retry launches change an env's transitions"
     assert int(a[3]["mp"].sum()) > 0                                          # RRT-Connect was exercised ...
     if env_name == ENV:
-        assert int(a[3]["mp_fail"].sum()) > 0 and b[4] > 0                    # ... with both outcomes, and second launches
+        assert int(a[3]["mp_fail"].sum()) > 0 and b[4] > 0 and d[4] > 0       # ... with both outcomes, and second launches
 
 
 def test_pullback_kernel_equals_host_form(oracle_mod):

@@ -271,3 +271,273 @@ def obj_facts(model, dyn: DynFacts, geom_name: str = "cube", kn: float = 500.0, 
         co_mu=np.array([c[5] for c in cols]), co_rbound=np.array([c[6] for c in cols]),
         kn=float(kn), dn=float(dn), eps_v=float(eps_v), ct_max=mass / (float(dyn.timestep) * 8.0),
         inv_mass=1.0 / mass, inv_inertia=1.0 / np.asarray(m.body_inertia[ob][:3], dtype=np.float64))
+
+
+# ---- stage C: contacts of the arm and of the manipulated object, behind one constraint solve -----------------------------
+CT_MAXCON = 24        # contacts the C ABI / the test oracle keep per env and sub-step at most (array bound)
+
+
+@dataclass
+class CtFacts:
+    """What the contact + constraint stage of `csrc/mopa_contact.inc` / the test oracle takes (stage C).
+    Bodies: 0 .. nd-1 the lumped dynamic bodies of the arm (`DynFacts`), nd the manipulated object (free body: Push the
+    cube, Lift the can, Assembly the furniture with its welded parts lumped), -1 the world.
+    Shapes = the collidable geoms, posed in the frame of their body; a mesh geom (the can) enters as the bounding cylinder of
+    its hull.  Features = sample points (sphere-swept when `ft_rad` > 0) on a shape, same frame.  A directed pair (F, S) tests
+    the features of F against the signed-distance function of S; its solver parameters are MuJoCo's per-pair mix of the two
+    geoms' friction / margin / solref / solimp (env/assets/xml/common/sawyer_dependencies.xml:36, the scene XMLs)."""
+    sh_geom: np.ndarray        # [ns] collidable-geom index of the shape
+    sh_body: np.ndarray        # [ns] i32
+    sh_type: np.ndarray        # [ns] i32 (mjtGeom; mesh -> cylinder)
+    sh_size: np.ndarray        # [ns,3]
+    sh_pos: np.ndarray         # [ns,3]
+    sh_mat: np.ndarray         # [ns,9]
+    sh_rbound: np.ndarray      # [ns]
+    sh_feat0: np.ndarray       # [ns+1] i32
+    ft_pos: np.ndarray         # [nf,3]
+    ft_rad: np.ndarray         # [nf]
+    pr_f: np.ndarray           # [np] i32
+    pr_s: np.ndarray           # [np] i32
+    pr_par: np.ndarray         # [np,8]: mu, margin, K, B, d0, dmax, width, 0
+    obj_qadr: int
+    obj_mass: float
+    obj_inertia: np.ndarray    # [3] principal moments at the COM
+    obj_ipos: np.ndarray       # [3] COM in the object's body frame
+    obj_iquat: np.ndarray      # [4] principal frame in the body frame
+    obj_damping: float
+    obj_inv_mass: float
+    obj_inv_inertia: np.ndarray
+    obj_inv_mass_d: float      # 1 / (m + h damping)
+    obj_inv_inertia_d: np.ndarray
+    maxcon: int
+    maxpair: int
+    iterations: int
+    tolerance: float
+    inv_scale: float
+    precull_every: int
+    precull_margin: float
+    warmstart: int
+
+
+def _joint_space_inertia_diag(dyn: DynFacts, qpos_row: np.ndarray) -> np.ndarray:
+    """diag(M) of the lumped arm at `qpos_row` (for MuJoCo's `meaninertia`): sum over the bodies at or below each dof of the
+    body's inertia about the dof's axis (hinge) or its mass (slide), + armature."""
+    nd = dyn.nd
+    pos, mat = np.zeros((nd, 3)), np.zeros((nd, 3, 3))
+    for i in range(nd):
+        R = _quat_to_mat(dyn.rel_quat[i])
+        p = np.asarray(dyn.rel_pos[i], dtype=np.float64)
+        if dyn.parent[i] >= 0:
+            p, R = pos[dyn.parent[i]] + mat[dyn.parent[i]] @ p, mat[dyn.parent[i]] @ R
+        dq = float(qpos_row[dyn.qadr[i]] - dyn.qref[i])
+        if dyn.jtype[i] == JNT_SLIDE:
+            p = p + R @ dyn.axis[i] * dq
+        else:
+            a = dyn.axis[i] / np.linalg.norm(dyn.axis[i])
+            K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+            Rj = np.eye(3) + np.sin(dq) * K + (1 - np.cos(dq)) * (K @ K)
+            anchor = p + R @ dyn.jpos[i]
+            R = R @ Rj
+            p = anchor - R @ dyn.jpos[i]
+        pos[i], mat[i] = p, R
+    diag = np.zeros(nd)
+    for k in range(nd):
+        a = mat[k] @ dyn.axis[k]
+        anchor = pos[k] + mat[k] @ dyn.jpos[k]
+        for b in range(nd):
+            c = b
+            while c >= 0 and c != k:
+                c = int(dyn.parent[c])
+            if c != k:
+                continue
+            if dyn.jtype[k] == JNT_SLIDE:
+                diag[k] += dyn.mass[b]
+            else:
+                xx, yy, zz, xy, xz, yz = dyn.inertia[b]
+                Iw = mat[b] @ np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]) @ mat[b].T
+                r = pos[b] + mat[b] @ dyn.ipos[b] - anchor
+                diag[k] += float(a @ Iw @ a) + dyn.mass[b] * float(np.dot(np.cross(a, r), np.cross(a, r)))
+        diag[k] += dyn.armature[k]
+    return diag
+
+
+def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 12, maxpair: int = 8, iterations: int = 50,
+                  tolerance: float = 1e-10, precull_every: int = 15, precull_margin: float = 0.15, warmstart: bool = True,
+                  qpos_ref: np.ndarray = None) -> CtFacts:
+    from .mjcf import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_MESH, GEOM_PLANE, GEOM_SPHERE, JNT_FREE
+    m = model
+    if len(getattr(m, "geom_solref", ())) == 0:
+        raise ValueError("compiled scene carries no solver parameters (recompile with tools/compile_scenes.py)")
+    if maxcon > CT_MAXCON:
+        raise ValueError(f"maxcon <= {CT_MAXCON}")
+    names = list(m.body_names)
+    ob = names.index(object_body)
+    jo = int(m.body_jntadr[ob])
+    if m.body_jntnum[ob] != 1 or int(m.jnt_type[jo]) != JNT_FREE:
+        raise ValueError("the object must hang on a free joint")
+    idx = {int(b): i for i, b in enumerate(dyn.body)}
+    nd = dyn.nd
+    h = float(dyn.timestep)
+
+    def owner(b):       # -> (body index, frame body id): dyn body i, nd = object, -1 = world, None = moves but is not simulated
+        c = b
+        while c > 0:
+            if c in idx:
+                return idx[c], c
+            if c == ob:
+                return nd, ob
+            if m.body_jntnum[c] > 0:
+                return None, c
+            c = int(m.body_parent[c])
+        return -1, 0
+
+    def frame_in(b, anc):
+        p, q = np.zeros(3), np.array([1.0, 0.0, 0.0, 0.0])
+        chain = []
+        while b != anc:
+            chain.append(b)
+            b = int(m.body_parent[b])
+        for c in reversed(chain):
+            p, q = _compose(p, q, np.asarray(m.body_pos[c], dtype=np.float64), np.asarray(m.body_quat[c], dtype=np.float64))
+        return p, q
+
+    # ---- the object's inertial: the free body + everything welded below it
+    parts = []
+    for w in range(1, len(names)):
+        ow, _ = owner(w)
+        if ow != nd or float(m.body_mass[w]) <= 0.0:
+            continue
+        p, q = frame_in(w, ob)
+        R = _quat_to_mat(q)
+        xx, yy, zz, xy, xz, yz = m.body_inertia[w]
+        T = R @ np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]) @ R.T
+        parts.append((float(m.body_mass[w]), p + R @ np.asarray(m.body_ipos[w], dtype=np.float64), T))
+    mt = sum(p[0] for p in parts)
+    if mt <= 0.0:
+        raise ValueError("the object has no mass")
+    com = sum(p[0] * p[1] for p in parts) / mt
+    T = np.zeros((3, 3))
+    for pm, pc, pT in parts:
+        dd = pc - com
+        T += pT + pm * (float(dd @ dd) * np.eye(3) - np.outer(dd, dd))
+    if np.abs(T - np.diag(np.diag(T))).max() <= 1e-12 * np.abs(T).max():
+        prin, iquat = np.diag(T).copy(), np.array([1.0, 0.0, 0.0, 0.0])
+    else:
+        from scipy.spatial.transform import Rotation
+        w_, V = np.linalg.eigh(T)
+        if np.linalg.det(V) < 0:
+            V[:, 2] = -V[:, 2]
+        x, y, z, w4 = Rotation.from_matrix(V).as_quat()
+        prin, iquat = w_.copy(), np.array([w4, x, y, z])
+    damp = float(m.jnt_damping[jo])
+
+    # ---- shapes and features
+    def rbound(t, s):
+        return {GEOM_SPHERE: s[0], GEOM_CAPSULE: s[0] + s[1], GEOM_CYLINDER: float(np.hypot(s[0], s[1])), GEOM_BOX: float(np.linalg.norm(s)),
+                GEOM_PLANE: 0.0}[t]
+
+    ng = len(m.geom_type)
+    shape_of = {}
+    sh = []
+    feats_of = []
+    for g in range(ng):
+        gb = int(m.geom_body[g])
+        own, fb = owner(gb)
+        if own is None:
+            continue
+        bp, bq = frame_in(gb, fb)
+        gp, gq = _compose(bp, bq, np.asarray(m.geom_pos[g], dtype=np.float64), np.asarray(m.geom_quat[g], dtype=np.float64))
+        R = _quat_to_mat(gq)
+        t = int(m.geom_type[g])
+        size = np.asarray(m.geom_size[g], dtype=np.float64).copy()
+        pts, rad = np.zeros((0, 3)), 0.0
+        if t == GEOM_MESH:
+            did = int(m.geom_dataid[g])
+            v = np.asarray(m.mesh_vert[int(m.mesh_vertadr[did]):int(m.mesh_vertadr[did]) + int(m.mesh_vertnum[did])], dtype=np.float64)
+            zlo, zhi = float(v[:, 2].min()), float(v[:, 2].max())
+            rho = np.hypot(v[:, 0], v[:, 1])
+            # features: per distinct height ring of the hull, the vertex nearest each of 8 equally spaced directions
+            rings = []
+            for z in np.unique(np.round(v[:, 2], 4)):
+                ring = v[np.abs(v[:, 2] - z) < 1e-4]
+                ang = np.arctan2(ring[:, 1], ring[:, 0])
+                pick = sorted({int(np.argmin(np.abs(np.angle(np.exp(1j * (ang - a)))))) for a in np.arange(8) * (np.pi / 4)})
+                rings.append(ring[pick])
+            pts = np.concatenate(rings)
+            t, size = GEOM_CYLINDER, np.array([float(rho.max()), 0.5 * (zhi - zlo), 0.0])
+            gp = gp + R @ np.array([0.0, 0.0, 0.5 * (zhi + zlo)])
+            pts = pts - np.array([0.0, 0.0, 0.5 * (zhi + zlo)])
+        elif t == GEOM_SPHERE:
+            pts, rad = np.zeros((1, 3)), float(size[0])
+        elif t == GEOM_CAPSULE:
+            n = int(np.ceil(2.0 * size[1] / size[0])) + 1
+            pts = np.stack([np.zeros(n), np.zeros(n), np.linspace(-size[1], size[1], n)], axis=1)
+            rad = float(size[0])
+        elif t == GEOM_CYLINDER:
+            nr = 8 if size[0] < 0.015 else 16       # rim sampling: a flat face sinks at most r (1 - cos(pi / nr)) between two samples
+            ang = np.arange(nr) * (2.0 * np.pi / nr)
+            ring = np.stack([size[0] * np.cos(ang), size[0] * np.sin(ang), np.zeros(nr)], axis=1)
+            pts = np.concatenate([ring + [0, 0, size[1]], ring - [0, 0, size[1]], [[0, 0, size[1]], [0, 0, -size[1]]]])
+        elif t == GEOM_BOX:
+            pts = np.array([[(size[0] if i & 1 else -size[0]), (size[1] if i & 2 else -size[1]), (size[2] if i & 4 else -size[2])] for i in range(8)])
+        elif t != GEOM_PLANE:
+            raise ValueError("unsupported collider type")
+        shape_of[g] = len(sh)
+        sh.append((g, own, t, size, gp, R.ravel(), rbound(t, size)))
+        feats_of.append((gp + pts @ R.T, rad))
+
+    never = {tuple(sorted((int(a), int(b)))) for a, b in (m.meta.get("never_violating_pairs") or [])}
+    round_t = (GEOM_SPHERE, GEOM_CAPSULE)
+    pairs = []
+    used_as_f = set()
+    for a, b in m.pair_geom:
+        a, b = int(a), int(b)
+        if a not in shape_of or b not in shape_of or tuple(sorted((a, b))) in never:
+            continue
+        sa, sb = shape_of[a], shape_of[b]
+        if sh[sa][1] < 0 and sh[sb][1] < 0:
+            continue
+        ta, tb = sh[sa][2], sh[sb][2]
+        if ta in round_t:
+            dirs = [(sa, sb)]
+        elif tb in round_t:
+            dirs = [(sb, sa)]
+        else:
+            dirs = [(sa, sb), (sb, sa)]
+        mu = max(float(m.geom_friction[a]), float(m.geom_friction[b]))
+        margin = max(float(m.geom_margin[a]), float(m.geom_margin[b]))
+        tc = max(0.5 * (float(m.geom_solref[a][0]) + float(m.geom_solref[b][0])), 2.0 * h)
+        dr = 0.5 * (float(m.geom_solref[a][1]) + float(m.geom_solref[b][1]))
+        d0, dmax, width = (0.5 * (float(m.geom_solimp[a][k]) + float(m.geom_solimp[b][k])) for k in range(3))
+        if not (m.geom_solref[a][0] > 0 and m.geom_solref[b][0] > 0 and dr > 0 and 0 < d0 <= dmax < 1 and width > 0):
+            raise ValueError("unsupported solref / solimp")
+        K, B = 1.0 / (dmax * dmax * tc * tc * dr * dr), 2.0 / (dmax * tc)
+        for f_, s_ in dirs:
+            if sh[f_][2] == GEOM_PLANE:
+                continue
+            pairs.append((f_, s_, [mu, margin, K, B, d0, dmax, width, 0.0]))
+            used_as_f.add(f_)
+    # features only of shapes that appear as F
+    feat0, ft_pos, ft_rad = [0], [], []
+    for s_ in range(len(sh)):
+        if s_ in used_as_f:
+            p, r = feats_of[s_]
+            ft_pos.append(p)
+            ft_rad += [r] * len(p)
+        feat0.append(len(ft_rad))
+    # meaninertia: mean of diag(M) over the arm dofs and the object's six
+    row = np.asarray(m.qpos0 if qpos_ref is None else qpos_ref, dtype=np.float64)
+    dg = np.concatenate([_joint_space_inertia_diag(dyn, row), [mt] * 3, prin])
+    nv = nd + 6
+    return CtFacts(
+        sh_geom=np.array([s[0] for s in sh], dtype=np.int32), sh_body=np.array([s[1] for s in sh], dtype=np.int32),
+        sh_type=np.array([s[2] for s in sh], dtype=np.int32), sh_size=np.array([s[3] for s in sh]), sh_pos=np.array([s[4] for s in sh]),
+        sh_mat=np.array([s[5] for s in sh]), sh_rbound=np.array([s[6] for s in sh]), sh_feat0=np.array(feat0, dtype=np.int32),
+        ft_pos=np.concatenate(ft_pos) if ft_pos else np.zeros((0, 3)), ft_rad=np.array(ft_rad, dtype=np.float64),
+        pr_f=np.array([p[0] for p in pairs], dtype=np.int32), pr_s=np.array([p[1] for p in pairs], dtype=np.int32),
+        pr_par=np.array([p[2] for p in pairs], dtype=np.float64).reshape(-1, 8),
+        obj_qadr=int(m.jnt_qposadr[jo]), obj_mass=mt, obj_inertia=prin, obj_ipos=com, obj_iquat=iquat, obj_damping=damp,
+        obj_inv_mass=1.0 / mt, obj_inv_inertia=1.0 / prin, obj_inv_mass_d=1.0 / (mt + h * damp), obj_inv_inertia_d=1.0 / (prin + h * damp),
+        maxcon=int(maxcon), maxpair=int(maxpair), iterations=int(iterations), tolerance=float(tolerance),
+        inv_scale=1.0 / (float(dg.mean()) * max(1, nv)), precull_every=int(precull_every), precull_margin=float(precull_margin),
+        warmstart=int(bool(warmstart)))

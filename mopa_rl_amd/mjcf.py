@@ -185,6 +185,9 @@ class CompiledModel:
     act_forcerange: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), dtype=np.float64))
     opt: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))             # [4] gravity xyz, timestep
     geom_friction: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.float64))   # [ngeom] sliding friction of the collidable geoms
+    geom_solref: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), dtype=np.float64))  # [ngeom,2] (timeconst, dampratio)
+    geom_solimp: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), dtype=np.float64))  # [ngeom,3] (d0, dmax, width)
+    geom_condim: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))         # [ngeom]
     meta: Dict[str, object] = field(default_factory=dict)
 
     # ---- name lookups mirroring the mujoco-py calls the reference makes ----
@@ -220,6 +223,7 @@ class CompiledModel:
     _ACT = "act_joint act_ctrllimited act_ctrlrange".split()                  # absent in scenes compiled before actuators were kept
     _DYN = ("body_mass body_ipos body_inertia jnt_damping jnt_armature jnt_stiffness act_kind act_gain act_gear act_forcelimited "
             "act_forcerange opt geom_friction").split()                                   # absent in scenes compiled before round 3
+    _CT = "geom_solref geom_solimp geom_condim".split()                                  # absent in scenes compiled before round 4
     _LISTS = "body_names jnt_names all_geom_names geom_mesh site_names".split()
 
     def to_json(self) -> str:
@@ -228,7 +232,7 @@ class CompiledModel:
             d[k] = getattr(self, k)
         d["act_names"] = list(self.act_names)
         for k in self._ARRAYS + ([k for k in self._OPTIONAL] if len(self.mesh_vertnum) else []) + self._ACT + \
-                (self._DYN if len(self.body_mass) else []):
+                (self._DYN if len(self.body_mass) else []) + (self._CT if len(self.geom_solref) else []):
             a = getattr(self, k)
             d[k] = {"dtype": str(a.dtype), "shape": list(a.shape),
                     "data": [float(x).hex() if a.dtype.kind == "f" else int(x) for x in a.ravel()]}
@@ -241,7 +245,7 @@ class CompiledModel:
         for k in cls._LISTS:
             kw[k] = list(d[k])
         kw["act_names"] = list(d.get("act_names", []))
-        for k in cls._ARRAYS + [k for k in cls._OPTIONAL + cls._ACT + cls._DYN if k in d]:
+        for k in cls._ARRAYS + [k for k in cls._OPTIONAL + cls._ACT + cls._DYN + cls._CT if k in d]:
             e = d[k]
             if e["dtype"].startswith("float"):
                 a = np.array([float.fromhex(x) for x in e["data"]], dtype=np.float64)
@@ -555,6 +559,9 @@ class _Builder:
              "conaffinity": int(at.get("conaffinity", "1")), "margin": float(at.get("margin", "0")),
              "mesh": at.get("mesh", ""), "density": float(at.get("density", "1000")),
              "friction": _floats(at.get("friction", "1 0.005 0.0001"))[0],
+             "solref": (_floats(at.get("solref", "0.02 1")) + [1.0])[:2],
+             "solimp": (_floats(at.get("solimp", "0.9 0.95 0.001")) + [0.95, 0.001])[:3],   # (d0, dmax, width); midpoint 0.5, power 2
+             "condim": int(at.get("condim", "3")),
              "mass": (float(at["mass"]) if "mass" in at else None)}
         self.geoms.append(g)
 
@@ -765,6 +772,9 @@ class _Builder:
             act_forcerange=np.array([a["frange"] for a in acts], dtype=np.float64).reshape(-1, 2),
             opt=np.array([*self.gravity, self.timestep], dtype=np.float64),
             geom_friction=arr(cg, "friction", np.float64),
+            geom_solref=np.array([g["solref"] for g in cg], dtype=np.float64).reshape(-1, 2),
+            geom_solimp=np.array([g["solimp"] for g in cg], dtype=np.float64).reshape(-1, 3),
+            geom_condim=arr(cg, "condim", np.int32),
             meta={"source": os.path.basename(self.xml_path)},
         )
 

@@ -1514,6 +1514,7 @@ int orc_env_obs_dim(const OrcEnvDesc *d) {
 int orc_env_action_dim(const OrcEnvDesc *d) { return d->n_arm + (d->kind == 1 ? 1 : 0); }
 
 #include "mopa_oracle_dyn.inc"
+#include "mopa_oracle_contact.inc"
 
 /* dyn == NULL: the kinematic limit (K4).  dyn != NULL (SURVEY 8 f4b stage A): `_do_simulation` is the contact-free servo
  * dynamics of mopa_oracle_dyn.inc -- nsub sub-steps towards ctrl, qvel / bias_lag carried per env; obs then reports the
@@ -1544,7 +1545,8 @@ static void env_step_impl(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDe
                 for (int k = 0; k < d->n_act; k++)
                     for (int i = 0; i < dyn->nd; i++)
                         if (dyn->qadr[i] == d->act_qpos_idx[k]) dctrl[i] = clampd(ctrl[k], d->act_lo[k], d->act_hi[k]);
-                orc_dyn_step_obj(dyn, qpos, qvel, bias_lag, dctrl, dyn->nsub, dyn->obj ? qvel + dyn->nd : NULL);
+                if (dyn->ct) orc_ct_step(dyn, qpos, qvel, bias_lag, dctrl, dyn->nsub, NULL);
+                else orc_dyn_step_obj(dyn, qpos, qvel, bias_lag, dctrl, dyn->nsub, dyn->obj ? qvel + dyn->nd : NULL);
             }
             *has_prev = 1;
         } else {
@@ -1663,7 +1665,7 @@ void orc_env_step_dyn_batch(const OrcScene *s, const OrcEnvDesc *d, const OrcDyn
 #pragma omp parallel for num_threads(nthreads) schedule(static)
 #endif
     for (int64_t e = 0; e < E; e++)
-        env_step_impl(s, d, dyn, qvel + e * (dyn->nd + (dyn->obj ? 6 : 0)), bias_lag + e * dyn->nd, qpos + e * s->nq, prev_state + e * d->n_arm,
+        env_step_impl(s, d, dyn, qvel + e * (dyn->nd + ((dyn->obj || dyn->ct) ? 6 : 0)), bias_lag + e * dyn->nd, qpos + e * s->nq, prev_state + e * d->n_arm,
                       has_prev + e, ep_len + e, action ? action + e * ad : NULL, is_planner, move_mask ? move_mask[e] : 1,
                       obs + e * od, reward + e, done + e, success + e);
 }

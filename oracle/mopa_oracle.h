@@ -158,7 +158,41 @@ typedef struct OrcDynDesc {
     double gravity[3], timestep;
     int32_t nsub;                           /* sub-steps per env.step (frame_dt / timestep) */
     const OrcObjDesc *obj;                  /* NULL: stage A (nothing but the robot moves) */
+    const struct OrcCtDesc *ct;             /* stage C: contacts + constraint solver (mopa_oracle_contact.inc); excludes obj */
 } OrcDynDesc;
+
+/* (stage C) contacts of the arm, of the manipulated object and between the two, resolved by a soft-constraint
+ * solver restated from MuJoCo's published formulation -- see mopa_oracle_contact.inc.  PARITY UNPINNED.
+ * Bodies: 0 .. nd-1 the lumped dynamic bodies of the arm, nd the manipulated object (free body), -1 the world.
+ * Shapes: the collidable geoms (plane / sphere / capsule / cylinder / box; a mesh enters as its bounding cylinder), posed in
+ * the frame of their body.  Features: points (with a radius: sphere-swept) sampled on a shape, in the same body frame.
+ * Directed pairs (F, S): the features of shape F are tested against the signed-distance function of shape S. */
+#define ORC_CT_MAXCON 24
+typedef struct OrcCtDesc {
+    int32_t ns;
+    const int32_t *sh_body, *sh_type;            /* [ns] */
+    const double *sh_size, *sh_pos, *sh_mat, *sh_rbound;   /* [ns,3] [ns,3] [ns,9] [ns] */
+    const int32_t *sh_feat0;                     /* [ns + 1] features of shape s: sh_feat0[s] .. sh_feat0[s + 1] - 1 */
+    int32_t nf;
+    const double *ft_pos, *ft_rad;               /* [nf,3] (body frame of the owning shape) [nf] */
+    int32_t np;
+    const int32_t *pr_f, *pr_s;                  /* [np] */
+    const double *pr_par;                        /* [np,8]: mu, margin, K, B, d0, dmax, width, - (solref / solimp mixed per pair) */
+    int32_t obj_qadr;                            /* qpos address of the object's free joint; -1: no object */
+    double obj_mass, obj_inertia[3], obj_ipos[3], obj_iquat[4], obj_damping;   /* principal inertia at the COM (ipos, iquat in the body frame) */
+    double obj_inv_mass, obj_inv_inertia[3];     /* reciprocals for the constraint stage (M^-1) */
+    double obj_inv_mass_d, obj_inv_inertia_d[3]; /* 1 / (M + h damping) for the integration */
+    int32_t maxcon, maxpair;                     /* contacts kept per env and sub-step (<= ORC_CT_MAXCON) / per directed pair */
+    int32_t iterations;                          /* PGS sweeps at most (XML: iterations="50") */
+    double tolerance, inv_scale;                 /* stop when improvement * inv_scale < tolerance; inv_scale = 1 / (meaninertia max(1, nv)) */
+    int32_t precull_every; double precull_margin;
+    int32_t warmstart;                           /* carry the pyramid forces of persisting contacts into the next sub-step */
+} OrcCtDesc;
+typedef struct OrcCtStats { int64_t substeps, contacts, sweeps, dropped; int32_t max_contacts; } OrcCtStats;
+/* n sub-steps with contacts; qvel [nd + 6]: dofs, then the object's (v of its COM, w) in the world; stats may be NULL (accumulated) */
+void orc_ct_step(const OrcDynDesc *d, double *qpos, double *qvel, double *bias_lag, const double *ctrl, int n, OrcCtStats *stats);
+/* the contacts of one configuration (no step): rows of [dist, pos 3, normal 3, shape F, shape S, feature] -> out [maxcon,10]; returns the count */
+int orc_ct_contacts(const OrcDynDesc *d, const double *qpos, double *out);
 /* qfrc_bias [nd] (RNE with qacc = 0, gravity included) and, if M != NULL, the joint-space inertia [nd,nd] (CRB + armature) */
 void orc_dyn_forward(const OrcDynDesc *d, const double *qpos, const double *qvel /*[nd]*/, double *bias, double *M);
 /* n sub-steps of mj_step towards ctrl [nd] (already ctrl-range clamped; entries of unactuated dofs ignored); in place */

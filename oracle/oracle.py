@@ -97,6 +97,10 @@ def lib():
         L.orc_dyn_step.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp, C.c_int]
         L.orc_dyn_step_obj.restype = None
         L.orc_dyn_step_obj.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp, C.c_int, _dp]
+        L.orc_ct_step.restype = None
+        L.orc_ct_step.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp, C.c_int, C.c_void_p]
+        L.orc_ct_contacts.restype = C.c_int
+        L.orc_ct_contacts.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp]
         L.orc_env_step_dyn_batch.restype = None
         L.orc_env_step_dyn_batch.argtypes = [C.c_void_p, C.POINTER(OrcEnvDesc), C.POINTER(OrcDynDesc), C.c_int64, _dp, _dp, _dp,
                                              _dp, _u8p, _ip, _dp, C.c_int, _u8p, _dp, _dp, _u8p, _u8p, C.c_int]
@@ -144,16 +148,36 @@ class OrcDynDesc(C.Structure):
         ("damping", _dp), ("armature", _dp), ("limited", _ip), ("lo", _dp), ("hi", _dp),
         ("actuated", _ip), ("kp", _dp), ("force_lo", _dp), ("force_hi", _dp), ("gravcomp", _ip),
         ("gravity", C.c_double * 3), ("timestep", C.c_double), ("nsub", C.c_int32), ("obj", C.POINTER(OrcObjDesc)),
+        ("ct", C.c_void_p),
     ]
+
+
+class OrcCtDesc(C.Structure):
+    _fields_ = [
+        ("ns", C.c_int32), ("sh_body", _ip), ("sh_type", _ip), ("sh_size", _dp), ("sh_pos", _dp), ("sh_mat", _dp), ("sh_rbound", _dp),
+        ("sh_feat0", _ip), ("nf", C.c_int32), ("ft_pos", _dp), ("ft_rad", _dp),
+        ("np", C.c_int32), ("pr_f", _ip), ("pr_s", _ip), ("pr_par", _dp),
+        ("obj_qadr", C.c_int32), ("obj_mass", C.c_double), ("obj_inertia", C.c_double * 3), ("obj_ipos", C.c_double * 3),
+        ("obj_iquat", C.c_double * 4), ("obj_damping", C.c_double), ("obj_inv_mass", C.c_double), ("obj_inv_inertia", C.c_double * 3),
+        ("obj_inv_mass_d", C.c_double), ("obj_inv_inertia_d", C.c_double * 3),
+        ("maxcon", C.c_int32), ("maxpair", C.c_int32), ("iterations", C.c_int32), ("tolerance", C.c_double), ("inv_scale", C.c_double),
+        ("precull_every", C.c_int32), ("precull_margin", C.c_double), ("warmstart", C.c_int32),
+    ]
+
+
+class OrcCtStats(C.Structure):
+    _fields_ = [("substeps", C.c_int64), ("contacts", C.c_int64), ("sweeps", C.c_int64), ("dropped", C.c_int64), ("max_contacts", C.c_int32)]
 
 
 class OracleDyn:
     """The servo dynamics of mopa_oracle_dyn.inc over a `mopa_rl_amd.dynamics.DynFacts` (plain arrays)."""
 
-    def __init__(self, f, obj=None):
-        """f: DynFacts; obj: ObjFacts (stage B: the manipulated object moves under penalty contacts) or None."""
+    def __init__(self, f, obj=None, ct=None):
+        """f: DynFacts; obj: ObjFacts (stage B: the manipulated object moves under penalty contacts) or None;
+        ct: CtFacts (stage C: contacts of arm and object behind the constraint solver) or None."""
+        assert obj is None or ct is None
         self.f, self.nd = f, int(f.nd)
-        self.nv = self.nd + (6 if obj is not None else 0)       # width of a qvel row: the dofs, then the object's (v, w)
+        self.nv = self.nd + (6 if (obj is not None or ct is not None) else 0)       # width of a qvel row: the dofs, then the object's (v, w)
         self._keep = []
         d = OrcDynDesc()
 
@@ -187,6 +211,26 @@ class OracleDyn:
             o.precull_every, o.precull_margin = int(obj.precull_every), float(obj.precull_margin)
             self.obj = o
             d.obj = C.pointer(o)
+        self.ct = None
+        if ct is not None:
+            c = OrcCtDesc()
+            c.ns, c.sh_body, c.sh_type = len(ct.sh_body), ip(ct.sh_body), ip(ct.sh_type)
+            c.sh_size, c.sh_pos, c.sh_mat, c.sh_rbound, c.sh_feat0 = dp(ct.sh_size), dp(ct.sh_pos), dp(ct.sh_mat), dp(ct.sh_rbound), ip(ct.sh_feat0)
+            c.nf, c.ft_pos, c.ft_rad = len(ct.ft_rad), dp(ct.ft_pos), dp(ct.ft_rad)
+            c.np, c.pr_f, c.pr_s, c.pr_par = len(ct.pr_f), ip(ct.pr_f), ip(ct.pr_s), dp(ct.pr_par)
+            c.obj_qadr, c.obj_mass, c.obj_damping = int(ct.obj_qadr), float(ct.obj_mass), float(ct.obj_damping)
+            c.obj_inertia = (C.c_double * 3)(*[float(x) for x in ct.obj_inertia])
+            c.obj_ipos = (C.c_double * 3)(*[float(x) for x in ct.obj_ipos])
+            c.obj_iquat = (C.c_double * 4)(*[float(x) for x in ct.obj_iquat])
+            c.obj_inv_mass, c.obj_inv_mass_d = float(ct.obj_inv_mass), float(ct.obj_inv_mass_d)
+            c.obj_inv_inertia = (C.c_double * 3)(*[float(x) for x in ct.obj_inv_inertia])
+            c.obj_inv_inertia_d = (C.c_double * 3)(*[float(x) for x in ct.obj_inv_inertia_d])
+            c.maxcon, c.maxpair, c.iterations = int(ct.maxcon), int(ct.maxpair), int(ct.iterations)
+            c.tolerance, c.inv_scale = float(ct.tolerance), float(ct.inv_scale)
+            c.precull_every, c.precull_margin, c.warmstart = int(ct.precull_every), float(ct.precull_margin), int(ct.warmstart)
+            self.ct = c
+            d.ct = C.cast(C.pointer(c), C.c_void_p)
+        self.stats = OrcCtStats()
         self.desc = d
 
     def forward(self, qpos, qvel, want_M: bool = True):
@@ -197,10 +241,21 @@ class OracleDyn:
         lib().orc_dyn_forward(C.byref(self.desc), qp, vp, bias.ctypes.data_as(_dp), M.ctypes.data_as(_dp) if want_M else None)
         return bias, M
 
+    def contacts(self, qpos):
+        """stage C: the contacts of one configuration, rows [dist, pos 3, normal 3, shape F, shape S, feature]"""
+        q, qp = _d(qpos)
+        out = np.zeros((self.ct.maxcon, 10))
+        n = lib().orc_ct_contacts(C.byref(self.desc), qp, out.ctypes.data_as(_dp))
+        return out[:n]
+
     def step(self, qpos, qvel, bias_lag, ctrl, n: int = 1):
         """n sub-steps in place on copies; returns (qpos, qvel, bias_lag).  qvel: [nd], or [nd + 6] with an object."""
         q, v, lag = (np.array(x, dtype=np.float64, copy=True) for x in (qpos, qvel, bias_lag))
         c, cp = _d(ctrl)
+        if self.ct is not None:
+            assert len(v) == self.nd + 6
+            lib().orc_ct_step(C.byref(self.desc), q.ctypes.data_as(_dp), v.ctypes.data_as(_dp), lag.ctypes.data_as(_dp), cp, int(n), C.byref(self.stats))
+            return q, v, lag
         ov = v[self.nd:].ctypes.data_as(_dp) if (self.obj is not None and len(v) == self.nd + 6) else None
         lib().orc_dyn_step_obj(C.byref(self.desc), q.ctypes.data_as(_dp), v.ctypes.data_as(_dp), lag.ctypes.data_as(_dp), cp, int(n), ov)
         return q, v, lag
@@ -223,9 +278,9 @@ class OracleEnv:
     `facts` is mopa_rl_amd.kinematic_env.EnvFacts (plain name->id data, no product code runs here)."""
 
     def __init__(self, scene: "OracleScene", facts, E: int, ac_scale=0.05, distance_threshold=0.06, success_reward=150.0,
-                 max_episode_steps=250, dyn=None, obj=None):
+                 max_episode_steps=250, dyn=None, obj=None, ct=None):
         self.scene, self.E, self.nq = scene, int(E), scene.nq
-        self.dyn = OracleDyn(dyn, obj) if dyn is not None else None     # DynFacts (+ ObjFacts): env.step runs the servo dynamics
+        self.dyn = OracleDyn(dyn, obj, ct) if dyn is not None else None     # DynFacts (+ ObjFacts): env.step runs the servo dynamics
         self._keep = []
         d = OrcEnvDesc()
 

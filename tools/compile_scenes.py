@@ -26,6 +26,9 @@ def main():
     for s in SCENES:
         m = compile_mjcf(os.path.join(args.xml_dir, s + ".xml"))
         out = os.path.join(SCENE_DIR, s + ".json")
+        if os.path.exists(out):      # keep what later tools wrote into the scene's meta (tools/prove_separated_pairs.py)
+            from mopa_rl_amd.mjcf import CompiledModel
+            m.meta = {**CompiledModel.load(out).meta, **m.meta}
         m.save(out)
         print(f"{s}: nq={m.nq} bodies={len(m.body_names)} geoms={len(m.all_geom_names)} "
               f"collidable={len(m.geom_type)} pairs={len(m.pair_geom)} -> {out} ({os.path.getsize(out)} B)")

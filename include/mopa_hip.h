@@ -375,6 +375,44 @@ typedef struct MopaDynDesc {
     const MopaObjDesc *obj;           /* NULL: stage A (only the robot moves) */
 } MopaDynDesc;
 int mopa_env_attach_dynamics(MopaEnv *env, const MopaDynDesc *desc);
+/* (stage C) contacts of the arm, of the manipulated object (Push: cube, Lift: can, Assembly: furniture; a
+ * free rigid body) and between the two, two-way coupled behind ONE soft-constraint solve per sub-step.  Replaces, inside
+ * `sim.step()` of the reference's `_do_simulation` loop (env/sawyer/sawyer_push_obstacle.py:186-203, sawyer_lift_obstacle.py:
+ * 218-236, sawyer_assembly_obstacle.py:121-139; options env/assets/xml/common/sawyer_dependencies.xml:11), [3P] MuJoCo 2.0's
+ * mj_collision + mj_makeConstraint + the constraint solver + mj_Euler.  RESTATED FROM THE PUBLISHED SOLVER, PARITY UNPINNED:
+ * soft constraints with solref / solimp impedance, pyramidal friction cones (the XML's elliptic cones, noslip pass, and
+ * torsional / rolling friction are not restated), projected Gauss-Seidel with the XML's `iterations` cap and `tolerance`.
+ * Collision geometry: sampled feature points of one geom in the exact signed-distance function of the other (plane, sphere,
+ * capsule, cylinder, box; the can as the bounding cylinder of its hull).
+ * Bodies: 0 .. nd-1 the lumped dynamic bodies of the arm, nd the object, -1 the world.  Shapes are posed in the frame of
+ * their body, features likewise.  A directed pair (F, S) tests the features of shape F in the distance function of shape S;
+ * pr_par rows: mu, margin, K, B, d0, dmax, width, 0 (MuJoCo's per-pair mix of friction / margin / solref / solimp, formed on
+ * the host).  Call after mopa_env_attach_dynamics (without MopaObjDesc); qvel rows become [nd + 6]: the dofs, then the
+ * object's (velocity of its COM, angular velocity) in the world. */
+#define MOPA_CT_MAXCON 24
+typedef struct MopaCtDesc {
+    int32_t ns;
+    const int32_t *sh_body, *sh_type;                       /* [ns] */
+    const double *sh_size, *sh_pos, *sh_mat, *sh_rbound;    /* [ns,3] [ns,3] [ns,9] [ns] */
+    const int32_t *sh_feat0;                                /* [ns + 1] */
+    int32_t nf;
+    const double *ft_pos, *ft_rad;                          /* [nf,3] [nf] */
+    int32_t np;
+    const int32_t *pr_f, *pr_s;                             /* [np] */
+    const double *pr_par;                                   /* [np,8] */
+    int32_t obj_qadr;                                       /* qpos address of the object's free joint */
+    double obj_mass, obj_inertia[3], obj_ipos[3], obj_iquat[4], obj_damping;
+    double obj_inv_mass, obj_inv_inertia[3], obj_inv_mass_d, obj_inv_inertia_d[3];
+    int32_t maxcon, maxpair, iterations;
+    double tolerance, inv_scale;
+    int32_t precull_every;
+    double precull_margin;
+    int32_t warmstart;
+} MopaCtDesc;
+int mopa_env_attach_contacts(MopaEnv *env, const MopaCtDesc *desc);
+/* per-env counters of the last stepping launch: [E,4] int32 = contacts summed over the sub-steps, solver sweeps summed,
+ * contacts dropped by the caps, largest contact count of a sub-step (NULL: not recorded) */
+int mopa_env_set_contact_stats(MopaEnv *env, int32_t *stats_dev);
 int mopa_env_dyn_dofs(const MopaEnv *env);      /* nd, or -1 without dynamics */
 int mopa_env_dyn_qvel_width(const MopaEnv *env); /* nd (+ 6 with an object), or -1 */
 /* mj_forward at (qpos, qvel): bias [E,nd] <- qfrc_bias (what the env reads as gravity compensation before its next

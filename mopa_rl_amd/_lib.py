@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
-    "mopa_env_attach_dynamics", "mopa_env_dyn_dofs", "mopa_env_dyn_qvel_width", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
+    "mopa_env_attach_dynamics", "mopa_env_attach_contacts", "mopa_env_set_contact_stats", "mopa_env_dyn_dofs", "mopa_env_dyn_qvel_width", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch",
     "mopa_paths_unwrap_batch", "mopa_paths_walk_batch", "mopa_paths_assemble_batch", "mopa_interpolate_batch",
 ]
@@ -89,6 +89,19 @@ class MopaDynDesc(C.Structure):
         ("damping", _dp), ("armature", _dp), ("limited", _ip), ("lo", _dp), ("hi", _dp),
         ("actuated", _ip), ("kp", _dp), ("force_lo", _dp), ("force_hi", _dp), ("gravcomp", _ip),
         ("gravity", C.c_double * 3), ("timestep", C.c_double), ("nsub", C.c_int32), ("obj", C.POINTER(MopaObjDesc)),
+    ]
+
+
+class MopaCtDesc(C.Structure):
+    _fields_ = [
+        ("ns", C.c_int32), ("sh_body", _ip), ("sh_type", _ip), ("sh_size", _dp), ("sh_pos", _dp), ("sh_mat", _dp), ("sh_rbound", _dp),
+        ("sh_feat0", _ip), ("nf", C.c_int32), ("ft_pos", _dp), ("ft_rad", _dp),
+        ("np", C.c_int32), ("pr_f", _ip), ("pr_s", _ip), ("pr_par", _dp),
+        ("obj_qadr", C.c_int32), ("obj_mass", C.c_double), ("obj_inertia", C.c_double * 3), ("obj_ipos", C.c_double * 3),
+        ("obj_iquat", C.c_double * 4), ("obj_damping", C.c_double), ("obj_inv_mass", C.c_double), ("obj_inv_inertia", C.c_double * 3),
+        ("obj_inv_mass_d", C.c_double), ("obj_inv_inertia_d", C.c_double * 3),
+        ("maxcon", C.c_int32), ("maxpair", C.c_int32), ("iterations", C.c_int32), ("tolerance", C.c_double), ("inv_scale", C.c_double),
+        ("precull_every", C.c_int32), ("precull_margin", C.c_double), ("warmstart", C.c_int32),
     ]
 
 
@@ -154,6 +167,8 @@ def lib() -> C.CDLL:
     L.mopa_env_exec_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.mopa_env_desired_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, C.c_int32, vp, vp]
     L.mopa_env_attach_dynamics.argtypes = [vp, C.POINTER(MopaDynDesc)]
+    L.mopa_env_attach_contacts.argtypes = [vp, C.POINTER(MopaCtDesc)]
+    L.mopa_env_set_contact_stats.argtypes = [vp, vp]
     L.mopa_env_dyn_dofs.argtypes = [vp]
     L.mopa_env_dyn_qvel_width.argtypes = [vp]
     L.mopa_env_dyn_forward_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]

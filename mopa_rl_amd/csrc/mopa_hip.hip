@@ -25,51 +25,20 @@
 #include <mutex>
 #include "../../include/mopa_hip.h"
 #include "mopa_device.hpp"
+#include "mopa_host.hpp"
 
 using namespace mopa;
 
 // ---------------------------------------------------------------------------
-// error plumbing
+// error plumbing (mopa_host.hpp: fail / HIP_TRY / DeviceGuard / ON_DEVICE / DevBuf, shared with mopa_envdyn.hip)
 // ---------------------------------------------------------------------------
 static thread_local std::string g_err;
-constexpr int kMaxLdsBytes = 160 * 1024;   // LDS per CU on gfx950
-constexpr double kV5MaxReach = 32.0;        // metres: beyond this the FP32 broad phase is not used (see mopa_scene_create)
-static void plan_register_lds();            // defined with K3 (mopa_planner.inc)
-static int fail(int code, const std::string &msg) {
+int mopa_fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
-#define HIP_TRY(expr)                                                                              \
-    do {                                                                                           \
-        hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess)                                                                      \
-            return fail(MOPA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));          \
-    } while (0)
-
-// Every entry point runs on its object's device and leaves the caller's current device as it found it (a torch process
-// that touches several GPUs keeps its own notion of "current").
-class DeviceGuard {
-    int prev_ = -1;
-    bool ok_ = false, switched_ = false;
-public:
-    explicit DeviceGuard(int device) {
-        if (hipGetDevice(&prev_) != hipSuccess) return;
-        if (prev_ != device) {
-            if (hipSetDevice(device) != hipSuccess) return;
-            switched_ = true;
-        }
-        ok_ = true;
-    }
-    ~DeviceGuard() {
-        if (switched_) (void)hipSetDevice(prev_);
-    }
-    DeviceGuard(const DeviceGuard &) = delete;
-    DeviceGuard &operator=(const DeviceGuard &) = delete;
-    bool ok() const { return ok_; }
-};
-#define ON_DEVICE(dev)                                                        \
-    DeviceGuard _guard(dev);                                                  \
-    if (!_guard.ok()) return fail(MOPA_ERR_HIP, "cannot switch to the object's HIP device")
+constexpr double kV5MaxReach = 32.0;        // metres: beyond this the FP32 broad phase is not used (see mopa_scene_create)
+static void plan_register_lds();            // defined with K3 (mopa_planner.inc)
 
 extern "C" const char *mopa_last_error(void) { return g_err.c_str(); }
 extern "C" const char *mopa_version(void) { return "mopa_hip 0.1.0 (gfx950)"; }
@@ -108,11 +77,6 @@ struct SceneHdr {
 constexpr int kWavesPerBlock = 4;
 constexpr int kBlock = 64 * kWavesPerBlock;
 
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;     // bytes
-    template <class T> T *as() const { return static_cast<T *>(p); }
-};
 struct StreamScratch {
     DevBuf slab;        // lane-per-state kernels: pose slabs of the launch's waves + [profile words | tile counter]
     DevBuf mpr;         // v5: per-wave ring of deferred cylinder pairs
@@ -549,16 +513,6 @@ struct Builder {
     int add_d(const std::vector<double> &v) { int o = (int)dbl.size(); dbl.insert(dbl.end(), v.begin(), v.end()); return o; }
     int add_i(const std::vector<int32_t> &v) { int o = (int)ints.size(); ints.insert(ints.end(), v.begin(), v.end()); return o; }
 };
-
-double rbound_of(int type, const double *sz) {
-    switch (type) {
-        case G_SPHERE: return sz[0];
-        case G_CAPSULE: return sz[0] + sz[1];
-        case G_CYLINDER: return sqrt(fma(sz[1], sz[1], sz[0] * sz[0]));
-        case G_BOX: return sqrt(fma(sz[2], sz[2], fma(sz[1], sz[1], sz[0] * sz[0])));
-        default: return 0.0;
-    }
-}
 
 }  // namespace
 
@@ -1373,7 +1327,5 @@ extern "C" const char *mopa_planner_status(const MopaScene *S) { return S ? S->s
 // The planner entry points are defined in mopa_planner.inc (K3).
 #include "mopa_planner.inc"
 #include "mopa_pullback.inc"
-#include "mopa_env.inc"
-#include "mopa_dyn.inc"
 #include "mopa_ik.inc"
 #include "mopa_paths.inc"

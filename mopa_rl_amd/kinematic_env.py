@@ -18,10 +18,15 @@ the reference's 75 sub-steps of force-limited position servos with gravity compe
 `csrc/mopa_dyn.inc`, `dynamics.py`): the arm lags `desired_state` as the real one does, the obs carries joint velocities,
 `qvel` / `bias_lag` are carried per env.  Without `contacts` nothing but the robot moves.
 
-`contacts=True` (stage B, Push only) makes the cube a free rigid body with PENALTY contacts against everything MuJoCo
-would pair it with (table, bin, ground, every robot geom): it rests on the table, the gripper can push it, it slides with
-friction and tumbles -- so the Push reward can actually be earned.  This is NOT MuJoCo's constraint solver (spring-damper
-normal force, capped regularised Coulomb friction, one-way coupling robot -> object); it is labelled as such everywhere.
+`contacts=True` (stage C, all three envs; K7 `csrc/mopa_contact.inc`) adds the contacts: the arm against the scene (it stops
+at the bin walls and the table), the manipulated object (Push: cube, Lift: can, Assembly: furniture) as a free rigid body,
+and the two against each other, two-way coupled behind ONE soft-constraint solve per sub-step -- MuJoCo's constraint model
+restated from its published formulation (solref / solimp impedance, pyramidal friction cones, projected Gauss-Seidel with
+the XML's iteration cap), PARITY UNPINNED; the collision geometry is sampled feature points in exact signed-distance
+functions.  The cube can be pushed, the can pinched and lifted by friction.  `contact_options` go to
+`dynamics.contact_facts` (maxcon, maxpair, iterations, tolerance, warmstart ...).
+`contacts="penalty"` (stage B of round 3, Push only) keeps the earlier stand-in: the cube under penalty springs, one-way
+coupled (spring-damper normal force, capped regularised Coulomb friction) -- NOT a constraint solver, labelled as such.
 
 `block_invalid=True` adds the one piece of contact behaviour a kinematic arm can have: a step whose desired state is
 in collision (K1 validity kernel, same rule as the planner) is not executed -- the arm stays where it is.
@@ -43,6 +48,7 @@ from .batch import BatchPlanner, _ptr, _stream_handle, _torch
 from .scene import ENV_SPECS, load_scene, planner_inputs, qpos_joint_arrays
 
 KIND_PUSH, KIND_LIFT, KIND_ASSEMBLY = 0, 1, 2
+OBJECT_BODY = {KIND_PUSH: "cube", KIND_LIFT: "cube", KIND_ASSEMBLY: "furniture"}     # the manipulated object's free body (stage C)
 ENV_KIND = {"SawyerPushObstacle-v0": KIND_PUSH, "SawyerLiftObstacle-v0": KIND_LIFT, "SawyerAssemblyObstacle-v0": KIND_ASSEMBLY}
 
 # observation layouts == the reference's OrderedDict order (sawyer.py:317-338, then the env's own `_get_obs`)
@@ -162,7 +168,8 @@ class BatchKinematicEnv:
 
     def __init__(self, env_name: str, num_envs: int, device=None, seed: int = 0, max_episode_steps: int = 250,
                  distance_threshold: float = 0.06, success_reward: float = 150.0, ac_scale: Optional[float] = None,
-                 block_invalid: bool = False, model=None, dynamics: bool = False, frame_dt: float = 0.15, contacts: bool = False):
+                 block_invalid: bool = False, model=None, dynamics: bool = False, frame_dt: float = 0.15, contacts=False,
+                 contact_options: dict = None):
         torch = _torch()
         if env_name not in ENV_KIND:
             raise _lib.MopaError(f"no batched kinematic env for {env_name!r}")
@@ -247,9 +254,11 @@ class BatchKinematicEnv:
             dd.gravity = (C.c_double * 3)(*[float(x) for x in df.gravity])
             dd.timestep, dd.nsub = float(df.timestep), int(df.nsub)
             self.obj = None
-            if contacts:
+            self.ct = None
+            if contacts == "penalty":
+                # stage B (round 3): the Push cube under penalty springs, one-way coupled -- kept as a labelled stand-in
                 if f.kind != KIND_PUSH:
-                    raise _lib.MopaError("contacts=True: the penalty-contact object model is built for the Push cube only")
+                    raise _lib.MopaError("contacts='penalty': the penalty-contact object model is built for the Push cube only")
                 from .dynamics import obj_facts
                 self.obj = of = obj_facts(self.model, df)
                 od = _lib.MopaObjDesc()
@@ -265,8 +274,30 @@ class BatchKinematicEnv:
                 od.precull_every, od.precull_margin = int(of.precull_every), float(of.precull_margin)
                 keep.append(od)
                 dd.obj = C.pointer(od)
+            elif contacts:
+                # stage C: contacts of arm and object behind the constraint solver, all three envs
+                from .dynamics import contact_facts
+                self.ct = contact_facts(self.model, df, OBJECT_BODY[f.kind], qpos_ref=self.init_qpos_row, **(contact_options or {}))
             _lib.check(L.mopa_env_attach_dynamics(self._h, C.byref(dd)))
             assert L.mopa_env_dyn_dofs(self._h) == df.nd
+            if self.ct is not None:
+                ct = self.ct
+                cd = _lib.MopaCtDesc()
+                cd.ns, cd.sh_body, cd.sh_type = len(ct.sh_body), ip(ct.sh_body), ip(ct.sh_type)
+                cd.sh_size, cd.sh_pos, cd.sh_mat, cd.sh_rbound, cd.sh_feat0 = dp(ct.sh_size), dp(ct.sh_pos), dp(ct.sh_mat), dp(ct.sh_rbound), ip(ct.sh_feat0)
+                cd.nf, cd.ft_pos, cd.ft_rad = len(ct.ft_rad), dp(ct.ft_pos), dp(ct.ft_rad)
+                cd.np, cd.pr_f, cd.pr_s, cd.pr_par = len(ct.pr_f), ip(ct.pr_f), ip(ct.pr_s), dp(ct.pr_par)
+                cd.obj_qadr, cd.obj_mass, cd.obj_damping = int(ct.obj_qadr), float(ct.obj_mass), float(ct.obj_damping)
+                cd.obj_inertia = (C.c_double * 3)(*[float(x) for x in ct.obj_inertia])
+                cd.obj_ipos = (C.c_double * 3)(*[float(x) for x in ct.obj_ipos])
+                cd.obj_iquat = (C.c_double * 4)(*[float(x) for x in ct.obj_iquat])
+                cd.obj_inv_mass, cd.obj_inv_mass_d = float(ct.obj_inv_mass), float(ct.obj_inv_mass_d)
+                cd.obj_inv_inertia = (C.c_double * 3)(*[float(x) for x in ct.obj_inv_inertia])
+                cd.obj_inv_inertia_d = (C.c_double * 3)(*[float(x) for x in ct.obj_inv_inertia_d])
+                cd.maxcon, cd.maxpair, cd.iterations = int(ct.maxcon), int(ct.maxpair), int(ct.iterations)
+                cd.tolerance, cd.inv_scale = float(ct.tolerance), float(ct.inv_scale)
+                cd.precull_every, cd.precull_margin, cd.warmstart = int(ct.precull_every), float(ct.precull_margin), int(ct.warmstart)
+                _lib.check(L.mopa_env_attach_contacts(self._h, C.byref(cd)))
             self.nv = int(L.mopa_env_dyn_qvel_width(self._h))
             assert self.nv == df.nd + (6 if contacts else 0)
             # velocities of the dynamic dofs (arm, gripper) [+ the object's linear / angular velocity, world frame]

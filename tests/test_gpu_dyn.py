@@ -165,7 +165,7 @@ def _setup_obj(oracle_mod, E, **kw):
     env_name = "SawyerPushObstacle-v0"
     pi = planner_inputs(env_name)
     orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
-    env = make_env(env_name, E, dynamics=True, contacts=True, **kw)
+    env = make_env(env_name, E, dynamics=True, contacts="penalty", **kw)
     ref = oracle_mod.OracleEnv(orc, env.facts, E, ac_scale=env.ac_scale, dyn=env.dyn, obj=env.obj, **kw)
     return pi, orc, env, ref
 
@@ -249,7 +249,7 @@ def test_object_env_rollout_bit_identical_to_oracle(oracle_mod, torch_mod):
     assert np.abs(ref.obs[:, 24:27] - q[:, env.obj.qadr:env.obj.qadr + 3]).max() > 1e-3
 
 
-@pytest.mark.parametrize("contacts", [False, True])
+@pytest.mark.parametrize("contacts", [False, "penalty"])
 def test_workgroup_and_single_wave_forms_agree(oracle_mod, torch_mod, contacts, monkeypatch):
     """K6 has two mappings -- four waves sharing the 64 envs of a workgroup (default) and one wave per 64 envs
     (MOPA_DYN_KERNEL=wave): same arithmetic per quantity, so the same bits, for ragged batch sizes too."""
@@ -324,7 +324,7 @@ def test_waypoint_execution_with_dynamics_equals_stepwise_oracle(oracle_mod, tor
 
 
 def test_rollout_runs_on_the_dynamics_env(torch_mod):
-    """BatchMoPARollout over an env whose physics is the servo dynamics + the cube's contacts: the planner / direct routing is
+    """BatchMoPARollout over an env whose physics is the servo dynamics + contacts (stage C): the planner / direct routing is
     unchanged (it reads qpos), paths are executed through the physics, counters move, nothing goes non-finite."""
     torch = torch_mod
     from mopa_rl_amd.kinematic_env import make_env
@@ -344,3 +344,126 @@ def test_rollout_runs_on_the_dynamics_env(torch_mod):
         env.reset(out["done"].bool())
     assert n_pl > 0 and int(ro.counters["rl"].sum()) > 0 and int(ro.counters["interpolation"].sum()) > 0
     assert float(env.qvel.abs().max()) > 1e-3
+
+
+# ---- stage C: contacts of arm and object behind the constraint solver (K7, mopa_contact.inc) -------------------------------
+def _setup_ct(oracle_mod, env_name, E, contact_options=None, **kw):
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(env_name)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    env = make_env(env_name, E, dynamics=True, contacts=True, contact_options=contact_options, **kw)
+    ref = oracle_mod.OracleEnv(orc, env.facts, E, ac_scale=env.ac_scale, dyn=env.dyn, ct=env.ct, **kw)
+    return pi, orc, env, ref
+
+
+def _ct_states(env, orc, E, seed):
+    """arm around its initial pose (some rows pushed into the table / the bin), the object resting, scattered around the
+    hand, dropped from above, tilted, with random velocities -- so that rest, impact, sliding, arm-object and arm-scene
+    contacts all occur in one batch"""
+    from mopa_rl_amd.mjcf import _quat_to_mat
+    d, ct, f = env.dyn, env.ct, env.facts
+    rng = np.random.default_rng(seed)
+    q = np.tile(env.init_qpos_row, (E, 1))
+    q[:, d.qadr[:7]] += rng.normal(0, 0.2, size=(E, 7))
+    q[:, d.qadr[:7]] = np.clip(q[:, d.qadr[:7]], d.lo[:7], d.hi[:7])
+    v = np.zeros((E, d.nd + 6))
+    v[:, :7] = rng.normal(0, 0.5, size=(E, 7))
+    oq = ct.obj_qadr
+    rest = env.init_qpos_row[oq:oq + 7].copy()
+    for e in range(E):
+        xp, xq = orc.fk_bodies(q[e])
+        b = int(f.frame_body[0])
+        hand = xp[b] + _quat_to_mat(xq[b]) @ f.frame_off[0]
+        mode = e % 4
+        if mode == 0:          # where the scene puts it (resting / settling)
+            q[e, oq:oq + 7] = rest
+            q[e, oq:oq + 2] += rng.normal(0, 0.01, 2)
+        elif mode == 1:        # at the hand
+            q[e, oq:oq + 3] = hand + rng.normal(0, 0.04, 3)
+            qq = rng.normal(size=4)
+            q[e, oq + 3:oq + 7] = qq / np.linalg.norm(qq)
+        elif mode == 2:        # dropped from a little above its rest pose, tilted
+            q[e, oq:oq + 7] = rest
+            q[e, oq + 2] += rng.uniform(0.0, 0.05)
+            qq = rest[3:] + rng.normal(0, 0.1, 4)
+            q[e, oq + 3:oq + 7] = qq / np.linalg.norm(qq)
+        else:                  # anywhere
+            q[e, oq:oq + 3] = rest[:3] + rng.normal(0, [0.15, 0.15, 0.1])
+            qq = rng.normal(size=4)
+            q[e, oq + 3:oq + 7] = qq / np.linalg.norm(qq)
+        v[e, d.nd:d.nd + 3] = rng.normal(0, 0.2, 3)
+        v[e, d.nd + 3:] = rng.normal(0, 1.0, 3)
+    return q, v
+
+
+@pytest.mark.parametrize("env_name", ENVS)
+@pytest.mark.parametrize("n", [1, 4, 75])
+def test_contact_substeps_bit_exact(oracle_mod, torch_mod, env_name, n):
+    torch = torch_mod
+    E = 130                 # not a multiple of 4: the last workgroup carries idle groups
+    pi, orc, env, ref = _setup_ct(oracle_mod, env_name, E)
+    d = env.dyn
+    q, v = _ct_states(env, orc, E, seed=10 + n)
+    rng = np.random.default_rng(200 + n)
+    ctrl = q[:, d.qadr] + rng.uniform(-0.3, 0.3, size=(E, d.nd)) * np.where(d.jtype == 3, 1.0, 0.02)
+    env.set_state(torch.tensor(q, device=env.device))
+    env.qvel.copy_(torch.tensor(v, device=env.device))
+    lag0 = env.dyn_forward()[0]
+    env.bias_lag.copy_(lag0)
+    env.dyn_substeps(torch.tensor(ctrl, device=env.device), n)
+    gq, gv, gl = env.qpos.cpu().numpy(), env.qvel.cpu().numpy(), env.bias_lag.cpu().numpy()
+    lag0 = lag0.cpu().numpy()
+    touched = 0
+    for e in range(E):
+        st0 = ref.dyn.stats.contacts
+        oq, ov, ol = ref.dyn.step(q[e], v[e], lag0[e], ctrl[e], n)
+        touched += int(ref.dyn.stats.contacts > st0)
+        assert np.array_equal(_bits(gq[e]), _bits(oq)), f"env {e}: qpos (object pose included) after {n} sub-steps"
+        assert np.array_equal(_bits(gv[e]), _bits(ov)), f"env {e}: qvel (object velocity included)"
+        assert np.array_equal(_bits(gl[e]), _bits(ol)), f"env {e}: lagged bias"
+    assert touched > E // 4
+
+
+@pytest.mark.parametrize("env_name", ENVS)
+def test_contact_env_rollout_bit_identical_to_oracle(oracle_mod, torch_mod, env_name):
+    torch = torch_mod
+    E = 40
+    pi, orc, env, ref = _setup_ct(oracle_mod, env_name, E, max_episode_steps=5)
+    q, v = _ct_states(env, orc, E, seed=21)
+    env.set_state(torch.tensor(q, device=env.device))
+    ref.set_state(q)
+    rng = np.random.default_rng(5)
+    for t in range(5):
+        a = rng.uniform(-1.5, 1.5, size=(E, env.action_dim))
+        obs, rew, done, info = env.step(torch.tensor(a, device=env.device))
+        ref.step(a, nthreads=8)
+        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(ref.qpos)), f"step {t}: qpos"
+        assert np.array_equal(_bits(env.qvel.cpu().numpy()), _bits(ref.qvel)), f"step {t}: qvel"
+        assert np.array_equal(_bits(obs.cpu().numpy()), _bits(ref.obs)), f"step {t}: obs"
+        assert np.array_equal(_bits(rew.cpu().numpy()), _bits(ref.reward)), f"step {t}: reward"
+        assert np.array_equal(done.cpu().numpy(), ref.done)
+
+
+def test_contact_free_envs_equal_the_servo_dynamics(oracle_mod, torch_mod):
+    """an env in which nothing touches anything and the object is in free fall far away: K7's arm state after a step equals
+    K6's (stage A) bit for bit -- the contact stage adds exact zeros"""
+    torch = torch_mod
+    from mopa_rl_amd.kinematic_env import make_env
+    E = 64
+    a = make_env("SawyerPushObstacle-v0", E, dynamics=True, seed=2)
+    b = make_env("SawyerPushObstacle-v0", E, dynamics=True, contacts=True, seed=2)
+    q = np.tile(a.init_qpos_row, (E, 1))
+    rng = np.random.default_rng(0)
+    q[:, a.dyn.qadr[:7]] += rng.normal(0, 0.02, size=(E, 7))
+    oq = b.ct.obj_qadr
+    q[:, oq:oq + 3] = [3.0, 3.0, 50.0]
+    for env in (a, b):
+        env.set_state(torch.tensor(q, device=env.device))
+    act = torch.tensor(rng.uniform(-0.3, 0.3, size=(E, 7)), device=a.device)
+    a.step(act)
+    b.step(act)
+    qa, qb = a.qpos.cpu().numpy(), b.qpos.cpu().numpy()
+    assert np.array_equal(_bits(qa[:, a.dyn.qadr]), _bits(qb[:, a.dyn.qadr]))
+    assert np.array_equal(_bits(a.qvel.cpu().numpy()), _bits(b.qvel.cpu().numpy()[:, :a.dyn.nd]))
+    assert np.all(qb[:, oq + 2] < 50.0)            # the object fell

@@ -361,7 +361,15 @@ def _joint_space_inertia_diag(dyn: DynFacts, qpos_row: np.ndarray) -> np.ndarray
     return diag
 
 
-def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 12, maxpair: int = 8, iterations: int = 50,
+def _spread_order(n: int):
+    """indices 0 .. n-1 of points on a circle, ordered so that every prefix is well spread (bit reversal): a per-pair contact
+    cap that keeps the first few hits then keeps a support polygon, not one side of the rim"""
+    bits = max(1, int(np.ceil(np.log2(n))))
+    order = sorted(range(1 << bits), key=lambda i: int(format(i, f"0{bits}b")[::-1], 2))
+    return [i for i in order if i < n]
+
+
+def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpair: int = 4, iterations: int = 50,
                   tolerance: float = 1e-10, precull_every: int = 15, precull_margin: float = 0.15, warmstart: bool = True,
                   qpos_ref: np.ndarray = None) -> CtFacts:
     from .mjcf import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_MESH, GEOM_PLANE, GEOM_SPHERE, JNT_FREE
@@ -461,7 +469,11 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 12, maxp
             for z in np.unique(np.round(v[:, 2], 4)):
                 ring = v[np.abs(v[:, 2] - z) < 1e-4]
                 ang = np.arctan2(ring[:, 1], ring[:, 0])
-                pick = sorted({int(np.argmin(np.abs(np.angle(np.exp(1j * (ang - a)))))) for a in np.arange(8) * (np.pi / 4)})
+                pick = []
+                for a in np.arange(8)[_spread_order(8)] * (np.pi / 4):
+                    i = int(np.argmin(np.abs(np.angle(np.exp(1j * (ang - a))))))
+                    if i not in pick:
+                        pick.append(i)
                 rings.append(ring[pick])
             pts = np.concatenate(rings)
             t, size = GEOM_CYLINDER, np.array([float(rho.max()), 0.5 * (zhi - zlo), 0.0])
@@ -475,7 +487,7 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 12, maxp
             rad = float(size[0])
         elif t == GEOM_CYLINDER:
             nr = 8 if size[0] < 0.015 else 16       # rim sampling: a flat face sinks at most r (1 - cos(pi / nr)) between two samples
-            ang = np.arange(nr) * (2.0 * np.pi / nr)
+            ang = np.arange(nr)[_spread_order(nr)] * (2.0 * np.pi / nr)
             ring = np.stack([size[0] * np.cos(ang), size[0] * np.sin(ang), np.zeros(nr)], axis=1)
             pts = np.concatenate([ring + [0, 0, size[1]], ring - [0, 0, size[1]], [[0, 0, size[1]], [0, 0, -size[1]]]])
         elif t == GEOM_BOX:

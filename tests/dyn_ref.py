@@ -104,3 +104,94 @@ def bias_force(model, qpos, qvel, dyn_bodies, qadr, armature, eps=1e-6):
     Mdot = sum(dM[k] * qvel[k] for k in range(nd))
     c = Mdot @ qvel - 0.5 * np.array([qvel @ dM[k] @ qvel for k in range(nd)])
     return c + G
+
+
+# ---- stage C: one sub-step with contacts, by an independent route (tests/test_oracle_contact.py) ---------------------------
+def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl):
+    """New velocities [nd + 6] (arm dofs, then the object's COM velocity and world angular velocity) after ONE sub-step from
+    (qpos, qvel), given the oracle's contact list (rows: dist, pos 3, normal 3, shape F, shape S, feature) -- everything else
+    independently: geometric Jacobians over scipy FK of the un-lumped model, M by `mass_matrix`, the bias by finite differences,
+    the constraint forces as the exact solution (active-set NNLS) of MuJoCo's dual problem
+        min_{f >= 0}  1/2 f^T (A + R) f + f^T (J a_smooth - aref),      A = J M^-1 J^T,  R = (1 - imp) / imp diag(A)
+    with pyramidal rows J_n +- mu J_t and aref = -B J v - K imp (dist - margin)."""
+    from scipy.optimize import nnls
+    m = model
+    nd, h = dyn.nd, float(dyn.timestep)
+    bodies = [int(b) for b in dyn.body]
+    P, R = fk(m, qpos)
+    M, _ = mass_matrix(m, qpos, bodies, dyn.armature)
+    bias = bias_force(m, qpos, qvel[:nd], bodies, [int(a) for a in dyn.qadr], dyn.armature)
+    q = qpos[dyn.qadr]
+    act = np.where(dyn.actuated == 1, np.clip(dyn.kp * (ctrl - q), dyn.force_lo, dyn.force_hi), 0.0)
+    tau = -dyn.damping * qvel[:nd] - bias + np.where(dyn.gravcomp == 1, bias_lag, 0.0) + act
+    # the object: dofs = COM velocity (world), angular velocity in the principal frame
+    oq = ct.obj_qadr
+    Rb = _rot(qpos[oq + 3:oq + 7] / np.linalg.norm(qpos[oq + 3:oq + 7]))
+    c = qpos[oq:oq + 3] + Rb @ ct.obj_ipos
+    RD = Rb @ _rot(ct.obj_iquat)
+    wb = RD.T @ qvel[nd + 3:nd + 6]
+    Mo = np.concatenate([[ct.obj_mass] * 3, ct.obj_inertia])
+    Fo = ct.obj_mass * np.asarray(m.opt[:3]) - ct.obj_damping * qvel[nd:nd + 3]
+    Tb = -ct.obj_damping * wb - np.cross(wb, ct.obj_inertia * wb)
+    nv = nd + 6
+    Mfull = np.zeros((nv, nv)); Mfull[:nd, :nd] = M; Mfull[nd:, nd:] = np.diag(Mo)
+    tfull = np.concatenate([tau, Fo, Tb])
+    vfull = np.concatenate([qvel[:nd], qvel[nd:nd + 3], wb])
+    axes, anchors, types = [], [], []
+    for b in bodies:
+        j = int(m.body_jntadr[b])
+        axes.append(R[b] @ m.jnt_axis[j]); anchors.append(P[b] + R[b] @ m.jnt_pos[j]); types.append(int(m.jnt_type[j]))
+
+    def point_jac(model_body, pos, d):      # d . velocity of the material point `pos` of a model body, per unit dof velocity
+        row = np.zeros(nv)
+        on_obj = False
+        a = model_body
+        while a > 0:
+            if a in bodies:
+                i = bodies.index(a)
+                row[i] = float(d @ (axes[i] if types[i] == 2 else np.cross(axes[i], pos - anchors[i])))
+            if int(m.body_jntnum[a]) == 1 and int(m.jnt_type[int(m.body_jntadr[a])]) == 0:
+                on_obj = True
+            a = int(m.body_parent[a])
+        if on_obj:
+            row[nd:nd + 3] = d
+            row[nd + 3:] = RD.T @ np.cross(pos - c, d)
+        return row
+
+    rows, pars, dists, mus = [], [], [], []
+    pair_of = {(int(f), int(s)): k for k, (f, s) in enumerate(zip(ct.pr_f, ct.pr_s))}
+    for r in contacts:
+        dist, pos, n = r[0], r[1:4], r[4:7]
+        sf, ss = int(r[7]), int(r[8])
+        par = ct.pr_par[pair_of[(sf, ss)]]
+        e = np.array([1.0, 0.0, 0.0]) if abs(n[0]) < 0.5 else np.array([0.0, 1.0, 0.0])
+        t1 = e - n * (n @ e); t1 /= np.linalg.norm(t1)
+        t2 = np.cross(n, t1)
+        bF, bS = int(m.geom_body[int(ct.sh_geom[sf])]), int(m.geom_body[int(ct.sh_geom[ss])])
+        Jd = [point_jac(bF, pos, d) - point_jac(bS, pos, d) for d in (n, t1, t2)]
+        mu = par[0]
+        for t in (1, 2):
+            for sg in (1.0, -1.0):
+                rows.append(Jd[0] + sg * mu * Jd[t]); pars.append(par); dists.append(dist)
+    if not rows:
+        f = np.zeros(0); J = np.zeros((0, nv))
+    else:
+        J = np.array(rows)
+        Minv = np.linalg.inv(Mfull)
+        A = J @ Minv @ J.T
+        dA = np.diag(A)
+        imp, aref = np.zeros(len(rows)), np.zeros(len(rows))
+        for i, (par, dist) in enumerate(zip(pars, dists)):
+            x = abs(dist - par[1]) / par[6]
+            y = 1.0 if x >= 1 else (2 * x * x if x <= 0.5 else 1 - 2 * (1 - x) ** 2)
+            imp[i] = par[4] + y * (par[5] - par[4])
+            aref[i] = -par[3] * (J[i] @ vfull) - par[2] * imp[i] * (dist - par[1])
+        Rr = (1 - imp) / imp * dA
+        Q = A + np.diag(Rr)
+        b = J @ (Minv @ tfull) - aref
+        L = np.linalg.cholesky(Q)
+        f, _ = nnls(L.T, -np.linalg.solve(L, b), maxiter=100 * len(b))
+    Dfull = np.concatenate([dyn.damping, [ct.obj_damping] * 6])
+    qacc = np.linalg.solve(Mfull + h * np.diag(Dfull), tfull + J.T @ f)
+    vn = vfull + h * qacc
+    return np.concatenate([vn[:nd + 3], RD @ vn[nd + 3:]]), f

@@ -467,3 +467,39 @@ def test_contact_free_envs_equal_the_servo_dynamics(oracle_mod, torch_mod):
     assert np.array_equal(_bits(qa[:, a.dyn.qadr]), _bits(qb[:, a.dyn.qadr]))
     assert np.array_equal(_bits(a.qvel.cpu().numpy()), _bits(b.qvel.cpu().numpy()[:, :a.dyn.nd]))
     assert np.all(qb[:, oq + 2] < 50.0)            # the object fell
+
+
+def test_arm_stops_at_the_bin_roof_on_the_gpu(oracle_mod, torch_mod):
+    """the scenario of tests/test_oracle_contact.py::test_arm_stops_at_the_bin_roof through the env's own stepping entry point
+    (K7): the hand servoed to a point below the roof plate of the Push bin comes to rest ON the plate -- and every env's
+    state equals the oracle's, sub-step by sub-step"""
+    torch = torch_mod
+    from mopa_rl_amd.mjcf import _quat_to_mat
+    from mopa_rl_amd.scene import ENV_SPECS
+    env_name = "SawyerPushObstacle-v0"
+    E = 6
+    pi, orc, env, ref = _setup_ct(oracle_mod, env_name, E)
+    d, f, m = env.dyn, env.facts, pi.model
+    q0 = np.tile(env.init_qpos_row, (E, 1))
+    jid = [m.joint_name2id(j) for j in ENV_SPECS[env_name].robot_joints]
+    ctrl = np.zeros((E, d.nd))
+    for e in range(E):
+        qt, err, steps, ok = orc.ik_solve(q0[e], np.array([0.78 + 0.01 * e, 0.0, 1.00]), jid, int(f.frame_body[0]), f.frame_off[0], max_steps=400, tol=1e-4)
+        assert ok
+        ctrl[e] = qt[d.qadr]
+        ctrl[e, 7:] = q0[e, d.qadr[7:]]
+    env.set_state(torch.tensor(q0, device=env.device))
+    lag0 = env.dyn_forward()[0]
+    env.bias_lag.copy_(lag0)
+    oq, ov, ol = q0.copy(), np.zeros((E, d.nd + 6)), lag0.cpu().numpy().copy()
+    for k in range(10):
+        env.dyn_substeps(torch.tensor(ctrl, device=env.device), 75)
+        for e in range(E):
+            oq[e], ov[e], ol[e] = ref.dyn.step(oq[e], ov[e], ol[e], ctrl[e], 75)
+        assert np.array_equal(_bits(env.qpos.cpu().numpy()), _bits(oq)) and np.array_equal(_bits(env.qvel.cpu().numpy()), _bits(ov))
+    gq = env.qpos.cpu().numpy()
+    for e in range(E):
+        xp, xq = orc.fk_bodies(gq[e])
+        b = int(f.frame_body[0])
+        eef = xp[b] + _quat_to_mat(xq[b]) @ f.frame_off[0]
+        assert eef[2] > 1.2 and orc.is_valid(gq[e])[0] and np.abs(gq[e, d.qadr[:7]] - ctrl[e, :7]).max() > 0.1

@@ -1,0 +1,224 @@
+"""CPU tests of the contact + constraint stage of the dynamics oracle (SURVEY.md 8 f4b stage C; oracle/mopa_oracle_contact.inc):
+one contact step against an independent QP solve (tests/dyn_ref.py), the per-pair solver parameters against MuJoCo's mixing
+rules on the XML's numbers, and the behaviours the stage exists for -- objects rest, the arm stops at obstacles, the gripper
+pushes the cube, the can is pinched and lifted by friction.  PARITY WITH MuJoCo IS UNPINNED (not available here)."""
+import numpy as np
+import pytest
+
+from mopa_rl_amd.dynamics import contact_facts, dyn_facts
+from mopa_rl_amd.kinematic_env import OBJECT_BODY, ENV_KIND, env_facts
+from mopa_rl_amd.mjcf import _quat_to_mat
+from mopa_rl_amd.scene import ENV_SPECS, load_scene, planner_inputs
+from oracle import oracle as O
+
+import dyn_ref
+
+ENVS = ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"]
+
+
+def _setup(env, **kw):
+    m = load_scene(ENV_SPECS[env].scene)
+    f = env_facts(env, m)
+    d = dyn_facts(m, f)
+    q0 = np.array(m.qpos0, dtype=np.float64)
+    q0[f.arm_qpos_idx] = ENV_SPECS[env].init_qpos
+    ct = contact_facts(m, d, OBJECT_BODY[ENV_KIND[env]], qpos_ref=q0, **kw)
+    return m, f, d, ct, O.OracleDyn(d, ct=ct), q0
+
+
+def _scene(env, m):
+    pi = planner_inputs(env, m)
+    return O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+
+
+def _eef(orc, f, q):
+    xp, xq = orc.fk_bodies(q)
+    b = int(f.frame_body[0])
+    return xp[b] + _quat_to_mat(xq[b]) @ f.frame_off[0]
+
+
+def _ik(env, m, f, orc, q, tg, quat=None):
+    jid = [m.joint_name2id(j) for j in ENV_SPECS[env].robot_joints]
+    qt, err, steps, ok = orc.ik_solve(q, tg, jid, int(f.frame_body[0]), f.frame_off[0], max_steps=400, tol=1e-4, target_quat=quat)
+    assert ok
+    return qt
+
+
+def test_pair_parameters_follow_mujocos_mixing_rules():
+    """robot geoms: solref 0.008 1, solimp 0.95 0.95 0.01, margin 0.001 (sawyer_dependencies.xml:36); table / cube: MuJoCo's
+    defaults 0.02 1 / 0.9 0.95 0.001, margin 0; cube friction 0.95, everything else 1 (sawyer_push_obstacle.xml)"""
+    m, f, d, ct, od, q0 = _setup("SawyerPushObstacle-v0")
+    names = [m.body_names[int(m.geom_body[int(g)])] for g in ct.sh_geom]
+    seen = set()
+    for p in range(len(ct.pr_f)):
+        a, b = names[ct.pr_f[p]], names[ct.pr_s[p]]
+        mu, margin, K, B, d0, dmax, width = ct.pr_par[p][:7]
+        robot = [n.startswith(("right_", "head", "screen", "clawGripper", "rightclaw", "leftclaw", "controller", "pedestal")) for n in (a, b)]
+        if "cube" in (a, b) and "table" in (a, b) or ("cube" in (a, b) and "bin1" in (a, b)):
+            assert (mu, margin, d0, dmax, width) == (1.0, 0.0, 0.9, 0.95, 0.001)
+            assert np.isclose(K, 1 / (0.95 ** 2 * 0.02 ** 2)) and np.isclose(B, 2 / (0.95 * 0.02))
+            seen.add("obj-static")
+        elif all(robot):
+            assert (mu, margin, width) == (1.0, 0.001, 0.01) and d0 == dmax == 0.95
+            assert np.isclose(K, 1 / (0.95 ** 2 * 0.008 ** 2)) and np.isclose(B, 2 / (0.95 * 0.008))
+            seen.add("robot-robot")
+        elif any(robot) and "cube" in (a, b):
+            assert (mu, margin) == (1.0, 0.001) and np.isclose(d0, 0.925) and np.isclose(width, 0.0055)
+            assert np.isclose(K, 1 / (0.95 ** 2 * 0.014 ** 2))          # timeconst (0.008 + 0.02) / 2
+            seen.add("robot-obj")
+    assert seen == {"obj-static", "robot-robot", "robot-obj"}
+    # the can's solref 0.001 mixes with the table's 0.02 to 0.0105; with a finger's 0.008 to 0.0045 (>= 2 timesteps = 0.004)
+    m, f, d, ct, od, q0 = _setup("SawyerLiftObstacle-v0")
+    tcs = sorted({round(float(np.sqrt(1.0 / (p[2] * p[5] ** 2))), 6) for p in ct.pr_par})
+    assert 0.0105 in tcs and 0.0045 in tcs and min(tcs) >= 0.004
+
+
+@pytest.mark.parametrize("env", ENVS)
+def test_objects_come_to_rest(env):
+    m, f, d, ct, od, q0 = _setup(env)
+    q, v = q0.copy(), np.zeros(od.nv)
+    lag = od.forward(q, v[:d.nd], want_M=False)[0]
+    ctrl = q[d.qadr].copy()
+    for _ in range(6):
+        q, v, lag = od.step(q, v, lag, ctrl, n=75)
+    oq = ct.obj_qadr
+    z1 = q[oq + 2]
+    q, v, lag = od.step(q, v, lag, ctrl, n=75)
+    assert np.all(np.isfinite(q)) and abs(q[oq + 2] - z1) < 1e-5 and np.abs(v[d.nd:d.nd + 3]).max() < 1e-3 and np.abs(v[d.nd + 3:]).max() < 2e-2
+    assert np.abs(q[oq:oq + 2] - q0[oq:oq + 2]).max() < 2e-3          # it did not wander
+    assert od.stats.max_contacts <= ct.maxcon and od.stats.contacts > 0
+    # warm-started, a resting contact set needs a handful of sweeps, not the cap of 50
+    assert od.stats.sweeps / max(od.stats.substeps, 1) < 15
+
+
+def test_one_contact_step_equals_an_independent_qp_solve():
+    """states with arm-table, arm-cube and cube-floor contacts at once: the oracle's sub-step (PGS run to convergence) against
+    tests/dyn_ref.contact_step_reference (independent FK / Jacobians / M / bias, exact active-set solve of the dual)"""
+    env = "SawyerPushObstacle-v0"
+    m, f, d, ct, od, q0 = _setup(env, iterations=3000, tolerance=0.0, warmstart=False)
+    orc = _scene(env, m)
+    oq = ct.obj_qadr
+    q0 = q0.copy(); q0[oq:oq + 3] = [0.80, 0.30, 0.853]
+    q, v = q0.copy(), np.zeros(od.nv)
+    lag = od.forward(q, v[:d.nd], want_M=False)[0]
+    q, v, lag = od.step(q, v, lag, q0[d.qadr].copy(), n=300)
+    cz = q[oq + 2]
+    checked = 0
+    for i, tg in enumerate([np.array([0.68, 0.30, cz + 0.15]), np.array([0.68, 0.30, cz + 0.03])] + [np.array([0.68 + 0.02 * k, 0.30, cz + 0.03]) for k in range(1, 6)]):
+        qt = _ik(env, m, f, orc, q, tg)
+        ctrl = qt[d.qadr].copy(); ctrl[7:] = q[d.qadr[7:]]
+        for _ in range(6 if i < 2 else 2):
+            q, v, lag = od.step(q, v, lag, ctrl, n=74)
+            con = od.contacts(q)
+            arm = [r for r in con if ct.sh_body[int(r[7])] in range(d.nd) or ct.sh_body[int(r[8])] in range(d.nd)]
+            if i >= 2 and arm:
+                vr, fr = dyn_ref.contact_step_reference(m, d, ct, con, q, v, lag, ctrl)
+                q1, v1, _ = od.step(q, v, lag, ctrl, n=1)
+                scale = max(np.abs(v1 - v).max(), 1e-3)
+                free = np.ones(od.nv, dtype=bool)          # (a dof the sub-step ends ON its joint stop is not the reference's business)
+                free[:d.nd] = ~((d.limited == 1) & ((q1[d.qadr] <= d.lo) | (q1[d.qadr] >= d.hi)))
+                assert np.abs(v1 - vr)[free].max() < 2e-4 * scale + 1e-7, (i, np.abs(v1 - vr).max(), scale)
+                assert fr.max() > 0
+                checked += 1
+            q, v, lag = od.step(q, v, lag, ctrl, n=1)
+    assert checked >= 6
+
+
+def test_arm_stops_at_the_bin_roof():
+    """Push: the hand is servoed towards a point below the bin's roof plate (z = 1.22 .. 1.23): with the contact stage it
+    comes to rest ON the plate (at rest the deepest pair stays above the planner's -2 mm: the state is valid), the servo
+    error stays; without it (stage A) the same command drives the arm through the plate."""
+    env = "SawyerPushObstacle-v0"
+    m, f, d, ct, od, q0 = _setup(env)
+    orc = _scene(env, m)
+    free = O.OracleDyn(d)
+    tg = np.array([0.80, 0.0, 1.00])
+    qt = _ik(env, m, f, orc, q0, tg)
+    ctrl = qt[d.qadr].copy(); ctrl[7:] = q0[d.qadr[7:]]
+    q, v = q0.copy(), np.zeros(od.nv)
+    lag = od.forward(q, v[:d.nd], want_M=False)[0]
+    qf, vf, lagf = q0.copy(), np.zeros(d.nd), lag.copy()
+    through = False
+    for k in range(14):
+        q, v, lag = od.step(q, v, lag, ctrl, n=75)
+        qf, vf, lagf = free.step(qf, vf, lagf, ctrl, n=75)
+        ok, depth = orc.is_valid(q)
+        # the impact itself (force-saturated servos drive the hand onto the plate) may dent the soft contact for an instant;
+        # from then on the state is one the planner calls valid
+        assert depth > -0.005 and (ok or k == 0), "the contact stage let the arm sink past the validity threshold"
+        through = through or not orc.is_valid(qf)[0]
+    assert _eef(orc, f, qf)[2] < 1.05 and through          # stage A: went through the plate, now hangs below it
+    e = _eef(orc, f, q)
+    assert e[2] > 1.2 and np.abs(q[d.qadr[:7]] - ctrl[:7]).max() > 0.1       # stage C: resting on it, servo error stays
+    assert np.abs(v[:7]).max() < 0.05                                          # ... at rest
+    con = od.contacts(q)
+    assert len(con) > 0 and con[:, 0].min() > -0.002
+
+
+def test_gripper_pushes_the_cube():
+    """the cube set on the open table (outside the bin tunnel); the hand comes down behind it and moves along +x: the cube
+    is pushed ahead, stays on the table, and stops when the hand stops"""
+    env = "SawyerPushObstacle-v0"
+    m, f, d, ct, od, q0 = _setup(env)
+    orc = _scene(env, m)
+    oq = ct.obj_qadr
+    q0 = q0.copy(); q0[oq:oq + 3] = [0.80, 0.30, 0.853]
+    q, v = q0.copy(), np.zeros(od.nv)
+    lag = od.forward(q, v[:d.nd], want_M=False)[0]
+    q, v, lag = od.step(q, v, lag, q0[d.qadr].copy(), n=300)
+    cz, x0 = q[oq + 2], q[oq]
+    assert abs(cz - 0.85) < 1e-3                     # table top 0.82 + half the cube
+    way = [np.array([0.68, 0.30, cz + 0.15]), np.array([0.68, 0.30, cz + 0.03])] + [np.array([0.68 + 0.01 * k, 0.30, cz + 0.03]) for k in range(1, 13)]
+    for i, tg in enumerate(way):
+        qt = _ik(env, m, f, orc, q, tg)
+        ctrl = qt[d.qadr].copy(); ctrl[7:] = q[d.qadr[7:]]
+        for _ in range(8 if i < 2 else 2):
+            q, v, lag = od.step(q, v, lag, ctrl, n=75)
+        assert np.all(np.isfinite(q)) and orc.is_valid(q)[0]
+    assert 0.03 < q[oq] - x0 < 0.15 and abs(q[oq + 2] - cz) < 2e-3 and abs(q[oq + 1] - 0.30) < 0.03
+    ctrl = q[d.qadr].copy()                          # the hand holds where it is: friction stops the cube
+    for _ in range(6):
+        q, v, lag = od.step(q, v, lag, ctrl, n=75)
+    assert np.abs(v[d.nd:d.nd + 3]).max() < 1e-3
+
+
+def test_can_is_pinched_and_lifted_by_friction():
+    """Lift: the open gripper comes down over the can (pointing down), the finger servos (kp 10000, +-20 N) close on it, the
+    arm rises: the can comes along, held by friction alone (mu 0.95, can 15 g) -- and falls when the fingers open"""
+    env = "SawyerLiftObstacle-v0"
+    m, f, d, ct, od, q0 = _setup(env)
+    orc = _scene(env, m)
+    oq = ct.obj_qadr
+    down = np.array([0.0, 0.0, 1.0, 0.0])
+    q, v = q0.copy(), np.zeros(od.nv)
+    lag = od.forward(q, v[:d.nd], want_M=False)[0]
+    can = q[oq:oq + 3].copy()
+    OPEN, CLOSE = np.full(2, -0.0115), np.full(2, 0.0208)
+
+    def go(z, grip, steps, q, v, lag):
+        qt = _ik(env, m, f, orc, q, np.array([can[0], can[1], z]), quat=down)
+        ctrl = qt[d.qadr].copy(); ctrl[7:] = grip
+        for _ in range(steps):
+            q, v, lag = od.step(q, v, lag, ctrl, n=75)
+        return q, v, lag
+
+    for z in [1.40, 1.35]:
+        q, v, lag = go(z, OPEN, 6, q, v, lag)
+    for z in np.arange(1.30, 0.869, -0.05):
+        q, v, lag = go(z, OPEN, 3, q, v, lag)
+    # the grip site sits at the finger tips: 2 cm below the can's centre the pads span its body (gripped by the tips alone,
+    # at one height, the can pivots about the line through the contacts and creeps out: no torsional friction is modelled)
+    zg = can[2] - 0.02
+    q, v, lag = go(zg, OPEN, 5, q, v, lag)
+    assert np.abs(q[oq:oq + 2] - can[:2]).max() < 5e-3 and abs(_eef(orc, f, q)[2] - zg) < 5e-3       # straddling the can
+    q, v, lag = go(zg, CLOSE, 6, q, v, lag)
+    grip = q[d.qadr[7:]]
+    assert np.all(grip > -0.0100) and np.all(grip < -0.0040)          # the fingers stopped ON the can (gap 37.5 - 2 q mm vs 50 mm)
+    off = _eef(orc, f, q) - q[oq:oq + 3]
+    for z in (0.90, 0.95, 0.98):
+        q, v, lag = go(z, CLOSE, 3, q, v, lag)
+    q, v, lag = go(0.98, CLOSE, 6, q, v, lag)
+    assert q[oq + 2] > can[2] + 0.10 and np.abs(v[d.nd:d.nd + 3]).max() < 5e-3          # lifted 10+ cm and held ...
+    assert np.abs((_eef(orc, f, q) - q[oq:oq + 3]) - off).max() < 1e-3                    # ... without slipping in the grasp
+    q, v, lag = go(0.98, OPEN, 6, q, v, lag)
+    assert q[oq + 2] < can[2] + 0.01                                                          # released: back on the bin floor

@@ -1,0 +1,47 @@
+"""K7 (env.step with contacts, stage C) timing probe: ms per env.step of E envs, contacts / solver sweeps per sub-step.
+   python tools/ct_bench.py [E] [steps] [maxcon]"""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import torch
+from mopa_rl_amd import _lib
+from mopa_rl_amd.kinematic_env import make_env
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+maxcon = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+dev = torch.device("cuda:0")
+for env_name in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"):
+    for scale in (1.0, 0.0):
+        env = make_env(env_name, E, device=dev, seed=11, dynamics=True, contacts=True, max_episode_steps=1 << 30,
+                       contact_options={"maxcon": maxcon, "maxpair": min(8, maxcon)})
+        g = torch.Generator(device=dev); g.manual_seed(3)
+        acts = ((torch.rand(steps + 2, E, env.action_dim, generator=g, dtype=torch.float64, device=dev) * 2 - 1) * scale).contiguous()
+        stats = torch.zeros(E, 4, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().mopa_env_set_contact_stats(env._h, stats.data_ptr()))
+        env.reset()
+        env.step(acts[0]); env.step(acts[1])
+        torch.cuda.synchronize()
+        tot = np.zeros(4)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for t in range(steps):
+            env.step(acts[2 + t])
+            s = stats.cpu().numpy().astype(np.float64)
+            tot[:3] += s[:, :3].sum(0); tot[3] = max(tot[3], s[:, 3].max())
+        ev1.record(); torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / steps
+        nsub = env.dyn.nsub * E * steps
+        print(f"{env_name:28s} action scale {scale}: {ms:7.3f} ms per env.step of {E} envs = {E / ms / 1e3:6.3f} M env-steps/s | "
+              f"contacts/sub-step {tot[0] / nsub:5.2f} sweeps/sub-step {tot[1] / nsub:5.2f} dropped/sub-step {tot[2] / nsub:5.3f} max {int(tot[3])} "
+              f"| lds {env.ct.maxcon} contacts", flush=True)
+        L = _lib.lib()
+        if hasattr(L, "mopa_debug_ct_prof"):
+            import ctypes
+            buf = (ctypes.c_ulonglong * 8)()
+            L.mopa_debug_ct_prof(buf, 1)
+            t = np.array(list(buf), dtype=np.float64)
+            nw = (E + 3) // 4 * env.dyn.nsub * (steps + 2)
+            names = ["smooth", "precull", "cull", "rows", "pgs", "forces", "integrate", "narrow"]
+            print("    us per sub-step (lane 0 of each wave, cycles / 2400): " + "  ".join(f"{n} {t[i] / nw / 2400:.2f}" for i, n in enumerate(names)), flush=True)
+        env.close()

@@ -277,8 +277,7 @@ def env_step_section(torch, E, device, steps, with_cpu):
                                        "sample": f"the same {steps + 2} x {E} steps through the oracle's orc_env_step_batch "
                                                  "(OpenMP over envs); our C restatement, not MuJoCo"}
         blk["dynamics"] = env_dynamics_block(torch, env_name, E, device, g, with_cpu and tag == "push")
-        if tag == "push":
-            blk["dynamics_contacts"] = env_dynamics_block(torch, env_name, E, device, g, with_cpu, contacts=True)
+        blk["dynamics_contacts"] = env_dynamics_block(torch, env_name, E, device, g, with_cpu, contacts=True, steps=6)
         out[tag] = blk
     out["steps_per_s"] = out["push"]["steps_per_s"]
     out["steps_per_s_dynamics"] = out["push"]["dynamics"]["steps_per_s"]
@@ -289,7 +288,8 @@ def env_step_section(torch, E, device, steps, with_cpu):
 def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contacts=False):
     """env.step with `_do_simulation` = the reference's 75 sub-steps of force-limited position servos + gravity compensation
     on the arm's own tree (K6 `k_env_dyn4`, SURVEY.md 8 f4b stage A); contact-free: the manipulated object does not move.
-    contacts=True (stage B, Push): the cube is a free body with PENALTY contacts (labelled: not MuJoCo's solver)."""
+    contacts=True (stage C, K7 `k_env_dyn_ct`): contacts of the arm, of the manipulated object (free rigid body) and between
+    the two behind one soft-constraint solve per sub-step -- restated from MuJoCo's published solver, parity unpinned."""
     from mopa_rl_amd.kinematic_env import make_env
     from mopa_rl_amd.scene import planner_inputs
     env = make_env(env_name, E, device=device, seed=11, dynamics=True, contacts=contacts, max_episode_steps=1 << 30)
@@ -308,9 +308,11 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
     dt = time.perf_counter() - t0
     nd, nsub = env.dyn.nd, env.dyn.nsub
     bytes_per_step = 6 * nd * 8 + 2 * env.action_dim * 8 + env.obs_dim * 8 + 18       # q / qvel / lagged bias in+out, action, prev_state, obs, flags
-    what = (f"servo + object contacts: as `dynamics`, plus the cube as a free rigid body with PENALTY contacts (spring-damper normal force, capped "
-            f"regularised Coulomb friction at 26 feature points against its {len(env.obj.co_body)} MuJoCo candidate pairs; one-way coupling robot -> "
-            "object) -- a labelled stand-in, NOT MuJoCo's constraint solver") if contacts else (
+    what = (f"servo + contacts (stage C): as `dynamics`, plus contacts of the arm with the scene, the manipulated object as a free rigid body and "
+            f"arm <-> object contacts, two-way coupled behind one soft-constraint solve per sub-step: {len(env.ct.pr_f)} directed geom pairs "
+            f"({len(env.ct.ft_rad)} feature points in exact signed-distance functions), <= {env.ct.maxcon} contacts per env, MuJoCo's solref / solimp "
+            f"impedance model, pyramidal friction cones, PGS <= {env.ct.iterations} sweeps at tolerance {env.ct.tolerance:g} -- RESTATED FROM THE "
+            "PUBLISHED SOLVER, PARITY UNPINNED; not restated: elliptic cones, noslip, torsional / rolling friction") if contacts else (
            f"servo, contact-free: {nsub} sub-steps of h = {env.dyn.timestep} s per env.step on {nd} dofs (RNE bias + CRB inertia + "
            "implicit-damping Euler, kp / forcerange servos, lagged qfrc_bias as gravity compensation); joint limits = inelastic "
            "stop; the manipulated object does not move (no contacts) -- labelled, NOT MuJoCo's constraint solver")
@@ -319,15 +321,28 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
            "steps_per_s": E * steps / dt, "ms_per_batch": dt / steps * 1e3, "substeps_per_s": E * steps * nsub / dt,
            "gpu_ms_per_batch": ev0.elapsed_time(ev1) / steps,
            "algorithmic_bytes_per_env_step": bytes_per_step, "achieved_GBps": E * steps * bytes_per_step / dt / 1e9,
-           "bound": "latency of the serial chain walk + 9 x 9 solve of a sub-step (four waves share 64 envs; one workgroup per CU: 64 of 256 "
+           "bound": ("latency: 16 lanes per env, one wave per SIMD (1024 workgroups of 4 envs): chain walk + contact culling / narrow phase + "
+                     "Gauss-Seidel sweeps of a sub-step; not HBM") if contacts else
+                    "latency of the serial chain walk + 9 x 9 solve of a sub-step (four waves share 64 envs; one workgroup per CU: 64 of 256 "
                     "CUs busy at 4096 envs); not HBM"}
+    if contacts:
+        from mopa_rl_amd import _lib
+        stats = torch.zeros(E, 4, dtype=torch.int32, device=device)
+        _lib.check(_lib.lib().mopa_env_set_contact_stats(env._h, stats.data_ptr()))
+        env.step(acts[2])
+        torch.cuda.synchronize()
+        st = stats.cpu().numpy().astype(np.float64)
+        blk["contacts_per_substep"] = float(st[:, 0].sum() / (E * nsub))
+        blk["solver_sweeps_per_substep"] = float(st[:, 1].sum() / (E * nsub))
+        blk["contacts_dropped_by_the_cap_per_substep"] = float(st[:, 2].sum() / (E * nsub))
+        _lib.check(_lib.lib().mopa_env_set_contact_stats(env._h, None))
     if with_cpu:
         from oracle import oracle as O
         pi = planner_inputs(env_name)
         orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
-        n = min(E, 1024)
-        k = 4
-        ref = O.OracleEnv(orc, env.facts, n, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn, obj=env.obj)
+        n = min(E, 256 if contacts else 1024)
+        k = 3 if contacts else 4
+        ref = O.OracleEnv(orc, env.facts, n, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn, obj=env.obj, ct=env.ct)
         ref.set_state(q_init[:n].cpu().numpy())
         a_host = acts[:, :n].cpu().numpy()
         cores = host_cores()
@@ -344,7 +359,7 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
         blk["parity_mismatches_vs_oracle"] = int((chk.obs.cpu().numpy().view(np.uint64) != ref.obs.view(np.uint64)).sum()
                                                  + (chk.qvel.cpu().numpy().view(np.uint64) != ref.qvel.view(np.uint64)).sum()
                                                  + (chk.qpos.cpu().numpy().view(np.uint64) != ref.qpos.view(np.uint64)).sum())
-        one = O.OracleEnv(orc, env.facts, 64, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn, obj=env.obj)
+        one = O.OracleEnv(orc, env.facts, 64, ac_scale=env.ac_scale, max_episode_steps=1 << 30, dyn=env.dyn, obj=env.obj, ct=env.ct)
         one.set_state(q_init[:64].cpu().numpy())
         t0 = time.perf_counter()
         one.step(a_host[0][:64], nthreads=1)
@@ -361,7 +376,7 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
 SAC_GRAD_FLOATS = 145678 + 2 * 78337       # actor + two critics for obs 40 / ac 7 (the payload of sync_grads)
 
 
-def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_planner=False, use_ik=False, use_graphs=False):
+def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_planner=False, use_ik=False, use_graphs=False, dynamics=False):
     """End-to-end MoPA rollout step (mopa_rl_amd/rollout.py), SURVEY 8d configs 3 / 4: a SAC actor (stock PyTorch, random-init
     obs-256-256-256-(2 x ac) MLP, f32; a = tanh(mu + sigma * eps)) samples the action from the obs inside the timed loop,
     then per env either a direct env step or target / pull-back / straight-line pre-check / RRT-Connect / densification /
@@ -373,7 +388,8 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     from mopa_rl_amd.dist import TransitionExchange, all_reduce_mean_
     from mopa_rl_amd.kinematic_env import make_env
     from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
-    env = make_env(env_name, E, device=device, seed=21 + int(os.environ.get("RANK", "0")), max_episode_steps=250)
+    env = make_env(env_name, E, device=device, seed=21 + int(os.environ.get("RANK", "0")), max_episode_steps=250,
+                   **({"dynamics": True, "contacts": True} if dynamics else {}))
     env.reset()
     over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("MOPA_BENCH_ROLLOUT", "").split(",") if kv)}   # A/B knob
     if world > 1:
@@ -458,7 +474,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     if use_ik:
         mode += "; IK action space: the actor's Cartesian displacement + quaternion -> joint displacement through the batched damped-LS IK (K5)"
     return {"config": f"{env_name}, {E} envs per GPU x {world} GPU(s), {agent_steps} calls of agent_step; actions sampled by a random-init SAC actor "
-                      f"({env.obs.shape[1]}-256-256-256-{2 * ad} MLP, f32, tanh-Gaussian) from the obs (omega 0.7), kinematic env; {mode}",
+                      f"({env.obs.shape[1]}-256-256-256-{2 * ad} MLP, f32, tanh-Gaussian) from the obs (omega 0.7), {'DYNAMICS env (servo dynamics + contacts behind the constraint solver, K7: every env.step is 75 sub-steps)' if dynamics else 'kinematic env'}; {mode}",
             "agent_steps_per_s": n_agent_steps / dt, "env_steps_per_s": n_env_steps / dt, "s_per_agent_step_batch": dt / agent_steps,
             "envs_stepping_per_call": n_agent_steps / (world * agent_steps), "counters": c,
             "exchange": {"transition_record_bytes": tx.width * 4, "all_gather_bytes_per_rank_per_step": tx.bytes_per_step,
@@ -595,6 +611,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-plan", action="store_true", help="skip the RRT-Connect section (config 3)")
     ap.add_argument("--plan-envs", type=int, default=4096)
+    ap.add_argument("--graphs", action="store_true", help="also run the HIP-graph replay form of the asynchronous Push rollout")
     ap.add_argument("--no-env", action="store_true", help="skip the kinematic env.step section")
     ap.add_argument("--no-rollout", action="store_true", help="skip the end-to-end rollout sections (Push at 1 GPU; Lift with the "
                     "transition all-gather + gradient all-reduce at any rank count)")
@@ -775,13 +792,33 @@ def main():
         if world == 1:
             ro["rollout"] = rollout_section(torch, ENV, args.envs, device, 3)
             ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True)     # (a retry launch lives ~25 calls: 300 calls = 12 of its cycles)
-            ro["rollout_async_graphs"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True, use_graphs=True)
+            if args.graphs:          # (HIP-graph replay no longer pays: DESIGN 8; kept behind the flag)
+                ro["rollout_async_graphs"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True, use_graphs=True)
+            # the same rollout where a Push policy could actually be trained: the env with dynamics + contacts (stage C)
+            ro["rollout_async_dyn"] = rollout_section(torch, ENV, args.envs, device, 40, async_planner=True, dynamics=True)
         ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 300, world, async_planner=True)
         # BASELINE config 5: SawyerAssemblyObstacle with the IK action space, 8192 envs per GPU
         ro["rollout_assembly_ik"] = rollout_section(torch, "SawyerAssemblyObstacle-v0", 2 * args.envs, device, 120, world, async_planner=True,
                                                     use_ik=True)
     if rank == 0:
         out.update(ro)
+        # the driver keeps the END of this line: the numbers of every section once more, compact, as the last key
+        def _g(d, *ks):
+            for k in ks:
+                d = d.get(k) if isinstance(d, dict) else None
+            return d
+        out["summary"] = {
+            "checks_per_s": out.get("value"), "roofline_frac_hbm": _g(out, "roofline", "frac"), "valu_frac": _g(out, "roofline", "valu", "frac"),
+            "planner_ms_per_batch": _g(out, "planner", "ms_per_batch"), "planner_plans_per_s": _g(out, "planner", "plans_per_s"),
+            "planner_laddered_plans_per_s": _g(out, "planner", "laddered", "plans_per_s"),
+            "scenes_checks_per_s": {k: _g(v, "checks_per_s") for k, v in (out.get("scenes") or {}).items() if isinstance(v, dict)},
+            "env_steps_per_s": {k: {"kinematic": _g(v, "steps_per_s"), "dynamics": _g(v, "dynamics", "steps_per_s"),
+                                    "dynamics_contacts": _g(v, "dynamics_contacts", "steps_per_s"),
+                                    "dynamics_contacts_cpu": _g(v, "dynamics_contacts", "cpu_baseline", "value")}
+                                for k, v in (out.get("env_step") or {}).items() if isinstance(v, dict) and "steps_per_s" in v},
+            "rollout_agent_steps_per_s": {k: _g(v, "agent_steps_per_s") for k, v in ro.items()},
+            "rollout_envs_stepping_per_call": {k: _g(v, "envs_stepping_per_call") for k, v in ro.items()},
+        }
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

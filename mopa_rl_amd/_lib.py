@@ -231,7 +231,10 @@ class Scene:
         """prune_pairs (default: on, MOPA_PRUNE_PAIRS=0 turns it off): candidate pairs that the scene's compile-time proof
         (tools/prove_separated_pairs.py, `meta["never_violating_pairs"]`: a Lipschitz branch-and-bound over the joint ranges)
         shows can never reach the contact threshold are not handed to the kernels at all.  Verdicts and depths are
-        unchanged for joint values inside their ranges -- the states OMPL samples and the rollouts clip to."""
+        unchanged for joint values inside their ranges inflated by the proof's guard band (`meta["prune_guard_band"]`: 0.05 rad /
+        2 mm) -- the states OMPL samples and the rollouts clip to, and what MuJoCo's soft joint limits let through.  The reference's
+        isValidState takes ANY state (motion_planners/KinematicPlanner.cpp:253-286): `is_valid_state` here, and `BatchPlanner.
+        is_valid(guard=True)`, send a state with a joint beyond range + band through a sibling scene with the full pair list."""
         L = lib()
         m = model
         keep = []
@@ -244,6 +247,16 @@ class Scene:
         if at and float(contact_threshold) <= float(at.get("threshold", -np.inf)):
             never += list(at.get("pairs") or [])      # may touch, never reach a threshold this negative
         self.npair_pruned = 0
+        self._full = None
+        self._ctor = (model, list(passive_joint_idx), list(ignored_contacts), float(contact_threshold), float(range_), float(resolution), int(seed),
+                      int(device))
+        # the box inside which the pruning is proven: range + guard band of every limited joint (scenes proven without a band: the range)
+        band = meta.get("prune_guard_band") or {}
+        lim = np.asarray(m.jnt_limited).astype(bool) & (np.asarray(m.jnt_type) != 0)
+        bw = np.where(np.asarray(m.jnt_type) == 2, float(band.get("slide", 0.0)), float(band.get("hinge", 0.0)))
+        self.guard_adr = np.asarray(m.jnt_qposadr, dtype=np.int64)[lim]
+        self.guard_lo = (np.asarray(m.jnt_range, dtype=np.float64)[:, 0] - bw)[lim]
+        self.guard_hi = (np.asarray(m.jnt_range, dtype=np.float64)[:, 1] + bw)[lim]
         if prune_pairs and len(never) and float(contact_threshold) <= 0.0:
             drop = {(int(a), int(b)) for a, b in never} | {(int(b), int(a)) for a, b in never}
             keep_row = np.array([(int(a), int(b)) not in drop for a, b in pairs], dtype=bool)
@@ -295,6 +308,9 @@ class Scene:
         self.seed = int(seed)
 
     def close(self):
+        if getattr(self, "_full", None) is not None:
+            self._full.close()
+            self._full = None
         if getattr(self, "_h", None) is not None and self._h.value:
             lib().mopa_scene_destroy(self._h)
             self._h = C.c_void_p()
@@ -309,11 +325,28 @@ class Scene:
     def handle(self):
         return self._h
 
+    def full(self) -> "Scene":
+        """the sibling scene with the FULL candidate-pair list (created on first use): where states outside the pruning proof's
+        box -- a joint beyond its range + guard band -- are evaluated"""
+        if not self.npair_pruned:
+            return self
+        if self._full is None:
+            mdl, pas, ign, thr, rng, res, seed, dev = self._ctor
+            self._full = Scene(mdl, pas, ign, thr, range_=rng, resolution=res, seed=seed, device=dev, prune_pairs=False)
+        return self._full
+
+    def outside_guard(self, qpos_rows) -> np.ndarray:
+        """bool per qpos row: some limited joint lies beyond its range + guard band (the pruned pair list is not proven there)"""
+        q = np.atleast_2d(np.asarray(qpos_rows, dtype=np.float64))[:, self.guard_adr]
+        return ((q < self.guard_lo) | (q > self.guard_hi)).any(axis=1)
+
     # ---- single-state forms (host pointers) ----
     def is_valid_state(self, qpos, want_min_dist: bool = False):
         q, qp = _d(qpos)
         if q.shape != (self.nq,):
             raise MopaError(f"state has dimension {q.shape}, expected nq={self.nq}")
+        if self.npair_pruned and bool(self.outside_guard(q)[0]):
+            return self.full().is_valid_state(q, want_min_dist)
         v = C.c_int32(0)
         md = C.c_double(0.0)
         check(lib().mopa_is_valid_state(self._h, qp, C.byref(v), C.byref(md) if want_min_dist else None))

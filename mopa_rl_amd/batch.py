@@ -75,7 +75,10 @@ class BatchPlanner:
 
     # valid[i] for state i = qpos_env[i // samples_per_env] with active entries <- q_active[i]
     def is_valid(self, q_active, qpos_env, samples_per_env: Optional[int] = None, want_min_dist: bool = False,
-                 out=None, stream=None):
+                 out=None, stream=None, guard: bool = False):
+        """guard: states with a joint beyond its range + the pruning proof's guard band are re-evaluated with the full pair list
+        (a device-side range test, one host read of the count; off on the hot paths, whose states are sampled / clipped inside
+        the ranges -- `Scene.is_valid_state`, the reference's isValidState, always guards)."""
         torch = _torch()
         _check_f64(q_active, "q_active", self.na)
         _check_f64(qpos_env, "qpos_env", self.nq)
@@ -87,6 +90,33 @@ class BatchPlanner:
         md = torch.empty(N, dtype=torch.float64, device=q_active.device) if want_min_dist else None
         _lib.check(_lib.lib().mopa_is_valid_batch(self.scene.handle, _ptr(q_active), _ptr(qpos_env), N, spe, _ptr(valid),
                                                   _ptr(md) if md is not None else None, _stream_handle(stream)))
+        if guard and self.scene.npair_pruned and N:
+            sc = self.scene
+            dev = q_active.device
+            if getattr(self, "_guard_t", None) is None or self._guard_t[0].device != dev:
+                pos = {int(a): k for k, a in enumerate(sc.active_idx)}
+                act = [k for k, a in enumerate(sc.guard_adr) if int(a) in pos]
+                pas = [k for k, a in enumerate(sc.guard_adr) if int(a) not in pos]
+                mk = lambda a, dt: torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+                self._guard_t = (mk([pos[int(sc.guard_adr[k])] for k in act], torch.long), mk(sc.guard_lo[act], torch.float64), mk(sc.guard_hi[act], torch.float64),
+                                 mk(sc.guard_adr[pas], torch.long), mk(sc.guard_lo[pas], torch.float64), mk(sc.guard_hi[pas], torch.float64))
+            ia, la, ha, ip_, lp, hp = self._guard_t
+            qa = q_active[:, ia]
+            oor = ((qa < la) | (qa > ha)).any(dim=1)
+            if len(ip_):
+                qp = qpos_env[:, ip_]
+                oor_env = ((qp < lp) | (qp > hp)).any(dim=1)
+                oor = oor | oor_env[torch.arange(N, device=dev) // spe]
+            rows = torch.nonzero(oor).flatten()
+            if len(rows):
+                if getattr(self, "_full_bp", None) is None:
+                    self._full_bp = BatchPlanner(sc.full())
+                r = self._full_bp.is_valid(q_active[rows].contiguous(), qpos_env[rows // spe].contiguous(), samples_per_env=1,
+                                           want_min_dist=want_min_dist, stream=stream)
+                if want_min_dist:
+                    valid[rows], md[rows] = r[0], r[1]
+                else:
+                    valid[rows] = r
         return (valid, md) if want_min_dist else valid
 
     def check_motion(self, qa, qb, qpos_env, samples_per_env: Optional[int] = None, stream=None):

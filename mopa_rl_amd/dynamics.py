@@ -147,6 +147,10 @@ def dyn_facts(model, facts, frame_dt: float = 0.15) -> DynFacts:
         i = int(np.where(qadr == int(facts.act_qpos_idx[k]))[0][0])
         if int(m.act_kind[k]) != 1:
             raise ValueError("only position servos are modelled")
+        if len(getattr(m, "act_gear", ())) and float(m.act_gear[k]) != 1.0:
+            raise ValueError("actuator gear != 1 is not modelled (the servo force is kp (ctrl - q) on the joint itself)")
+        if not int(m.act_ctrllimited[k]):
+            raise ValueError("the kernels clamp ctrl to the actuator's ctrlrange: an actuator without ctrllimited is not modelled")
         actuated[i], kp[i] = 1, float(m.act_gain[k])
         if m.act_forcelimited[k]:
             flo[i], fhi[i] = m.act_forcerange[k]

@@ -22,7 +22,8 @@ RRT-Connect query is one batched GPU launch over all envs that need it; env step
 The ragged bookkeeping of planner paths (a minority of envs per step) is done on the host in numpy with the same
 arithmetic as the scalar code, so that results equal the per-env reference loop bit for bit (tests/test_gpu_rollout.py).
 RNG streams: the RRT-Connect query of env e at agent step t uses (seed + t, stream e); the fallback planners inside the
-densification use streams E + e (simple planner) and 2E + e (main planner).
+densification use streams E + e (simple planner) and 2E + e (main planner); e is the GLOBAL env id (`env_id_base` + row) and
+E the global env count (`env_id_total`), so a sharded rollout draws what the unsharded one draws.
 """
 from __future__ import annotations
 
@@ -63,6 +64,11 @@ class RolloutConfig:
     max_nodes: int = 1024
     max_path: int = 256
     seed: int = 1234
+    # data-parallel runs (sample streams keyed by (seed, GLOBAL env id, iteration), so results do not depend on how
+    # the envs are sharded): this rank's envs are rows env_id_base .. env_id_base + E - 1 of env_id_total envs in all
+    # (rank * E and world * E; 0 total = this rank alone)
+    env_id_base: int = 0
+    env_id_total: int = 0
     # MoPA + IK action space (config/__init__.py --use_ik_target / --ik_target; rl/trainer.py:93-125): the policy outputs a
     # Cartesian displacement of the ik_target site (3) + a rotation quaternion (4) [+ the gripper entry]
     async_planner: bool = False       # RRT-Connect on side streams; envs waiting for a query sit out (see agent_step)
@@ -115,6 +121,9 @@ def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30, grip_
     if cfg.use_ik_target:
         raise NotImplementedError("reuse_data relabelling for the IK action space (cart_list / quat_list, rl/mopa_rollouts.py:247-262)")
     rec = out["record"]
+    if grip_qpos_idx is None and int(out["ac"].shape[1]) > n_arm:
+        raise ValueError("the env's action has a gripper entry: pass grip_qpos_idx (BatchMoPARollout.reuse_transitions does)")
+    ac_type = out["ac_type"].cpu().numpy() if (cfg.discrete_action and "ac_type" in out) else None
     ob, mr, dn, wp = (rec[k].cpu().numpy() for k in ("ob", "meta_rew", "done", "waypoint"))
     nexec = rec["n_exec"].cpu().numpy()
     extra = []
@@ -142,6 +151,8 @@ def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30, grip_
             rew = (mr[e, goal] - mr[e, start]) * cfg.discount_factor ** (-(start + 1))
             extra.append({"env": int(e), "start": start, "goal": goal, "ob": ob[e, start], "ac": ac, "rew": float(rew),
                           "done": int(dn[e, goal]), "intra_steps": goal - start - 1, "ob_next": ob[e, goal]})
+            if ac_type is not None:       # `inter_subgoal_ac["ac_type"] = ac["ac_type"]` (rl/mopa_rollouts.py:266-267)
+                extra[-1]["ac_type"] = int(ac_type[e])
     return extra
 
 
@@ -160,6 +171,13 @@ def _side_streams(dev, n):
 
 
 class BatchMoPARollout:
+    def reuse_transitions(self, out, rng, max_reuse_data: int = 30):
+        """`reuse_transitions` on a recorded step of this rollout, with the env's gripper joint supplied where its action has
+        a gripper entry (Lift)"""
+        f = self.env.facts
+        grip = int(f.grip_qpos_idx[0]) if self.ac_dim > self.n and len(f.grip_qpos_idx) else None
+        return reuse_transitions(out, self.cfg, self.n, rng, max_reuse_data=max_reuse_data, grip_qpos_idx=grip)
+
     def __init__(self, env, cfg: Optional[RolloutConfig] = None):
         torch = _torch()
         self.env = env
@@ -292,17 +310,18 @@ class BatchMoPARollout:
         torch = _torch()
         cfg = self.cfg
         seeds = (self.t_env[ids] + cfg.seed).contiguous()
+        gids = (ids + int(cfg.env_id_base)).contiguous() if cfg.env_id_base else ids       # the planner's stream id: the GLOBAL env id
         iters = self.main_iters if iters is None else int(iters)
         job = {"ids": ids, "cur": cur_f, "target": target_f, "steps": self.t_env[ids].clone(), "event": None, "stage": "rrt", "stream": stream,
                "iters": iters}
         if stream is None:
             job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=iters, max_nodes=cfg.max_nodes,
-                                                                      max_path=cfg.max_path, seed=cfg.seed, env_ids=ids, seeds=seeds)
+                                                                      max_path=cfg.max_path, seed=cfg.seed, env_ids=gids, seeds=seeds)
         else:
             stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):
                 res = self.bp.plan(cur_f, target_f, max_iters=iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path, seed=cfg.seed,
-                                   env_ids=ids, seeds=seeds, stream=stream, max_workgroups=cfg.planner_workgroups,
+                                   env_ids=gids, seeds=seeds, stream=stream, max_workgroups=cfg.planner_workgroups,
                                    keep_state=keep, resume=resume)
                 job["path"], job["plen"], job["status"] = res[0], res[1], res[2]
                 if keep:
@@ -312,16 +331,16 @@ class BatchMoPARollout:
                     job["event"] = torch.cuda.Event()
                     job["event"].record(stream)
                     rb = self.bp.plan(cur_f, target_f, max_iters=self.main_iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path,
-                                      seed=cfg.seed, env_ids=ids, seeds=seeds, stream=stream, max_workgroups=cfg.planner_workgroups,
+                                      seed=cfg.seed, env_ids=gids, seeds=seeds, stream=stream, max_workgroups=cfg.planner_workgroups,
                                       resume=res[4])
                     ev_b = torch.cuda.Event()
                     ev_b.record(stream)
                     job["chain"] = {"path": rb[0], "plen": rb[1], "status": rb[2], "event": ev_b}
                     job["post_on_main"] = True      # this stream is busy with the continuation: post-process on the caller's
-                    for t in (cur_f, target_f, ids, seeds):
+                    for t in (cur_f, target_f, ids, gids, seeds):
                         t.record_stream(stream)
                     return job
-                for t in (cur_f, target_f, ids, seeds):
+                for t in (cur_f, target_f, ids, gids, seeds):
                     t.record_stream(stream)
                 job["event"] = torch.cuda.Event()
                 job["event"].record(stream)
@@ -422,6 +441,8 @@ class BatchMoPARollout:
             just_enqueued = True
             if "lazy" in job:        # continuation half of a chained launch: its rows of the continuation's outputs
                 src, rows = job.pop("lazy")
+                if job["stream"] is not None and job.get("built") is not None:
+                    job["stream"].wait_event(job.pop("built"))
                 with (torch.cuda.stream(job["stream"]) if job["stream"] is not None else contextlib.nullcontext()):
                     job["path"], job["plen"], job["status"] = src["path"][rows], src["plen"][rows], src["status"][rows]
             pstream = None if job.get("post_on_main") else job["stream"]
@@ -519,7 +540,8 @@ class BatchMoPARollout:
         starts = torch.tensor(job["starts"][ks], device=dev)
         ends = torch.tensor(job["ends"][ks], device=dev)
         rows = job["good"][job["seg_r"][ks]]
-        ids = torch.tensor(self.E * base + job["ids_h"][rows], dtype=torch.int64, device=dev)
+        total = int(cfg.env_id_total) if cfg.env_id_total else self.E
+        ids = torch.tensor(total * base + int(cfg.env_id_base) + job["ids_h"][rows], dtype=torch.int64, device=dev)
         seeds = torch.tensor(cfg.seed + job["steps_h"][rows], dtype=torch.int64, device=dev)
         stream = job["stream"]
         job["stage"] = stage
@@ -678,6 +700,9 @@ class BatchMoPARollout:
         torch = _torch()
         if self.cfg.use_ik_target or not self.cfg.async_planner:
             raise _lib.MopaError("use_graphs serves the asynchronous joint-space rollout")
+        if getattr(self.env, "dynamics", False):
+            # waypoint execution through the physics loops over a data-dependent path length on the host: not capturable
+            raise _lib.MopaError("use_graphs serves the kinematic env (a dynamics env executes waypoints step by step on the host)")
         G = getattr(self, "_graphs", None)
         main = torch.cuda.current_stream(self.env.device)
         if G is None:
@@ -920,9 +945,17 @@ class BatchMoPARollout:
                     # the second event
                     rows = torch.nonzero(again).flatten()
                     if len(rows):
-                        still.append({"ids": jid[rows], "cur": job["cur"][rows], "target": job["target"][rows], "steps": job["steps"][rows],
-                                      "event": job["chain"]["event"], "stage": "rrt", "stream": job["stream"], "iters": self.main_iters,
-                                      "retry": True, "lazy": (job["chain"], rows)})
+                        lazy = {"ids": jid[rows], "cur": job["cur"][rows], "target": job["target"][rows], "steps": job["steps"][rows],
+                                "event": job["chain"]["event"], "stage": "rrt", "stream": job["stream"], "iters": self.main_iters,
+                                "retry": True, "lazy": (job["chain"], rows)}
+                        # its tensors come from THIS stream's ops (nonzero, gathers) and are read on the side stream later:
+                        # an event the side stream waits for, and the allocator told about the second reader
+                        lazy["built"] = torch.cuda.Event()
+                        lazy["built"].record(torch.cuda.current_stream())
+                        if job["stream"] is not None:
+                            for x in (lazy["ids"], lazy["cur"], lazy["target"], lazy["steps"], rows):
+                                x.record_stream(job["stream"])
+                        still.append(lazy)
                 else:
                     self._retry_mask[jid[again]] = True
                     if "pstate" in job:

@@ -1462,6 +1462,23 @@ done:
     return status;
 }
 
+void orc_plan_batch(const OrcScene *s, int64_t E, const double *start, const double *goal, double range, double resolution, int max_iters,
+                    int max_nodes, uint64_t seed, uint64_t env_id_base, double *path, int max_path, int32_t *status, int32_t *path_len,
+                    int64_t *n_checks, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    for (int64_t e = 0; e < E; e++) {
+        double *row = path ? path + (size_t)e * max_path * s->nq : (double *)malloc(sizeof(double) * (size_t)max_path * s->nq);
+        int pl = 0, it = 0;
+        int64_t nc = 0;
+        status[e] = orc_plan(s, start + e * s->nq, goal + e * s->nq, range, resolution, max_iters, max_nodes, seed, env_id_base + (uint64_t)e, row,
+                             max_path, &pl, &nc, &it);
+        path_len[e] = pl;
+        n_checks[e] = nc;
+        if (!path) free(row);
+    }
+}
+
 /* ------------------------------------------------------------------ */
 /*  kinematic env.step of the Sawyer obstacle envs */
 /* ------------------------------------------------------------------ */

@@ -95,6 +95,12 @@ int orc_plan(const OrcScene *s, const double *start /*[nq]*/, const double *goal
              double range, double resolution, int max_iters, int max_nodes, uint64_t seed, uint64_t env_id,
              double *path, int max_path, int *path_len, int64_t *n_checks, int *n_iters);
 
+/* E queries, OpenMP over queries (dynamic schedule: a query that runs out its budget takes 100x a quick one); env ids
+ * env_id_base + e.  path [E, max_path, nq] may be NULL (status / length / check counts only). */
+void orc_plan_batch(const OrcScene *s, int64_t E, const double *start /*[E,nq]*/, const double *goal /*[E,nq]*/, double range,
+                    double resolution, int max_iters, int max_nodes, uint64_t seed, uint64_t env_id_base, double *path, int max_path,
+                    int32_t *status /*[E]*/, int32_t *path_len /*[E]*/, int64_t *n_checks /*[E]*/, int nthreads);
+
 /* deterministic exp / tanh(x>=0) shared (as a specification) with the HIP env kernel */
 double orc_exp(double x);
 double orc_tanh_pos(double x);

@@ -65,6 +65,9 @@ def lib():
         L.orc_rng_u64.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
         L.orc_rng_uniform.restype = C.c_double
         L.orc_rng_uniform.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64]
+        L.orc_plan_batch.restype = None
+        L.orc_plan_batch.argtypes = [C.c_void_p, C.c_int64, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_uint64, _dp, C.c_int,
+                                     _ip, _ip, C.c_void_p, C.c_int]
         L.orc_plan.restype = C.c_int
         L.orc_plan.argtypes = [C.c_void_p, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                _dp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
@@ -499,6 +502,16 @@ class OracleScene:
                            int(max_steps), float(tol), float(max_update_norm), float(progress_thresh), float(reg_strength),
                            C.byref(en), C.byref(st), C.byref(su))
         return q, en.value, st.value, bool(su.value)
+
+    def plan_batch(self, start, goal, range_: float, resolution: float = 0.005, max_iters: int = 2000, max_nodes: int = 4096, seed: int = 0,
+                   env_id_base: int = 0, max_path: int = 512, nthreads: int = 1):
+        """E queries with OpenMP over queries inside the oracle; returns (status [E], path_len [E], n_checks [E])"""
+        s = np.ascontiguousarray(start, dtype=np.float64); g = np.ascontiguousarray(goal, dtype=np.float64)
+        E = len(s)
+        st = np.zeros(E, dtype=np.int32); pl = np.zeros(E, dtype=np.int32); nc = np.zeros(E, dtype=np.int64)
+        lib().orc_plan_batch(self._h, E, s.ctypes.data_as(_dp), g.ctypes.data_as(_dp), range_, resolution, max_iters, max_nodes, seed, env_id_base,
+                             None, max_path, st.ctypes.data_as(_ip), pl.ctypes.data_as(_ip), nc.ctypes.data_as(C.c_void_p), int(nthreads))
+        return st, pl, nc
 
     def plan(self, start, goal, range_: float, resolution: float = 0.005, max_iters: int = 2000,
              max_nodes: int = 4096, seed: int = 0, env_id: int = 0, max_path: int = 512):

@@ -823,3 +823,53 @@ def test_continued_planning_equals_one_full_launch(oracle_mod):
     for e in range(E):
         assert np.array_equal(out[0][e, :out[1][e]].view(np.uint64), full[0][e, :full[1][e]].view(np.uint64))
     assert (full[2] == 0).sum() > E // 4 and (full[2] == _lib.PLAN_NO_EXACT).sum() > 4 and (full[2] == _lib.PLAN_INVALID_GOAL).sum() == 4
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_states_outside_the_joint_ranges_take_the_full_pair_list(env, oracle_mod):
+    """The reference's isValidState accepts ANY state (motion_planners/KinematicPlanner.cpp:253-286), and MuJoCo's soft joint
+    limits let a reported qpos sit outside the range.  The compile-time pair pruning is proven inside range + guard band only:
+    states up to 0.5 rad (5 cm for slides) beyond every range must come back with the oracle's verdict AND depth -- through the
+    guarded entry points (`Scene.is_valid_state`, `BatchPlanner.is_valid(guard=True)`), which route them to the full list."""
+    import torch
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.batch import BatchPlanner
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(env)
+    m = pi.model
+    sc = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range)
+    assert sc.npair_pruned > 0
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    bp = BatchPlanner(sc)
+    rng = np.random.default_rng(5)
+    N = 600
+    lim = [j for j in range(len(m.jnt_names)) if m.jnt_limited[j] and int(m.jnt_type[j]) != 0]
+    rows = np.tile(np.array(m.qpos0, dtype=np.float64), (N, 1))
+    for i in range(N):
+        for j in lim:
+            lo, hi = m.jnt_range[j]
+            ext = 0.5 if int(m.jnt_type[j]) == 3 else 0.05
+            if i % 3 == 0:            # one joint beyond its range, the others inside
+                rows[i, int(m.jnt_qposadr[j])] = rng.uniform(lo, hi)
+            else:                     # every joint anywhere in the extended box
+                rows[i, int(m.jnt_qposadr[j])] = rng.uniform(lo - ext, hi + ext)
+        if i % 3 == 0:
+            j = lim[rng.integers(len(lim))]
+            lo, hi = m.jnt_range[j]
+            ext = 0.5 if int(m.jnt_type[j]) == 3 else 0.05
+            rows[i, int(m.jnt_qposadr[j])] = (lo - rng.uniform(0, ext)) if rng.random() < 0.5 else (hi + rng.uniform(0, ext))
+    outside = sc.outside_guard(rows)
+    assert outside.sum() > N // 2 and (~outside).sum() > 5
+    qa = torch.tensor(rows[:, sc.active_idx], device="cuda").contiguous()
+    qe = torch.tensor(rows, device="cuda").contiguous()
+    v, md = bp.is_valid(qa, qe, samples_per_env=1, want_min_dist=True, guard=True)
+    v, md = v.cpu().numpy().astype(bool), md.cpu().numpy()
+    ov = np.zeros(N, dtype=bool); omd = np.zeros(N)
+    for i in range(N):
+        ov[i], omd[i] = orc.is_valid(rows[i])
+    assert np.array_equal(v, ov) and np.array_equal(md.view(np.uint64), omd.view(np.uint64))
+    for i in range(0, N, 37):        # the single-state entry point (the reference's isValidState) guards by itself
+        a, d = sc.is_valid_state(rows[i], want_min_dist=True)
+        assert a == ov[i] and np.float64(d).view(np.uint64) == omd[i].view(np.uint64)
+    assert (~ov).sum() > 20 and ov.sum() > 20
+    sc.close()

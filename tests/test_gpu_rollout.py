@@ -333,3 +333,41 @@ def test_path_postprocessing_edge_cases():
     assert L.mopa_paths_unwrap_batch(0, 1, 65, 7, None, 4, None, None, None, 0.05, 1, None, None, None, None, None, None, None, None) == 1   # MOPA_ERR_INVALID_ARG
     assert L.mopa_paths_unwrap_batch(0, 0, 36, 7, None, 4, None, None, None, 0.05, 1, None, None, None, None, None, None, None, None) == 0
     assert L.mopa_interpolate_batch(ro.scene._h, 4, 7, 0, None, None, 0.05, None, None, None, None, None) == 1   # MOPA_ERR_INVALID_ARG
+
+
+def test_sharded_rollout_equals_the_unsharded_one():
+    """"results are independent of G".  A rank's rollout draws its planner sample streams by the GLOBAL env id
+    (`RolloutConfig.env_id_base` = rank * E_g, `env_id_total` = world * E_g; reference rank set-up: rl/main.py:24-35), so the
+    rows a shard produces are bit for bit the rows the unsharded rollout produces for the same envs."""
+    import torch
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    E, T, G = 128, 4, 2
+    rng = np.random.default_rng(7)
+    AC = rng.uniform(-1, 1, size=(E, T, 7)) * rng.choice([0.6, 0.9, 1.0], size=(E, T, 1))
+    AC[:, 1, 1], AC[:, 1, 3] = 1.0, -1.0           # blocked straight lines: every env plans with RRT-Connect at step 1
+    base = make_env(ENV, E, seed=12, max_episode_steps=1000)
+    base.reset()
+    q0 = base.qpos.clone()
+
+    def run(rows, id_base, total):
+        env = make_env(ENV, len(rows), seed=99, max_episode_steps=1000)
+        env.set_state(q0[rows].clone())
+        ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.15, max_nodes=512, max_path=128, num_trials=10, env_id_base=id_base, env_id_total=total))
+        out_rows = []
+        for t in range(T):
+            out = ro.agent_step(torch.tensor(AC[rows, t], device="cuda").contiguous())
+            out_rows.append(np.concatenate([out["rew"].cpu().numpy()[:, None], out["done"].cpu().numpy()[:, None].astype(np.float64),
+                                            out["intra_steps"].cpu().numpy()[:, None].astype(np.float64), env.qpos.cpu().numpy(),
+                                            out["ob_next"].cpu().numpy()], axis=1))
+        return np.stack(out_rows, axis=1), int(ro.counters["mp"].sum())
+
+    full, n_mp = run(np.arange(E), 0, E)
+    assert n_mp > E // 2
+    for g in range(G):
+        rows = np.arange(g * E // G, (g + 1) * E // G)
+        part, _ = run(rows, g * E // G, E)
+        assert np.array_equal(_bits(part), _bits(full[rows])), f"shard {g} of {G} differs from its rows of the unsharded rollout"
+    # ... and the ids matter: the second shard with rank-local ids (base 0) draws other streams
+    wrong, _ = run(np.arange(E // G, E), 0, E // G)
+    assert not np.array_equal(_bits(wrong), _bits(full[E // G:]))

@@ -238,3 +238,21 @@ def _rbound(m, g):
     if t == 7:
         return float(np.linalg.norm(m.mesh_vert, axis=1).max())
     return {2: s[0], 3: s[0] + s[1], 5: float(np.hypot(s[0], s[1])), 6: float(np.linalg.norm(s))}[t]
+
+
+def test_plan_batch_equals_plan(oracle_mod):
+    """orc_plan_batch (OpenMP over queries, the planner's CPU baseline in bench.py) returns what orc_plan returns per query"""
+    from conftest import sample_states
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs("SawyerPushObstacle-v0")
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    qa, rows = sample_states(pi, 300, 3, "near")
+    q = np.tile(rows[0], (len(qa), 1))
+    q[:, pi.ref_joint_pos_indexes] = qa
+    q = q[[orc.is_valid(x)[0] for x in q]][:48]
+    s, g = q[:24], q[24:48]
+    st, pl, nc = orc.plan_batch(s, g, pi.spec.range, max_iters=300, max_nodes=512, seed=3, env_id_base=5, max_path=128, nthreads=4)
+    for e in range(len(s)):
+        a, path, chk, _ = orc.plan(s[e], g[e], pi.spec.range, 0.005, 300, 512, seed=3, env_id=5 + e, max_path=128)
+        assert (a, len(path), chk) == (st[e], pl[e], nc[e])
+    assert (st == 0).any()

@@ -77,3 +77,36 @@ def test_committed_cull_radii_hold_on_samples(env, oracle_mod):
         hits += int(viol.sum())
         assert np.all(cd[viol] <= rad[viol]), (env, i)
     assert hits > 0                                            # the property was exercised
+
+
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_committed_pruning_is_a_subset_of_what_the_tool_proves_today(env, oracle_mod):
+    """a change in the MJCF compile (mjcf.py) must not leave a stale `never_violating_pairs` behind: five committed pairs per
+    scene are re-proven here with the tool's own routine (same guard band, smaller budget: the cheap proofs), and the guard
+    band the runtime reads is the one the tool proves with"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tools"))
+    import prove_separated_pairs as P
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs(env)
+    m = pi.model
+    band = m.meta.get("prune_guard_band")
+    assert band == {"hinge": P.BAND_HINGE, "slide": P.BAND_SLIDE}
+    never = [(int(a), int(b)) for a, b in m.meta.get("never_violating_pairs", [])]
+    orc = oracle_mod.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    q0 = np.array(m.qpos0, dtype=np.float64)
+    rng = np.random.default_rng(11)
+    done = 0
+    for k in rng.permutation(len(never)):
+        a, b = never[k]
+        res, why = P.prove_pair(m, orc, q0, a, b, 60000)
+        if res is None and why.startswith("budget"):
+            continue                    # an expensive proof: another pair
+        assert res is True, f"pair {a} / {b} is committed as never-violating but is not proven today: {why}"
+        done += 1
+        if done == 5:
+            break
+    assert done == 5
+    # and an unlimited slide can never be part of a proof (its box would be empty)
+    assert all(P.joint_box(m, j) is not None or int(m.jnt_type[j]) == 2 for j in range(len(m.jnt_names)))

@@ -1,7 +1,7 @@
 """K7 (env.step with contacts, stage C) timing probe: ms per env.step of E envs, contacts / solver sweeps per sub-step.
    python tools/ct_bench.py [E] [steps] [maxcon]"""
-import sys, time
-sys.path.insert(0, ".")
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import torch
 from mopa_rl_amd import _lib

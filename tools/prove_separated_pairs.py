@@ -16,8 +16,9 @@ branch and bound with a Lipschitz bound:
 
 A box is proven when LB(q_c) - sum_j rho_j w_j > margin (> 0 > contact_threshold); otherwise it is split along its widest
 (rho-weighted) side.  Pairs whose relative pose depends on more than 3 joints, on a free joint, or that cannot be proven
-within the evaluation budget stay in the list.  The proof covers joint values INSIDE the joint ranges (what OMPL samples
-and the rollouts clip to).  Output: `never_violating_pairs` (pairs of collidable-geom indices) into the scene JSON's meta,
+within the evaluation budget stay in the list.  The proof covers joint values inside the joint ranges INFLATED BY A GUARD BAND
+(0.05 rad / 2 mm; OMPL samples inside the ranges, the rollouts clip to them, MuJoCo's soft limits let a reported qpos sit a little
+outside); `_lib.Scene` routes states beyond range + band through the unpruned pair list.  Output: `never_violating_pairs` (pairs of collidable-geom indices) into the scene JSON's meta,
 which `_lib.Scene` drops from the kernel's pair list (the oracle keeps checking them: the parity sweeps are the cross-check).
 
     python tools/prove_separated_pairs.py            # all four scenes, rewrites mopa_rl_amd/scenes/*.json meta
@@ -37,6 +38,21 @@ from oracle import oracle as O  # noqa: E402
 
 MARGIN = 1e-4
 MAX_JOINTS = 3
+# guard band: the box of joint values is inflated by this much beyond every limited joint's range before it is proven, so that
+# the pruning stays sound for states a little OUTSIDE the ranges (MuJoCo's joint limits are soft: a reported qpos can sit a few
+# milliradians beyond them).  The runtime routes states beyond range + band through the unpruned pair list (mopa_rl_amd/_lib.py).
+BAND_HINGE, BAND_SLIDE = 0.05, 0.002
+
+
+def joint_box(m, j):
+    """(lo, hi) of the proof's box for joint j, or None: an unlimited SLIDE has no box (an unlimited hinge has: one turn)"""
+    jt = int(m.jnt_type[j])
+    if m.jnt_limited[j]:
+        band = BAND_SLIDE if jt == JNT_SLIDE else BAND_HINGE
+        return float(m.jnt_range[j][0]) - band, float(m.jnt_range[j][1]) + band
+    if jt == JNT_SLIDE:
+        return None
+    return -np.pi, np.pi
 
 
 def chain_joints(m, body, stop):
@@ -125,10 +141,14 @@ def pair_setup(m, a, b):
                 reach += float(np.linalg.norm(m.body_pos[pb]))
                 for jj in range(int(m.body_jntadr[pb]), int(m.body_jntadr[pb]) + int(m.body_jntnum[pb])):
                     if int(m.jnt_type[jj]) == JNT_SLIDE:
-                        reach += float(np.abs(m.jnt_range[jj] - m.jnt_ref[jj]).max())
+                        if not m.jnt_limited[jj]:
+                            return None
+                        reach += float(np.abs(m.jnt_range[jj] - m.jnt_ref[jj]).max()) + BAND_SLIDE
             rho = 1.0 if jt == JNT_SLIDE else reach
-            lo, hi = (m.jnt_range[j] if m.jnt_limited[j] else (-np.pi, np.pi))
-            joints.append((int(m.jnt_qposadr[j]), float(lo), float(hi), rho))
+            box = joint_box(m, j)
+            if box is None:
+                return None
+            joints.append((int(m.jnt_qposadr[j]), box[0], box[1], rho))
     if not joints or len(joints) > MAX_JOINTS:
         return None
 
@@ -165,10 +185,14 @@ def prove_pair(m, orc, q0, a, b, max_evals, floor=MARGIN):
                 reach += float(np.linalg.norm(m.body_pos[pb]))
                 for jj in range(int(m.body_jntadr[pb]), int(m.body_jntadr[pb]) + int(m.body_jntnum[pb])):
                     if int(m.jnt_type[jj]) == JNT_SLIDE:      # a slide below the joint lengthens the arm by its travel
-                        reach += float(np.abs(m.jnt_range[jj] - m.jnt_ref[jj]).max())
+                        if not m.jnt_limited[jj]:
+                            return None, "unlimited slide"
+                        reach += float(np.abs(m.jnt_range[jj] - m.jnt_ref[jj]).max()) + BAND_SLIDE
             rho = 1.0 if jt == JNT_SLIDE else reach
-            lo, hi = (m.jnt_range[j] if m.jnt_limited[j] else (-np.pi, np.pi))
-            joints.append((int(m.jnt_qposadr[j]), float(lo), float(hi), rho))
+            box = joint_box(m, j)
+            if box is None:
+                return None, "unlimited slide"
+            joints.append((int(m.jnt_qposadr[j]), box[0], box[1], rho))
     if not joints:
         return None, "rigid"
     if len(joints) > MAX_JOINTS:
@@ -252,7 +276,7 @@ def main():
             if res:
                 proven.append([a, b])
                 print(f"  {env}: PROVEN separated  {name(a)} / {name(b)}: {why}", flush=True)
-            elif res is None and why not in ("type", "free joint", "rigid") and "joints" not in why:
+            elif res is None and why not in ("type", "free joint", "rigid", "unlimited slide") and "joints" not in why:
                 print(f"  {env}: undecided        {name(a)} / {name(b)}: {why}", flush=True)
         print(f"{env}: {len(radii)} tightened cull radii; {len(proven)} (+ {len(proven_thr)} that may touch) of {len(m.pair_geom)} candidate pairs proven never to violate the threshold ({time.time() - t0:.0f} s)", flush=True)
         if not args.dry:
@@ -263,8 +287,10 @@ def main():
             cm.meta["never_violating_pairs_thr"] = {"threshold": spec.contact_threshold, "pairs": proven_thr}
             # [geom a, geom b, radius]: the pair can only reach `threshold` while its geom centres are within `radius`
             cm.meta["pair_cull_radius"] = {"threshold": spec.contact_threshold, "pairs": radii}
-            cm.meta["never_violating_pairs_note"] = ("tools/prove_separated_pairs.py: branch-and-bound Lipschitz proof over the joint ranges, margin "
-                                                     f"{MARGIN} m; valid for joint values inside their ranges")
+            cm.meta["prune_guard_band"] = {"hinge": BAND_HINGE, "slide": BAND_SLIDE}
+            cm.meta["never_violating_pairs_note"] = ("tools/prove_separated_pairs.py: branch-and-bound Lipschitz proof over the joint ranges inflated by "
+                                                     f"the guard band ({BAND_HINGE} rad / {BAND_SLIDE} m), margin {MARGIN} m; valid for joint values "
+                                                     "inside range + band -- the runtime sends states beyond that through the unpruned pair list")
             cm.save(path)
 
 

@@ -194,7 +194,7 @@ typedef struct OrcCtDesc {
     int32_t precull_every; double precull_margin;
     int32_t warmstart;                           /* carry the pyramid forces of persisting contacts into the next sub-step */
 } OrcCtDesc;
-typedef struct OrcCtStats { int64_t substeps, contacts, sweeps, dropped; int32_t max_contacts; } OrcCtStats;
+typedef struct OrcCtStats { int64_t substeps, contacts, sweeps, dropped; int32_t max_contacts; int64_t hot_pairs, active_pairs; } OrcCtStats;
 /* n sub-steps with contacts; qvel [nd + 6]: dofs, then the object's (v of its COM, w) in the world; stats may be NULL (accumulated) */
 void orc_ct_step(const OrcDynDesc *d, double *qpos, double *qvel, double *bias_lag, const double *ctrl, int n, OrcCtStats *stats);
 /* the contacts of one configuration (no step): rows of [dist, pos 3, normal 3, shape F, shape S, feature] -> out [maxcon,10]; returns the count */

@@ -169,7 +169,8 @@ class OrcCtDesc(C.Structure):
 
 
 class OrcCtStats(C.Structure):
-    _fields_ = [("substeps", C.c_int64), ("contacts", C.c_int64), ("sweeps", C.c_int64), ("dropped", C.c_int64), ("max_contacts", C.c_int32)]
+    _fields_ = [("substeps", C.c_int64), ("contacts", C.c_int64), ("sweeps", C.c_int64), ("dropped", C.c_int64), ("max_contacts", C.c_int32),
+                ("hot_pairs", C.c_int64), ("active_pairs", C.c_int64)]
 
 
 class OracleDyn:

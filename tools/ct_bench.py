@@ -38,10 +38,10 @@ for env_name in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemb
         L = _lib.lib()
         if hasattr(L, "mopa_debug_ct_prof"):
             import ctypes
-            buf = (ctypes.c_ulonglong * 8)()
+            buf = (ctypes.c_ulonglong * 12)()
             L.mopa_debug_ct_prof(buf, 1)
             t = np.array(list(buf), dtype=np.float64)
             nw = (E + 3) // 4 * env.dyn.nsub * (steps + 2)
-            names = ["smooth", "precull", "cull", "rows", "pgs", "forces", "integrate", "narrow"]
+            names = ["m-rows+frames", "precull", "cull", "rows", "pgs", "forces", "integrate", "narrow", "walk", "owner", "bias", "crb-acc"]
             print("    us per sub-step (lane 0 of each wave, cycles / 2400): " + "  ".join(f"{n} {t[i] / nw / 2400:.2f}" for i, n in enumerate(names)), flush=True)
         env.close()

@@ -6,6 +6,8 @@ pointers to libmopa_hip.so through the C ABI (include/mopa_hip.h).
 from __future__ import annotations
 
 import ctypes as C
+
+import numpy as np
 from typing import Optional, Tuple
 
 from . import _lib

@@ -93,6 +93,7 @@ def test_committed_pruning_is_a_subset_of_what_the_tool_proves_today(env, oracle
     m = pi.model
     band = m.meta.get("prune_guard_band")
     assert band == {"hinge": P.BAND_HINGE, "slide": P.BAND_SLIDE}
+    P.MAX_JOINTS = 5            # (the committed scenes were proven with --max-joints 5)
     never = [(int(a), int(b)) for a, b in m.meta.get("never_violating_pairs", [])]
     orc = oracle_mod.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
     q0 = np.array(m.qpos0, dtype=np.float64)

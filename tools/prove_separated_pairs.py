@@ -266,7 +266,9 @@ def main():
             if not res:
                 # not prunable: is the bounding-sphere cull at least loose for it?
                 has_cyl = GEOM_CYLINDER in (int(m.geom_type[a]), int(m.geom_type[b]))
-                cr = cull_radius(m, orc, q0, a, b, args.max_evals // 4, MARGIN if has_cyl else spec.contact_threshold + MARGIN)
+                # (floor = touching, not the threshold: K1 also reports the deepest penetration, and an overlap shallower than
+                #  the threshold must not vanish from it)
+                cr = cull_radius(m, orc, q0, a, b, args.max_evals // 4, MARGIN)
                 if cr is not None:
                     rsum = rbound(int(m.geom_type[a]), m.geom_size[a]) + rbound(int(m.geom_type[b]), m.geom_size[b])
                     if cr[0] + 1e-3 < 0.9 * rsum:

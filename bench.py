@@ -791,7 +791,7 @@ def main():
             if args.graphs:          # (HIP-graph replay no longer pays: DESIGN 8; kept behind the flag)
                 ro["rollout_async_graphs"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True, use_graphs=True)
             # the same rollout where a Push policy could actually be trained: the env with dynamics + contacts (stage C)
-            ro["rollout_async_dyn"] = rollout_section(torch, ENV, args.envs, device, 40, async_planner=True, dynamics=True)
+            ro["rollout_async_dyn"] = rollout_section(torch, ENV, args.envs, device, 12, async_planner=True, dynamics=True)
         ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 300, world, async_planner=True)
         # BASELINE config 5: SawyerAssemblyObstacle with the IK action space, 8192 envs per GPU
         ro["rollout_assembly_ik"] = rollout_section(torch, "SawyerAssemblyObstacle-v0", 2 * args.envs, device, 120, world, async_planner=True,

@@ -10,8 +10,6 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 only = sys.argv[2] if len(sys.argv) > 2 else ""      # "push": the dynamics step of Push only (profiling)
 for name in (["SawyerPushObstacle-v0"] if only in ("push", "contacts") else ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"]):
     for dyn in ((("contacts",) if only == "contacts" else (True,)) if only else (False, True, "contacts")):
-        if dyn == "contacts" and "Push" not in name:
-            continue
         env = make_env(name, E, dynamics=bool(dyn), contacts=(dyn == "contacts"))
         env.reset()
         n = 20

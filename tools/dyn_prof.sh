@@ -1,6 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace stats + SQ PMC passes for the servo-dynamics kernel (K6 k_env_dyn).
-TAG=${1:-r03_dyn}
+# Runs on the GPU box (via gpurun): kernel-trace stats + SQ PMC passes for the dynamics kernels inside env.step:
+#   bash tools/dyn_prof.sh <tag> push       K6 k_env_dyn4 (servo dynamics, contact-free)
+#   bash tools/dyn_prof.sh <tag> contacts   K7 k_env_dyn_ct (contacts behind the constraint solver)
+TAG=${1:-r04_dyn}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 WORK=/tmp/prof_$TAG
@@ -10,7 +12,7 @@ CMD="python $R/tools/dyn_bench.py 4096 ${2:-push}"
 run() {
   name=$1; shift
   rocprofv3 "$@" --output-format csv -d $WORK/$name -o $name -- $CMD > $OUT/${name}.log 2>&1
-  for f in $(find $WORK/$name -name "*.csv"); do
+  for f in $(find $WORK/$name -name "*.csv" 2>/dev/null); do
     sz=$(stat -c %s $f)
     if [ $sz -lt 300000 ]; then cp $f $OUT/$(basename $f); else
       (head -1 $f; grep -E 'k_env_dyn' $f | head -400) > $OUT/$(basename $f .csv)_dyn.csv

@@ -397,6 +397,11 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         #  tools/rollout_knobs3.sh)
         over.setdefault("planner_streams", 2)
         over.setdefault("planner_workgroups", 128)
+    if dynamics:
+        # a waypoint is a 75-sub-step physics launch whose time does not depend on how many envs take part: every call advances
+        # every env on a path by one waypoint (in the launch that also carries the direct steps), instead of draining towards the
+        # longest path of the call (walk_chunk 0: 7.1 k agent steps/s; 1: 23.9 k; 2: 23.5 k; 4: 24.0 k -- profiles/r04)
+        over.setdefault("walk_chunk", 1)
     if use_ik:
         over["use_ik_target"] = 1       # MoPA + IK action space (BASELINE config 5): Cartesian displacement + rotation quaternion
     rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
@@ -470,7 +475,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     if use_ik:
         mode += "; IK action space: the actor's Cartesian displacement + quaternion -> joint displacement through the batched damped-LS IK (K5)"
     return {"config": f"{env_name}, {E} envs per GPU x {world} GPU(s), {agent_steps} calls of agent_step; actions sampled by a random-init SAC actor "
-                      f"({env.obs.shape[1]}-256-256-256-{2 * ad} MLP, f32, tanh-Gaussian) from the obs (omega 0.7), {'DYNAMICS env (servo dynamics + contacts behind the constraint solver, K7: every env.step is 75 sub-steps)' if dynamics else 'kinematic env'}; {mode}",
+                      f"({env.obs.shape[1]}-256-256-256-{2 * ad} MLP, f32, tanh-Gaussian) from the obs (omega 0.7), {'DYNAMICS env (servo dynamics + contacts behind the constraint solver, K7: every env.step is 75 sub-steps; walk_chunk ' + str(ro.cfg.walk_chunk) + ': envs on a path advance one waypoint per call and sit out the policy until it ends)' if dynamics else 'kinematic env'}; {mode}",
             "agent_steps_per_s": n_agent_steps / dt, "env_steps_per_s": n_env_steps / dt, "s_per_agent_step_batch": dt / agent_steps,
             "envs_stepping_per_call": n_agent_steps / (world * agent_steps), "counters": c,
             "exchange": {"transition_record_bytes": tx.width * 4, "all_gather_bytes_per_rank_per_step": tx.bytes_per_step,
@@ -791,7 +796,7 @@ def main():
             if args.graphs:          # (HIP-graph replay no longer pays: DESIGN 8; kept behind the flag)
                 ro["rollout_async_graphs"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True, use_graphs=True)
             # the same rollout where a Push policy could actually be trained: the env with dynamics + contacts (stage C)
-            ro["rollout_async_dyn"] = rollout_section(torch, ENV, args.envs, device, 12, async_planner=True, dynamics=True)
+            ro["rollout_async_dyn"] = rollout_section(torch, ENV, args.envs, device, 150, async_planner=True, dynamics=True)
         ro["rollout_lift"] = rollout_section(torch, "SawyerLiftObstacle-v0", args.envs, device, 300, world, async_planner=True)
         # BASELINE config 5: SawyerAssemblyObstacle with the IK action space, 8192 envs per GPU
         ro["rollout_assembly_ik"] = rollout_section(torch, "SawyerAssemblyObstacle-v0", 2 * args.envs, device, 120, world, async_planner=True,

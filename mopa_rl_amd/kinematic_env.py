@@ -339,15 +339,21 @@ class BatchKinematicEnv:
             _ptr(move_mask) if move_mask is not None else None, _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
             _ptr(self.success), _stream_handle(stream)))
 
-    def exec_trajectories(self, traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec=None, last_extra=None, stream=None):
+    def exec_trajectories(self, traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec=None, last_extra=None, stream=None,
+                          pos=None, chunk=0):
         """Waypoint execution of the rollout (rl/mopa_rollouts.py:152-199) in one launch: env e steps through
         traj[e, :path_len[e]] ([E, L, nq] f64, [E] int64) until its path ends or a step reports done; smdp_rew [E] f64,
         smdp_done [E] uint8 and intra [E] int64 are updated in place (disc_pow [L] f64 = discount^k).  last_extra [E] f64
         (envs with more action entries than arm joints, i.e. Lift): the policy's gripper action, applied at the LAST
         waypoint of a path (:163-167); the other waypoints carry `form_action`'s gripper difference.  rec: optional dict
-        with 'ob' [E,L,obs_dim] f64, 'meta_rew' [E,L] f64, 'done' [E,L] uint8, 'n_exec' [E] int64 filled per executed waypoint."""
+        with 'ob' [E,L,obs_dim] f64, 'meta_rew' [E,L] f64, 'done' [E,L] uint8, 'n_exec' [E] int64 filled per executed waypoint.
+        Dynamics envs only: pos [E] int64 = every env's next waypoint index (advanced in place; set to its path_len when a
+        step reports done), chunk > 0 = at most that many step launches -- the resumable form a rollout uses to spread long
+        walks over several calls."""
         if self.dynamics:
-            return self._exec_trajectories_dyn(traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec, last_extra, stream)
+            return self._exec_trajectories_dyn(traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec, last_extra, stream, pos, chunk)
+        if pos is not None or chunk:
+            raise _lib.MopaError("pos / chunk: the kinematic env walks a path in one launch")
         L = int(traj.shape[1])
         r = rec or {}
         p = lambda k: _ptr(r[k]) if k in r else None
@@ -359,12 +365,12 @@ class BatchKinematicEnv:
             _ptr(self.done), _ptr(self.success), _ptr(smdp_rew), _ptr(smdp_done), _ptr(intra), p("ob"), p("meta_rew"), p("done"),
             p("n_exec"), _stream_handle(stream)))
 
-    def _exec_trajectories_dyn(self, traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec, last_extra, stream):
+    def _exec_trajectories_dyn(self, traj, path_len, disc_pow, smdp_rew, smdp_done, intra, rec, last_extra, stream, pos=None, chunk=0):
         """`exec_trajectories` with the servo dynamics as the physics: a waypoint is a full env.step (75 dependent sub-steps),
-        so the walk is one step launch per waypoint index over the envs still on their paths (the others sit the launch
-        out through the step's move mask), with the SMDP return / done / intra_steps folded between launches by the same
-        arithmetic as the kinematic kernel (`rew = rew + gamma^k r_k`; stop at the first `done`).  One host read-back (the
-        longest path)."""
+        so the walk is one step launch per round over the envs still on their paths (the others sit the launch out through
+        the step's move mask), every env at its OWN waypoint index `pos`, with the SMDP return / done / intra_steps folded
+        between launches by the same arithmetic as the kinematic kernel (`rew = rew + gamma^k r_k`; stop at the first
+        `done`).  One host read-back (the longest remaining walk)."""
         torch = _torch()
         if stream is not None:
             raise _lib.MopaError("the dynamics form of exec_trajectories runs on the current stream")
@@ -372,27 +378,51 @@ class BatchKinematicEnv:
         if self.action_dim > self.n_arm and last_extra is None:
             raise _lib.MopaError("this env needs last_extra (the gripper action of the last waypoint)")
         plen = torch.clamp(path_len, max=L)
-        alive = plen > 0
-        n_walk = int(plen.max().item()) if E else 0
+        if pos is None:
+            pos = torch.zeros(E, dtype=torch.int64, device=self.device)
+        n_walk = int((plen - pos).max().item()) if E else 0
+        if chunk > 0:
+            n_walk = min(n_walk, int(chunk))
+        for _ in range(max(n_walk, 0)):
+            self.walk_round(traj, plen, pos, disc_pow, smdp_rew, smdp_done, intra, rec, last_extra)
+
+    def walk_round(self, traj, plen, pos, disc_pow, smdp_rew, smdp_done, intra, rec=None, last_extra=None, other_action=None, other_flags=None):
+        """One round of the dynamics walk: ONE step launch in which every env with pos < plen executes waypoint traj[e, pos[e]]
+        (`is_planner` step towards it) and folds the step into its SMDP return / done / intra_steps / records; pos advances
+        (to plen when the step reports done).  The other envs sit the launch out -- or, with other_action [E, action_dim] /
+        other_flags [E] uint8 (move-mask values), take that step in the same launch (a rollout's direct and failed-plan steps;
+        their arm actions already multiplied by ac_scale, since the launch runs with planner-step semantics; has_prev of
+        those envs must be 0)."""
+        torch = _torch()
+        E, L = self.E, int(traj.shape[1])
+        rows = getattr(self, "_rows", None)
+        if rows is None:
+            rows = self._rows = torch.arange(E, device=self.device)
         g0 = int(self.facts.grip_qpos_idx[0]) if self.action_dim > self.n_arm else None
-        for k in range(n_walk):
-            act = alive & (plen > k)
-            wp = traj[:, k]
-            a = wp[:, self._arm_idx] - self.qpos[:, self._arm_idx]          # env.form_action(waypoint): waypoint - current arm state
-            if g0 is not None:
-                extra = torch.where(plen - 1 == k, last_extra, wp[:, g0] - self.qpos[:, g0])
-                a = torch.cat([a, extra[:, None]], dim=1)
+        act = pos < plen
+        k = torch.clamp(pos, max=L - 1)
+        wp = traj[rows, k]
+        a = wp[:, self._arm_idx] - self.qpos[:, self._arm_idx]          # env.form_action(waypoint): waypoint - current arm state
+        if g0 is not None:
+            extra = torch.where(plen - 1 == k, last_extra, wp[:, g0] - self.qpos[:, g0])
+            a = torch.cat([a, extra[:, None]], dim=1)
+        if other_action is not None:
+            a = torch.where(act[:, None], a, other_action)
+            flags = torch.where(act, torch.ones_like(other_flags), other_flags).contiguous()
+        else:
             flags = torch.where(act, 1, 2).to(torch.uint8).contiguous()
-            self._launch(a.contiguous(), True, flags)
-            smdp_rew.copy_(torch.where(act, smdp_rew + disc_pow[k] * self.reward, smdp_rew))
-            smdp_done.copy_(torch.where(act, self.done, smdp_done))
-            intra.copy_(torch.where(act, torch.full_like(intra, k), intra))
-            if rec:
-                rec["ob"][:, k] = torch.where(act[:, None], self.obs, rec["ob"][:, k])
-                rec["meta_rew"][:, k] = torch.where(act, smdp_rew, rec["meta_rew"][:, k])
-                rec["done"][:, k] = torch.where(act, self.done, rec["done"][:, k])
-                rec["n_exec"].copy_(torch.where(act, torch.full_like(rec["n_exec"], k + 1), rec["n_exec"]))
-            alive = alive & ~(act & self.done.bool())       # `if done or ep_len >= max_step: break`
+        self._launch(a.contiguous(), True, flags)
+        smdp_rew.copy_(torch.where(act, smdp_rew + disc_pow[k] * self.reward, smdp_rew))
+        smdp_done.copy_(torch.where(act, self.done, smdp_done))
+        intra.copy_(torch.where(act, k, intra))
+        if rec:
+            rec["ob"][rows, k] = torch.where(act[:, None], self.obs, rec["ob"][rows, k])
+            rec["meta_rew"][rows, k] = torch.where(act, smdp_rew, rec["meta_rew"][rows, k])
+            rec["done"][rows, k] = torch.where(act, self.done, rec["done"][rows, k])
+            rec["n_exec"].copy_(torch.where(act, k + 1, rec["n_exec"]))
+        # `if done or ep_len >= max_step: break`: the walk of such an env is over
+        pos.copy_(torch.where(act, torch.where(self.done.bool(), plen, pos + 1), pos))
+        return act
 
     # ------------------------------------------------------------------
     def reset(self, mask=None):

@@ -100,6 +100,12 @@ class RolloutConfig:
                                       # planner launch finished in the call) are captured once as HIP graphs and replayed -- ~90
                                       # launches of host dispatch per call become two.  The returned tensors are then the graphs'
                                       # static buffers: valid until the next call
+    walk_chunk: int = 0               # dynamics envs (a waypoint = one 75-sub-step physics launch whose time does not depend on how
+                                      # many envs take part): a call executes at most this many waypoints per env; envs still on
+                                      # their path are busy -- they sit out the policy's action of the following calls like envs
+                                      # waiting for a query -- and complete their agent step in the call their walk ends in.  Every
+                                      # env goes through the same transitions; launches stay full instead of draining towards the
+                                      # longest path of the call.  0: a call walks every path to its end
     use_ik_target: bool = False
     ik_target: str = "grip_site"
     min_world_size: tuple = (-1.2, -1.2, 0.0)        # env/sawyer/sawyer.py:52-53
@@ -990,7 +996,8 @@ class BatchMoPARollout:
             finished = torch.zeros(E, dtype=torch.bool, device=dev)
         direct = active & ~is_pl
         self.counters["rl"] += direct.to(torch.int64)
-        sitting = self.busy & ~finished            # still waiting for their query: nothing of theirs is touched
+        sitting = self.busy & ~finished            # still waiting for their query (or on a walk): nothing of theirs is touched
+        chunked = cfg.walk_chunk > 0 and getattr(env, "dynamics", False)
         stepped = ~sitting
         # ---- direct execution (:336-356) and failed plans (:303-334: reward of the current state, one env step) in one launch
         # (:349-352: with the discrete head the direct action goes to the env as it is, otherwise rescaled by 1 / omega)
@@ -999,37 +1006,128 @@ class BatchMoPARollout:
             act0 = torch.cat([act0, torch.where(direct[:, None], extra_ac, torch.zeros_like(extra_ac))], dim=1)
         act0 = act0.contiguous()
         flags = torch.where(direct, 1, torch.where(plan_ok | sitting, 2, 0)).to(torch.uint8).contiguous()
-        env._launch(act0, False, flags)
-        rew = torch.where(plan_ok, torch.zeros_like(env.reward), env.reward)
-        done = torch.where(plan_ok, torch.zeros_like(env.done), env.done)
-        intra = torch.zeros(E, dtype=torch.int64, device=dev)
-        # ---- waypoint execution (:152-199)
+        is_pl_out = is_pl | finished
+        last_extra = extra_ac[:, 0].contiguous() if env.action_dim > n else None
         rec = None
-        L = traj_pad.shape[1]
-        if record:
-            rec = {"ob": torch.zeros(E, L, env.obs.shape[1], dtype=torch.float64, device=dev),
-                   "meta_rew": torch.zeros(E, L, dtype=torch.float64, device=dev),
-                   "done": torch.zeros(E, L, dtype=torch.uint8, device=dev),
-                   "waypoint": traj_pad, "n_exec": torch.zeros(E, dtype=torch.int64, device=dev)}
-        # one launch: every env walks its own waypoints until its path ends or a step reports done (envs without a path: length 0)
-        disc = self._disc.get(L)
-        if disc is None:
-            disc = self._disc[L] = torch.tensor([cfg.discount_factor ** k for k in range(L)], dtype=torch.float64, device=dev)
-        rew, done = rew.contiguous(), done.to(torch.uint8).contiguous()
-        env.exec_trajectories(traj_pad.contiguous(), torch.where(plan_ok, path_len, torch.zeros_like(path_len)).contiguous(), disc,
-                              rew, done, intra, rec={k: rec[k] for k in ("ob", "meta_rew", "done", "n_exec")} if rec else None,
-                              last_extra=extra_ac[:, 0].contiguous() if env.action_dim > n else None)
+        if chunked:
+            # (the direct / failed-plan steps share a launch with the first waypoint of every env on a walk)
+            rew, done, intra, rec, path_len, plan_ok, is_pl_out, stepped = self._walk_chunk(bag, act0, flags, record, sitting, is_pl_out, last_extra)
+        else:
+            env._launch(act0, False, flags)
+            rew = torch.where(plan_ok, torch.zeros_like(env.reward), env.reward)
+            done = torch.where(plan_ok, torch.zeros_like(env.done), env.done)
+            intra = torch.zeros(E, dtype=torch.int64, device=dev)
+            # ---- waypoint execution (:152-199)
+            L = traj_pad.shape[1]
+            if record:
+                rec = {"ob": torch.zeros(E, L, env.obs.shape[1], dtype=torch.float64, device=dev),
+                       "meta_rew": torch.zeros(E, L, dtype=torch.float64, device=dev),
+                       "done": torch.zeros(E, L, dtype=torch.uint8, device=dev),
+                       "waypoint": traj_pad, "n_exec": torch.zeros(E, dtype=torch.int64, device=dev)}
+            # one launch: every env walks its own waypoints until its path ends or a step reports done (envs without a path: length 0)
+            disc = self._disc_pow(L)
+            rew, done = rew.contiguous(), done.to(torch.uint8).contiguous()
+            env.exec_trajectories(traj_pad.contiguous(), torch.where(plan_ok, path_len, torch.zeros_like(path_len)).contiguous(), disc,
+                                  rew, done, intra, rec={k: rec[k] for k in ("ob", "meta_rew", "done", "n_exec")} if rec else None,
+                                  last_extra=last_extra)
         mark("execute")
-        env.has_prev.zero_()                                     # env._reset_prev_state()
+        if chunked:
+            env.has_prev.copy_(torch.where(self._walk["on"], env.has_prev, torch.zeros_like(env.has_prev)))
+        else:
+            env.has_prev.zero_()                                 # env._reset_prev_state()
         self.t_env += stepped.to(torch.int64)
         self._t_dev += 1
         res = {"ob": prev_ob, "ac": ac_tr, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra,
-               "is_planner": is_pl | finished, "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok, "stepped": stepped}
+               "is_planner": is_pl_out, "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok, "stepped": stepped}
         if cfg.discrete_action:
             res["ac_type"] = bag["ac_type"]
         if rec is not None:
             res["record"] = rec
         return res
+
+    def _disc_pow(self, L):
+        disc = self._disc.get(L)
+        if disc is None:
+            disc = self._disc[L] = _torch().tensor([self.cfg.discount_factor ** k for k in range(L)], dtype=_torch().float64, device=self.env.device)
+        return disc
+
+    def _walk_chunk(self, bag, act0, flags0, record, sitting, is_pl_out, last_extra):
+        """cfg.walk_chunk (dynamics env): the paths handed out in this call join the persistent walk state; every env on a walk
+        advances by at most walk_chunk waypoints, each a physics launch over all envs on a walk -- the first of them also
+        carries this call's direct and failed-plan steps (act0 / flags0).  The envs whose walk ended complete their agent
+        step, the others stay busy.  Per env the arithmetic is that of one uninterrupted walk."""
+        torch = _torch()
+        env, cfg, E, n = self.env, self.cfg, self.E, self.n
+        dev = env.device
+        plan_ok, traj_pad, path_len = bag["plan_ok"], bag["traj_pad"], bag["path_len"]
+        L = int(traj_pad.shape[1])
+        W = getattr(self, "_walk", None)
+        if W is None:
+            z = lambda *sh, dt=torch.float64: torch.zeros(*sh, dtype=dt, device=dev)
+            W = self._walk = {"on": z(E, dt=torch.bool), "traj": z(E, L, self.nq), "len": z(E, dt=torch.int64), "pos": z(E, dt=torch.int64),
+                              "rew": z(E), "done": z(E, dt=torch.uint8), "intra": z(E, dt=torch.int64), "is_pl": z(E, dt=torch.bool),
+                              "extra": z(E), "rec": None}
+        if L > W["traj"].shape[1]:                                   # a longer path than any before: widen (rare)
+            grow = lambda x: torch.cat([x, torch.zeros(E, L - x.shape[1], *x.shape[2:], dtype=x.dtype, device=dev)], dim=1)
+            W["traj"] = grow(W["traj"])
+            if W["rec"] is not None:
+                for k in ("ob", "meta_rew", "done"):
+                    W["rec"][k] = grow(W["rec"][k])
+        Lw = int(W["traj"].shape[1])
+        if L < Lw:
+            traj_pad = torch.cat([traj_pad, torch.zeros(E, Lw - L, self.nq, dtype=traj_pad.dtype, device=dev)], dim=1)
+        on0 = W["on"]
+        new = plan_ok & ~sitting                                     # paths handed out in this call (straight lines, finished queries)
+        zi = torch.zeros_like(W["len"])
+        W["traj"].copy_(torch.where(new[:, None, None], traj_pad, W["traj"]))
+        W["len"].copy_(torch.where(new, torch.clamp(path_len, max=Lw), torch.where(on0, W["len"], zi)))
+        W["pos"].copy_(torch.where(on0, W["pos"], zi))
+        W["rew"].copy_(torch.where(on0, W["rew"], torch.zeros_like(W["rew"])))
+        W["done"].copy_(torch.where(on0, W["done"], torch.zeros_like(W["done"])))
+        W["intra"].copy_(torch.where(on0, W["intra"], zi))
+        W["is_pl"].copy_(torch.where(on0, W["is_pl"], is_pl_out))
+        if last_extra is not None:
+            W["extra"].copy_(torch.where(new, last_extra, W["extra"]))
+        rec = None
+        if record:
+            if W["rec"] is None:
+                W["rec"] = {"ob": torch.zeros(E, Lw, env.obs.shape[1], dtype=torch.float64, device=dev),
+                            "meta_rew": torch.zeros(E, Lw, dtype=torch.float64, device=dev),
+                            "done": torch.zeros(E, Lw, dtype=torch.uint8, device=dev), "n_exec": torch.zeros(E, dtype=torch.int64, device=dev)}
+            rec = W["rec"]
+            fresh = ~on0
+            rec["ob"].copy_(torch.where(fresh[:, None, None], torch.zeros_like(rec["ob"]), rec["ob"]))
+            rec["meta_rew"].copy_(torch.where(fresh[:, None], torch.zeros_like(rec["meta_rew"]), rec["meta_rew"]))
+            rec["done"].copy_(torch.where(fresh[:, None], torch.zeros_like(rec["done"]), rec["done"]))
+            rec["n_exec"].copy_(torch.where(fresh, torch.zeros_like(rec["n_exec"]), rec["n_exec"]))
+        disc = self._disc_pow(Lw)
+        ext = W["extra"] if last_extra is not None else None
+        # the launch runs with planner-step semantics (the action IS the displacement): a direct action's arm entries are
+        # multiplied by ac_scale here instead of in the kernel -- the same one multiplication
+        other = act0.clone()
+        other[:, :n] = act0[:, :n] * torch.full_like(act0[:, :n], cfg.ac_scale)
+        walked = env.walk_round(W["traj"], W["len"], W["pos"], disc, W["rew"], W["done"], W["intra"], rec, ext, other_action=other, other_flags=flags0)
+        rew1, done1 = env.reward.clone(), env.done.clone()           # of the envs that took their direct / failed-plan step
+        if cfg.walk_chunk > 1:
+            env.exec_trajectories(W["traj"], W["len"], disc, W["rew"], W["done"], W["intra"], rec=rec, last_extra=ext, pos=W["pos"],
+                                  chunk=cfg.walk_chunk - 1)
+        still = W["pos"] < W["len"]
+        # envs on a walk are busy: the following calls ignore the policy's rows for them; the transition's first half is parked
+        # exactly as for envs waiting for a query
+        self._pend_ob.copy_(torch.where(still[:, None], bag["prev_ob"], self._pend_ob))
+        self._pend_ac.copy_(torch.where(still[:, None], bag["ac_tr"], self._pend_ac))
+        if cfg.discrete_action:
+            self._pend_type.copy_(torch.where(still, bag["ac_type"], self._pend_type))
+        self.busy.copy_((self.busy & ~on0) | still)
+        W["on"] = still
+        stepped = (~sitting | on0) & ~still
+        walker = on0 | new
+        out_rec = None
+        if record:
+            out_rec = {k: v.clone() for k, v in rec.items()}
+            out_rec["waypoint"] = W["traj"].clone()
+        return (torch.where(walker, W["rew"], rew1), torch.where(walker, W["done"], done1.to(torch.uint8)), W["intra"].clone(), out_rec,
+                torch.where(walker, W["len"], path_len), plan_ok | on0, W["is_pl"].clone(), stepped)
 
     def drain(self):
         """wait for every RRT-Connect launch in flight (async_planner); their envs complete their step in a following agent_step"""

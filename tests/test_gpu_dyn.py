@@ -346,6 +346,66 @@ def test_rollout_runs_on_the_dynamics_env(torch_mod):
     assert float(env.qvel.abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("env_name", ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0"])
+def test_chunked_walks_give_every_env_the_same_transitions(torch_mod, env_name):
+    """`walk_chunk` on a dynamics env: a call executes at most that many waypoints per env (the first in the same launch as
+    the call's direct and failed-plan steps), envs still on their path sit out the following calls.  Every env must go through
+    exactly the transitions -- and waypoint records -- of the run that walks every path to its end within its call."""
+    torch = torch_mod
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    E, T = 96, 4
+    rng = np.random.default_rng(11)
+    n_ac = 8 if env_name == "SawyerLiftObstacle-v0" else 7
+    AC = rng.uniform(-1, 1, size=(E, T, n_ac)) * rng.choice([0.5, 0.69, 1.0], size=(E, T, 1))
+    AC[: E // 3, 1, 1], AC[: E // 3, 1, 3] = 1.0, -1.0           # blocked straight lines: RRT-Connect queries
+    ACt = torch.tensor(AC, device="cuda")
+    runs = {}
+    for mode, chunk, asyn in (("whole", 0, False), ("chunk1", 1, True), ("chunk3", 3, True), ("chunk2_lockstep", 2, False)):
+        env = make_env(env_name, E, dynamics=True, contacts=True, seed=5, max_episode_steps=14)
+        env.reset()
+        ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.1, max_nodes=512, max_path=128, num_trials=10, async_planner=asyn,
+                                                 planner_first_iters=60, planner_min_job=1, walk_chunk=chunk))
+        seq = [[] for _ in range(E)]
+        recs = [[] for _ in range(E)]
+        calls = n_sitting = 0
+        while min(len(q) for q in seq) < T:
+            te = ro.t_env.clamp(max=T - 1)
+            ac = ACt[torch.arange(E, device="cuda"), te].contiguous()
+            out = ro.agent_step(ac, record=True)
+            st = out["stepped"].cpu().numpy()
+            rows = np.concatenate([out["rew"].cpu().numpy()[:, None], out["done"].cpu().numpy()[:, None].astype(np.float64),
+                                   out["intra_steps"].cpu().numpy()[:, None].astype(np.float64),
+                                   out["is_planner"].cpu().numpy()[:, None].astype(np.float64), out["plan_ok"].cpu().numpy()[:, None].astype(np.float64),
+                                   out["path_len"].cpu().numpy()[:, None].astype(np.float64),
+                                   env.qpos.cpu().numpy(), env.qvel.cpu().numpy(), out["ac"].cpu().numpy(), out["ob"].cpu().numpy(),
+                                   out["ob_next"].cpu().numpy()], axis=1)
+            r = out["record"]
+            nx = r["n_exec"].cpu().numpy()
+            r_ob, r_rew, r_done, r_wp = (r[k].cpu().numpy() for k in ("ob", "meta_rew", "done", "waypoint"))
+            for e in np.where(st)[0]:
+                if len(seq[e]) < T:
+                    seq[e].append(rows[e])
+                    k = int(nx[e])
+                    recs[e].append(np.concatenate([[k], r_ob[e, :k].ravel(), r_rew[e, :k], r_done[e, :k].astype(np.float64), r_wp[e, :k].ravel()]))
+            n_sitting += int((~st).sum())
+            calls += 1
+            assert calls < 400
+        runs[mode] = (np.array([np.array(q) for q in seq]), recs, calls, n_sitting, {k: int(v.sum()) for k, v in ro.counters.items()})
+        env.close()
+    a = runs["whole"]
+    assert a[3] == 0 and a[2] == T
+    assert a[4]["interpolation"] > 0 and a[4]["rl"] > 0 and a[4]["mp"] + a[4]["mp_fail"] > 0
+    assert a[0][:, :, 2].max() >= 4 and a[0][:, :, 1].sum() > 0          # walks longer than every chunk, and walks cut by `done`
+    for mode in ("chunk1", "chunk3", "chunk2_lockstep"):
+        b = runs[mode]
+        assert np.array_equal(_bits(a[0]), _bits(b[0])), mode
+        for e in range(E):
+            for t in range(T):
+                assert np.array_equal(_bits(a[1][e][t]), _bits(b[1][e][t])), (mode, e, t)
+        assert b[3] > 0                                                  # envs did sit calls out
+
+
 # ---- stage C: contacts of arm and object behind the constraint solver (K7, mopa_contact.inc) -------------------------------
 def _setup_ct(oracle_mod, env_name, E, contact_options=None, **kw):
     from mopa_rl_amd.kinematic_env import make_env

@@ -433,6 +433,50 @@ int mopa_env_step_dyn_batch(MopaEnv *env, int64_t E, double *qpos_dev, double *q
                             const uint8_t *move_mask_dev, double *obs_dev, double *reward_dev, uint8_t *done_dev,
                             uint8_t *success_dev, void *stream);
 
+/* ---- bookkeeping of one batched rollout call (rl/mopa_rollouts.py:70-375 + rl/sac_agent.py:148-318 for E envs at once) -------------
+ * The elementwise work of mopa_rl_amd/rollout.py::BatchMoPARollout.agent_step between the library's launches, as six
+ * one-wave-per-env kernels (mopa_rollstep.inc names the stages).  All pointers are device buffers; bool buffers are bytes. */
+typedef struct MopaRolloutStep {
+    int64_t E;
+    int32_t nq, n_arm, ac_dim, ac_stride, adim, obs_dim, K /* width of the straight-line pre-check: traj is [E, K+1, nq] */;
+    int32_t discrete, normal_space;
+    double omega, ac_scale, action_range, omega_over_scale, one_minus_omega, range_minus_scale;
+    const double *lim_lo, *lim_hi, *lo_state, *hi_state, *lo_shrunk, *hi_shrunk, *safe_q;              /* [nq] */
+    /* the env's buffers */
+    const double *qpos, *obs, *reward;
+    const uint8_t *done, *success;
+    uint8_t *has_prev;
+    /* the rollout's persistent state */
+    uint8_t *busy, *pool_mask, *interp_overflow;
+    int64_t *wait_since, *t_dev, *t_env, *pend_type;
+    double *q_cur, *q_tgt, *pend_ob, *pend_ac;
+    int64_t *c_rl, *c_interp, *c_mp_fail, *c_invalid;
+    /* this call's inputs */
+    const double *ac;                  /* [E, ac_stride] policy output */
+    const int64_t *ac_type_in;         /* [E] (discrete) */
+    const double *a_in;                /* [E, n_arm] joint displacement action from the IK (use_ik_target) or NULL */
+    /* this call's buffers */
+    double *prev_ob, *ac_tr, *a, *extra_ac, *target, *cur_m, *cur_v, *tgt_v, *traj;
+    uint8_t *active, *is_pl, *pv, *plan_ok;
+    int64_t *ac_type, *path_len;
+    const uint8_t *tv, *ok;            /* target valid (after the pull-back); pre-check verdict */
+    const int32_t *nst, *tlen;         /* pre-check: steps needed, trajectory length */
+    const uint8_t *finished;           /* [E] envs whose planner query was picked up in this call, or NULL */
+    double *act0;                      /* [E, adim] */
+    uint8_t *flags, *sitting, *stepped, *is_pl_out;
+    int64_t *plen_m;
+    double *last_extra;                /* [E] or NULL */
+    double *rew;
+    uint8_t *done_out;
+    int64_t *intra;
+    double *ob_next;
+    uint8_t *success_out;
+    const uint8_t *retry_mask;         /* [E] envs waiting for a retry launch, or NULL */
+    int64_t *pool_counts;              /* [2] <- number of set entries of pool_mask / retry_mask after the call, or NULL */
+} MopaRolloutStep;
+int mopa_rollout_stage(const MopaRolloutStep *step, int32_t stage /*0..5*/, void *stream);
+int mopa_rollout_step_size(void);      /* sizeof(MopaRolloutStep) as the library was built (binding self-check) */
+
 /* The arm state the NEXT mopa_env_step_batch call with the same arguments would reach (desired_state clamped to ctrlrange
  * and joint limits), without stepping: input of a collision gate (mopa_is_valid_batch with samples_per_env = 1 -> move_mask). */
 int mopa_env_desired_batch(MopaEnv *env, int64_t E, const double *qpos_dev /*[E,nq]*/, const double *prev_state_dev /*[E,n_arm]*/,

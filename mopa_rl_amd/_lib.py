@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
-    "mopa_env_attach_dynamics", "mopa_env_attach_contacts", "mopa_env_set_contact_stats", "mopa_env_dyn_dofs", "mopa_env_dyn_qvel_width", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
+    "mopa_env_attach_dynamics", "mopa_env_attach_contacts", "mopa_env_set_contact_stats", "mopa_rollout_stage", "mopa_rollout_step_size", "mopa_env_dyn_dofs", "mopa_env_dyn_qvel_width", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch",
     "mopa_paths_unwrap_batch", "mopa_paths_walk_batch", "mopa_paths_assemble_batch", "mopa_interpolate_batch",
 ]
@@ -90,6 +90,21 @@ class MopaDynDesc(C.Structure):
         ("actuated", _ip), ("kp", _dp), ("force_lo", _dp), ("force_hi", _dp), ("gravcomp", _ip),
         ("gravity", C.c_double * 3), ("timestep", C.c_double), ("nsub", C.c_int32), ("obj", C.POINTER(MopaObjDesc)),
     ]
+
+
+class MopaRolloutStep(C.Structure):
+    """include/mopa_hip.h MopaRolloutStep: every pointer as an address (c_void_p), filled from tensors' data_ptr()"""
+    _I32 = ("nq", "n_arm", "ac_dim", "ac_stride", "adim", "obs_dim", "K", "discrete", "normal_space")
+    _F64 = ("omega", "ac_scale", "action_range", "omega_over_scale", "one_minus_omega", "range_minus_scale")
+    _PTR = ("lim_lo", "lim_hi", "lo_state", "hi_state", "lo_shrunk", "hi_shrunk", "safe_q",
+            "qpos", "obs", "reward", "done", "success", "has_prev",
+            "busy", "pool_mask", "interp_overflow", "wait_since", "t_dev", "t_env", "pend_type", "q_cur", "q_tgt", "pend_ob", "pend_ac",
+            "c_rl", "c_interp", "c_mp_fail", "c_invalid",
+            "ac", "ac_type_in", "a_in",
+            "prev_ob", "ac_tr", "a", "extra_ac", "target", "cur_m", "cur_v", "tgt_v", "traj",
+            "active", "is_pl", "pv", "plan_ok", "ac_type", "path_len", "tv", "ok", "nst", "tlen", "finished",
+            "act0", "flags", "sitting", "stepped", "is_pl_out", "plen_m", "last_extra", "rew", "done_out", "intra", "ob_next", "success_out", "retry_mask", "pool_counts")
+    _fields_ = ([("E", C.c_int64)] + [(k, C.c_int32) for k in _I32] + [(k, C.c_double) for k in _F64] + [(k, C.c_void_p) for k in _PTR])
 
 
 class MopaCtDesc(C.Structure):
@@ -169,6 +184,8 @@ def lib() -> C.CDLL:
     L.mopa_env_attach_dynamics.argtypes = [vp, C.POINTER(MopaDynDesc)]
     L.mopa_env_attach_contacts.argtypes = [vp, C.POINTER(MopaCtDesc)]
     L.mopa_env_set_contact_stats.argtypes = [vp, vp]
+    L.mopa_rollout_stage.argtypes = [C.POINTER(MopaRolloutStep), C.c_int32, vp]
+    L.mopa_rollout_step_size.argtypes = []
     L.mopa_env_dyn_dofs.argtypes = [vp]
     L.mopa_env_dyn_qvel_width.argtypes = [vp]
     L.mopa_env_dyn_forward_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp]

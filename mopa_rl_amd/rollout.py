@@ -106,6 +106,8 @@ class RolloutConfig:
                                       # waiting for a query -- and complete their agent step in the call their walk ends in.  Every
                                       # env goes through the same transitions; launches stay full instead of draining towards the
                                       # longest path of the call.  0: a call walks every path to its end
+    fused: bool = True                # the elementwise bookkeeping of a call as six library kernels (mopa_rollout_stage) instead of
+                                      # ~170 torch launches; False: the torch form (the two agree bit for bit, tests/test_gpu_rollout.py)
     use_ik_target: bool = False
     ik_target: str = "grip_site"
     min_world_size: tuple = (-1.2, -1.2, 0.0)        # env/sawyer/sawyer.py:52-53
@@ -782,6 +784,8 @@ class BatchMoPARollout:
         env, cfg, E, n = self.env, self.cfg, self.E, self.n
         mark = self._mark
         mark(None)
+        if cfg.fused:
+            return self._seg_pre_fused(ac)
         busy0 = self.busy.clone()
         active = ~busy0
         prev_ob = torch.where(busy0[:, None], self._pend_ob, env.obs)
@@ -894,11 +898,17 @@ class BatchMoPARollout:
             if side is None and cfg.async_planner:
                 break
             mask = self._retry_mask if retry else self._pool_mask
-            bi = torch.nonzero(mask).flatten()
             # (a launch costs the host about as much as a call: with several streams free, small pools wait for company
             # unless nothing of their kind is in flight)
             kind_in_flight = any(j.get("retry", False) == retry for j in self._jobs)
             min_job = cfg.planner_min_job // 4 if retry else cfg.planner_min_job
+            known = self._pool_counts_known() if cfg.async_planner else None
+            if known is not None:
+                # listing the waiting envs reads their number back (the host waits for the stream): only in calls in which
+                # the count an earlier call left behind says a launch is due
+                if not (known[int(retry)] >= min_job or (known[int(retry)] > 0 and not kind_in_flight)):
+                    continue
+            bi = torch.nonzero(mask).flatten()
             if len(bi) and (not cfg.async_planner or len(bi) >= min_job or not kind_in_flight):
                 if bool(self._interp_overflow):
                     raise _lib.MopaError(f"a straight-line pre-check needed more than {self._k_interp} steps (targets further than "
@@ -994,10 +1004,12 @@ class BatchMoPARollout:
         finished = bag.get("finished")
         if finished is None:
             finished = torch.zeros(E, dtype=torch.bool, device=dev)
+        chunked = cfg.walk_chunk > 0 and getattr(env, "dynamics", False)
+        if cfg.fused and not chunked:
+            return self._seg_exec_fused(bag, record)
         direct = active & ~is_pl
         self.counters["rl"] += direct.to(torch.int64)
         sitting = self.busy & ~finished            # still waiting for their query (or on a walk): nothing of theirs is touched
-        chunked = cfg.walk_chunk > 0 and getattr(env, "dynamics", False)
         stepped = ~sitting
         # ---- direct execution (:336-356) and failed plans (:303-334: reward of the current state, one env step) in one launch
         # (:349-352: with the discrete head the direct action goes to the env as it is, otherwise rescaled by 1 / omega)
@@ -1039,6 +1051,168 @@ class BatchMoPARollout:
         self._t_dev += 1
         res = {"ob": prev_ob, "ac": ac_tr, "ob_next": env.obs.clone(), "rew": rew, "done": done, "intra_steps": intra,
                "is_planner": is_pl_out, "success": env.success.clone(), "path_len": path_len, "plan_ok": plan_ok, "stepped": stepped}
+        if cfg.discrete_action:
+            res["ac_type"] = bag["ac_type"]
+        if rec is not None:
+            res["record"] = rec
+        return res
+
+    # ---- the same two parts with the elementwise work in the library's bookkeeping kernels (cfg.fused) ----
+    def _fused_struct(self):
+        torch = _torch()
+        S = getattr(self, "_fs", None)
+        if S is not None:
+            return S
+        import ctypes as C
+        env, cfg = self.env, self.cfg
+        if _lib.lib().mopa_rollout_step_size() != C.sizeof(_lib.MopaRolloutStep):
+            raise _lib.MopaError("MopaRolloutStep: the binding's layout differs from the library's")
+        S = self._fs = _lib.MopaRolloutStep()
+        S.E, S.nq, S.n_arm, S.ac_dim, S.adim, S.obs_dim, S.K = self.E, self.nq, self.n, self.ac_dim, env.action_dim, env.obs.shape[1], self._k_interp
+        S.discrete, S.normal_space = int(cfg.discrete_action), int(cfg.ac_space_type == "normal")
+        if cfg.ac_space_type not in ("normal", "piecewise"):
+            raise NotImplementedError(cfg.ac_space_type)
+        S.omega, S.ac_scale, S.action_range = cfg.omega, cfg.ac_scale, cfg.action_range
+        S.omega_over_scale, S.one_minus_omega, S.range_minus_scale = cfg.omega / cfg.ac_scale, 1 - cfg.omega, cfg.action_range - cfg.ac_scale
+        lim = self.limits
+        self._fs_keep = [t.contiguous() for t in (lim.lo, lim.hi, lim.lo_state, lim.hi_state, lim.lo_shrunk, lim.hi_shrunk, self._safe_q.reshape(-1))]
+        for k, t in zip(("lim_lo", "lim_hi", "lo_state", "hi_state", "lo_shrunk", "hi_shrunk", "safe_q"), self._fs_keep):
+            setattr(S, k, t.data_ptr())
+        if self._interp_overflow.dtype != torch.bool:
+            raise _lib.MopaError("interp_overflow must be a bool scalar")
+        return S
+
+    def _fused_bind(self, **tensors):
+        """device addresses of this call's tensors -> the step struct (None -> NULL); every tensor must be contiguous"""
+        S = self._fs
+        for k, t in tensors.items():
+            if t is None:
+                setattr(S, k, None)
+                continue
+            if not t.is_contiguous():
+                raise _lib.MopaError(f"rollout step buffer {k} is not contiguous")
+            setattr(S, k, t.data_ptr())
+
+    def _pool_counts_known(self):
+        """(envs waiting for a planner launch, for a retry launch) as of the latest earlier call whose bookkeeping has finished
+        on the device, or None (torch form of the calls / no such call yet): copied to pinned memory behind each call"""
+        ring = getattr(self, "_count_ring", None)
+        if not ring:
+            return None
+        for k in range(len(ring) - 1, -1, -1):
+            if ring[k][0].query():
+                del ring[:k]                                  # older entries are of no use any more
+                return [int(x) for x in ring[0][1]]
+        return None
+
+    def _pool_counts_push(self):
+        torch = _torch()
+        ring = getattr(self, "_count_ring", None)
+        if ring is None:
+            ring = self._count_ring = []
+            self._count_free = []
+        # at most two calls enqueued ahead of the device: the planner's pick-ups are decided on the host's clock, and a host
+        # far ahead would enqueue calls in which envs sit out although their query has long finished
+        pending = [r for r in ring if not r[0].query()]
+        if len(pending) >= 2:
+            pending[0][0].synchronize()
+        while len(ring) > 4:
+            self._count_free.append(ring.pop(0))
+        ev, host = self._count_free.pop() if self._count_free else (torch.cuda.Event(), torch.zeros(2, dtype=torch.int64).pin_memory())
+        host.copy_(self._pool_counts, non_blocking=True)
+        ev.record(torch.cuda.current_stream())
+        ring.append((ev, host))
+
+    def _fused_stage(self, stage):
+        import ctypes as C
+        from .batch import _stream_handle
+        _lib.check(_lib.lib().mopa_rollout_stage(C.byref(self._fs), int(stage), _stream_handle(None)))
+
+    def _seg_pre_fused(self, ac):
+        torch = _torch()
+        from .batch import _ptr, _stream_handle
+        env, cfg, E, n, nq = self.env, self.cfg, self.E, self.n, self.nq
+        dev, f64, u8, i64 = env.device, torch.float64, torch.bool, torch.int64
+        mark = self._mark
+        S = self._fused_struct()
+        ac = ac if ac.is_contiguous() else ac.contiguous()
+        if ac.dtype != f64 or ac.shape[0] != E or ac.shape[1] < self.ac_dim:
+            raise _lib.MopaError("agent_step: ac must be float64 [E, >= ac_dim]")
+        a_in = None
+        if cfg.use_ik_target:
+            a_in = self.ik_displacement(ac, env.qpos.clone()).contiguous()
+            mark("ik")
+        em = lambda *sh, dt=f64: torch.empty(*sh, dtype=dt, device=dev)
+        n_extra = env.action_dim - n
+        B = {"prev_ob": em(E, S.obs_dim), "ac_tr": em(E, self.ac_dim), "a": em(E, n), "extra_ac": em(E, max(n_extra, 1)),
+             "target": em(E, nq), "cur_m": em(E, nq), "cur_v": em(E, nq), "tgt_v": em(E, nq), "traj": em(E, self._k_interp + 1, nq),
+             "active": em(E, dt=u8), "is_pl": em(E, dt=u8), "pv": em(E, dt=u8), "plan_ok": em(E, dt=u8),
+             "ac_type": em(E, dt=i64) if cfg.discrete_action else None, "path_len": em(E, dt=i64)}
+        S.ac_stride = int(ac.shape[1])
+        c = self.counters
+        self._fused_bind(qpos=env.qpos, obs=env.obs, reward=env.reward, done=env.done, success=env.success, has_prev=env.has_prev,
+                         busy=self.busy, pool_mask=self._pool_mask, interp_overflow=self._interp_overflow, wait_since=self._wait_since,
+                         t_dev=self._t_dev, t_env=self.t_env, pend_type=self._pend_type, q_cur=self._q_cur, q_tgt=self._q_tgt,
+                         pend_ob=self._pend_ob, pend_ac=self._pend_ac, c_rl=c["rl"], c_interp=c["interpolation"], c_mp_fail=c["mp_fail"],
+                         c_invalid=c["invalid"], ac=ac, ac_type_in=self._ac_type_in, a_in=a_in, **B)
+        self._fused_stage(0)
+        if cfg.invalid_target_handling:
+            trials = em(E, dt=torch.int32)
+            tv = em(E, dt=torch.uint8)
+            _lib.check(_lib.lib().mopa_pullback_batch(self.scene.handle, _ptr(B["cur_m"]), _ptr(B["target"]), E, float(cfg.step_size), int(cfg.num_trials),
+                                                      _ptr(trials), _ptr(tv), _stream_handle(None)))
+        else:
+            tv = self._valid(B["target"]).contiguous()
+        mark("target")
+        self._fused_bind(tv=tv)
+        self._fused_stage(1)
+        tlen, ok, nst = em(E, dt=torch.int32), em(E, dt=torch.uint8), em(E, dt=torch.int32)
+        _lib.check(_lib.lib().mopa_interpolate_batch(self.scene._h, E, n, self._k_interp, _ptr(B["cur_v"]), _ptr(B["tgt_v"]), float(cfg.ac_scale),
+                                                     _ptr(B["traj"]), _ptr(tlen), _ptr(ok), _ptr(nst), _stream_handle(None)))
+        self._fused_bind(tlen=tlen, ok=ok, nst=nst)
+        self._fused_stage(2)
+        mark("interpolate")
+        self._fs_call = (ac, a_in, tv, tlen, ok, nst)          # alive until the call's last stage has been enqueued
+        return {"ac_type": B["ac_type"], "active": B["active"], "prev_ob": B["prev_ob"], "ac_tr": B["ac_tr"], "a": B["a"],
+                "extra_ac": B["extra_ac"][:, :n_extra] if n_extra else B["extra_ac"][:, :0], "is_pl": B["is_pl"], "plan_ok": B["plan_ok"],
+                "traj_pad": B["traj"], "path_len": B["path_len"], "n_finished": 0, "_extra_buf": B["extra_ac"]}
+
+    def _seg_exec_fused(self, bag, record: bool = False):
+        torch = _torch()
+        env, cfg, E, n = self.env, self.cfg, self.E, self.n
+        dev, f64, u8, i64 = env.device, torch.float64, torch.bool, torch.int64
+        mark = self._mark
+        S = self._fs
+        em = lambda *sh, dt=f64: torch.empty(*sh, dtype=dt, device=dev)
+        traj_pad, plan_ok, path_len = bag["traj_pad"], bag["plan_ok"], bag["path_len"]
+        lift = env.action_dim > n
+        X = {"act0": em(E, env.action_dim), "flags": em(E, dt=torch.uint8), "sitting": em(E, dt=u8), "stepped": em(E, dt=u8),
+             "is_pl_out": em(E, dt=u8), "plen_m": em(E, dt=i64), "last_extra": em(E) if lift else None, "rew": em(E),
+             "done_out": em(E, dt=torch.uint8), "intra": em(E, dt=i64), "ob_next": em(E, S.obs_dim), "success_out": em(E, dt=env.success.dtype)}
+        # (the planner's pick-ups may have replaced plan_ok / path_len rows in place and widened traj_pad)
+        counting = cfg.async_planner and not cfg.use_graphs
+        if counting and getattr(self, "_pool_counts", None) is None:
+            self._pool_counts = torch.zeros(2, dtype=i64, device=dev)
+        self._fused_bind(finished=bag.get("finished"), plan_ok=plan_ok, path_len=path_len, active=bag["active"], is_pl=bag["is_pl"], a=bag["a"],
+                         extra_ac=bag["_extra_buf"], retry_mask=self._retry_mask if counting else None,
+                         pool_counts=self._pool_counts if counting else None, **X)
+        self._fused_stage(3)
+        env._launch(X["act0"], False, X["flags"])
+        self._fused_stage(4)
+        rec = None
+        L = traj_pad.shape[1]
+        if record:
+            rec = {"ob": torch.zeros(E, L, env.obs.shape[1], dtype=f64, device=dev), "meta_rew": torch.zeros(E, L, dtype=f64, device=dev),
+                   "done": torch.zeros(E, L, dtype=torch.uint8, device=dev), "waypoint": traj_pad, "n_exec": torch.zeros(E, dtype=i64, device=dev)}
+        env.exec_trajectories(traj_pad if traj_pad.is_contiguous() else traj_pad.contiguous(), X["plen_m"], self._disc_pow(L), X["rew"], X["done_out"],
+                              X["intra"], rec={k: rec[k] for k in ("ob", "meta_rew", "done", "n_exec")} if rec else None, last_extra=X["last_extra"])
+        mark("execute")
+        self._fused_stage(5)
+        if counting:
+            self._pool_counts_push()
+        self._fs_call = None
+        res = {"ob": bag["prev_ob"], "ac": bag["ac_tr"], "ob_next": X["ob_next"], "rew": X["rew"], "done": X["done_out"], "intra_steps": X["intra"],
+               "is_planner": X["is_pl_out"], "success": X["success_out"], "path_len": path_len, "plan_ok": plan_ok, "stepped": X["stepped"]}
         if cfg.discrete_action:
             res["ac_type"] = bag["ac_type"]
         if rec is not None:

@@ -71,3 +71,10 @@ def test_positive_contact_threshold_is_rejected():
     pi = planner_inputs("SawyerPushObstacle-v0")
     with pytest.raises(_lib.MopaError, match="contact_threshold"):
         _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, 0.001)
+
+
+def test_rollout_step_struct_layout_matches_the_library():
+    """MopaRolloutStep is filled field by field from Python: its ctypes layout must be the one the library was compiled with."""
+    import ctypes as C
+    from mopa_rl_amd import _lib
+    assert _lib.lib().mopa_rollout_step_size() == C.sizeof(_lib.MopaRolloutStep)

@@ -222,6 +222,68 @@ def test_async_planner_gives_every_env_the_same_transitions(env_name):
         assert int(a[3]["mp_fail"].sum()) > 0 and b[4] > 0 and d[4] > 0       # ... with both outcomes, and second launches
 
 
+@pytest.mark.parametrize("env_name,kw", [("SawyerPushObstacle-v0", {}), ("SawyerLiftObstacle-v0", {}),
+                                         ("SawyerPushObstacle-v0", {"discrete_action": True}),
+                                         ("SawyerPushObstacle-v0", {"invalid_target_handling": False, "ac_space_type": "normal"}),
+                                         ("SawyerAssemblyObstacle-v0", {"use_ik_target": True})])
+def test_fused_bookkeeping_equals_the_torch_form(env_name, kw):
+    """`RolloutConfig.fused` (the call's elementwise bookkeeping as six library kernels, mopa_rollstep.inc) against the torch
+    form of the same call: every returned tensor, the env's state and the rollout's persistent state bit for bit, call by
+    call, in lock-step runs (the asynchronous form of the fused calls -- envs parked while their query runs -- is what
+    test_async_planner_gives_every_env_the_same_transitions compares with these)."""
+    import torch
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    E, T = 160, 6
+    rng = np.random.default_rng(9)
+    for asyn in (False,):
+        runs = []
+        for fused in (False, True):
+            env = make_env(env_name, E, seed=12, max_episode_steps=9)
+            env.reset()
+            ro = BatchMoPARollout(env, RolloutConfig(timelimit=0.15, max_nodes=512, max_path=128, num_trials=10, async_planner=asyn,
+                                                     planner_first_iters=60, planner_min_job=1, fused=fused, **kw))
+            r2 = np.random.default_rng(4)
+            log = []
+            for t in range(T):
+                AC = r2.uniform(-1, 1, size=(E, ro.ac_dim + 1)) * r2.choice([0.6, 0.9, 1.0], size=(E, 1))      # (a spare column: ac_stride > ac_dim)
+                if t in (1, 3) and not kw.get("use_ik_target"):
+                    AC[: E // 2, 1], AC[: E // 2, 3] = 1.0, -1.0                # blocked straight lines: RRT-Connect queries
+                ac_type = torch.tensor(r2.integers(0, 2, size=E), device="cuda") if kw.get("discrete_action") else None
+                if asyn:
+                    ro.drain()            # (pick-ups then happen in the same calls in both runs)
+                out = ro.agent_step(torch.tensor(AC, device="cuda"), record=(t % 2 == 1), ac_type=ac_type)
+                row = {k: v.cpu().numpy().copy() for k, v in out.items() if k != "record"}
+                if "record" in out:
+                    row.update({"rec_" + k: v.cpu().numpy().copy() for k, v in out["record"].items()})
+                row.update(qpos=env.qpos.cpu().numpy().copy(), has_prev=env.has_prev.cpu().numpy().copy(), ep_len=env.ep_len.cpu().numpy().copy(),
+                           busy=ro.busy.cpu().numpy().copy(), pool=ro._pool_mask.cpu().numpy().copy(), wait=ro._wait_since.cpu().numpy().copy(),
+                           q_cur=ro._q_cur.cpu().numpy().copy(), q_tgt=ro._q_tgt.cpu().numpy().copy(), pend_ob=ro._pend_ob.cpu().numpy().copy(),
+                           pend_ac=ro._pend_ac.cpu().numpy().copy(), pend_type=ro._pend_type.cpu().numpy().copy(), t_env=ro.t_env.cpu().numpy().copy(),
+                           t_dev=ro._t_dev.cpu().numpy().copy(), overflow=ro._interp_overflow.cpu().numpy().copy(),
+                           **{"c_" + k: v.cpu().numpy().copy() for k, v in ro.counters.items()})
+                log.append(row)
+            runs.append(log)
+            ro.drain()
+            env.close()
+        for t, (ra, rb) in enumerate(zip(*runs)):
+            assert ra.keys() == rb.keys()
+            st = ra["stepped"].astype(bool)
+            for k in ra:
+                a, b = ra[k], rb[k]
+                assert a.dtype == b.dtype and a.shape == b.shape, (asyn, t, k, a.dtype, b.dtype)
+                if k in ("rew", "done", "intra_steps", "ob_next", "success", "is_planner", "path_len", "plan_ok", "ac_type") or k.startswith("rec_"):
+                    a, b = a[st], b[st]                         # rows of envs that sat the call out are not meaningful
+                same = np.array_equal(_bits(a), _bits(b)) if a.dtype == np.float64 else np.array_equal(a, b)
+                assert same, (asyn, t, k)
+        tot = {k[2:]: int(v.sum()) for k, v in runs[1][-1].items() if k.startswith("c_")}
+        assert tot["rl"] > 0 and tot["interpolation"] > 0, tot
+        if not kw.get("use_ik_target"):
+            assert tot["mp"] + tot["mp_fail"] > 0, tot
+        if asyn and not kw.get("use_ik_target"):
+            assert any(r["busy"].any() for r in runs[1])
+
+
 def test_pullback_kernel_equals_host_form(oracle_mod):
     """`mopa_pullback_batch` (one launch) against `handle_invalid_target_batch` (torch ops + one validity launch per
     trial, itself the batched form of rl/mopa_rollouts.py:133-143): same targets, trial counts and verdicts, bit for bit."""

@@ -1,5 +1,7 @@
-"""Kernel launches of one BatchMoPARollout.agent_step call (kinematic env, asynchronous planner), by kernel name: torch's
-profiler around `calls` steady-state calls.  python tools/count_launches.py [calls] [env]"""
+"""Device launches (kernels + memcpys / memsets) of one BatchMoPARollout.agent_step call (kinematic env, asynchronous planner,
+4096 envs), by name: torch's profiler around `calls` steady-state calls of agent_step ALONE -- the actions are drawn before the
+profiled region and episodes are not reset inside it (MOPA_COUNT_LOOP=1: with the bench loop's action draw + env.reset).
+MOPA_BENCH_ROLLOUT=fused=0 counts the torch form.   python tools/count_launches.py [calls] [env]"""
 import os
 import sys
 from collections import Counter
@@ -21,19 +23,25 @@ g.manual_seed(8)
 ad = ro.ac_dim
 
 
-def one():
-    a = (torch.rand(E, ad, generator=g, dtype=torch.float64, device=env.device) * 2 - 1)
+loop = bool(os.environ.get("MOPA_COUNT_LOOP"))
+
+
+def one(a=None):
+    if a is None:
+        a = (torch.rand(E, ad, generator=g, dtype=torch.float64, device=env.device) * 2 - 1)
     out = ro.agent_step(a)
-    env.reset(out["done"].bool() & out["stepped"])
+    if loop or a is None:
+        env.reset(out["done"].bool() & out["stepped"])
 
 
 for _ in range(40):
     one()
+acts = [(torch.rand(E, ad, generator=g, dtype=torch.float64, device=env.device) * 2 - 1) for _ in range(calls)]
 torch.cuda.synchronize()
 from torch.profiler import profile, ProfilerActivity
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
-    for _ in range(calls):
-        one()
+    for k in range(calls):
+        one(None if loop else acts[k])
     torch.cuda.synchronize()
 c = Counter()
 t = Counter()
@@ -42,6 +50,9 @@ for ev in prof.events():
         c[ev.name] += 1
         t[ev.name] += ev.device_time
 tot = sum(c.values())
-print(f"{tot / calls:.1f} device launches per call (incl. the action draw and env.reset of the loop), {sum(t.values()) / calls:.0f} us of device time per call")
+lib_k = sum(v for k, v in c.items() if k.startswith("k_") or k.startswith("void k_"))
+print(f"{tot / calls:.1f} device launches per agent_step call over {calls} calls ({'with' if loop else 'without'} the loop's action draw / env.reset; "
+      f"fused={ro.cfg.fused}): {lib_k / calls:.1f} library kernels, {(tot - lib_k) / calls:.1f} torch kernels / copies; "
+      f"{sum(t.values()) / calls:.0f} us of device time per call, side streams included")
 for k, v in c.most_common(60):
     print(f"{v / calls:7.2f}  {t[k] / calls:8.1f} us  {k[:110]}")

@@ -126,9 +126,14 @@ def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30, grip_
     `env.form_action` appends that joint's difference (env/sawyer/sawyer.py:283-299), `valid_action` checks the whole vector,
     `is_planner_ac` the arm entries.
     Returns a list of dicts (env, start, goal, ob, ac, rew, done, intra_steps, ob_next) of numpy values."""
-    if cfg.use_ik_target:
-        raise NotImplementedError("reuse_data relabelling for the IK action space (cart_list / quat_list, rl/mopa_rollouts.py:247-262)")
     rec = out["record"]
+    if cfg.use_ik_target:
+        # With use_ik_target the reference never moves target_qpos off curr_qpos (BatchMoPARollout._seg_pre), so a planner step
+        # executes the two waypoints of a zero-length line and `len(ob_list) > 3` (:222) never holds: the IK branch of the
+        # relabelling (:247-262, cart_list / quat_list) cannot be reached.  Anything longer here is not the reference's rollout.
+        if bool((rec["n_exec"] > 3).any()):
+            raise NotImplementedError("reuse_data relabelling for the IK action space (cart_list / quat_list, rl/mopa_rollouts.py:247-262)")
+        return []
     if grip_qpos_idx is None and int(out["ac"].shape[1]) > n_arm:
         raise ValueError("the env's action has a gripper entry: pass grip_qpos_idx (BatchMoPARollout.reuse_transitions does)")
     ac_type = out["ac_type"].cpu().numpy() if (cfg.discrete_action and "ac_type" in out) else None

@@ -127,7 +127,10 @@ def test_ik_action_space_rollout_equals_reference_runner():
         _load_state(env, G["qpos_start"][:, t], G["ep_len_start"][:, t])
         before = {k: ro.counters[k].clone() for k in COUNTERS}
         ro.t = t
-        out = ro.agent_step(torch.tensor(G["ac"][:, t], device=env.device))
+        out = ro.agent_step(torch.tensor(G["ac"][:, t], device=env.device), record=True)
+        # (a planner step of this action space executes the two waypoints of a zero-length line: nothing for `reuse_data` to
+        #  relabel -- its `len(ob_list) > 3` never holds, rl/mopa_rollouts.py:222)
+        assert int(out["record"]["n_exec"].max()) <= 2 and ro.reuse_transitions(out, np.random.RandomState(0)) == []
         np.testing.assert_allclose(env.qpos.cpu().numpy(), G["qpos_end"][:, t], rtol=0, atol=2e-6, err_msg=f"step {t}: qpos")
         assert np.array_equal(out["done"].cpu().numpy().astype(np.int64), G["done"][:, t]), f"step {t}: done"
         assert np.array_equal(out["intra_steps"].cpu().numpy(), G["intra"][:, t]), f"step {t}: intra_steps"

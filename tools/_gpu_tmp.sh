@@ -1,4 +1,6 @@
-mkdir -p gpurun_out/r04_launches
-MOPA_BENCH_ROLLOUT=fused=0 timeout 600 python tools/count_launches.py 100 2>&1 | grep -v "amdgpu.ids\|Warn\|warn" > gpurun_out/r04_launches/torch_form.txt
-timeout 600 python tools/count_launches.py 100 2>&1 | grep -v "amdgpu.ids\|Warn\|warn" > gpurun_out/r04_launches/fused_form.txt
-head -3 gpurun_out/r04_launches/torch_form.txt | cut -c1-300; head -70 gpurun_out/r04_launches/fused_form.txt | cut -c1-140
+mkdir -p gpurun_out/r04_full
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 > gpurun_out/r04_full/pytest_gpu.txt
+cat gpurun_out/r04_full/pytest_gpu.txt
+timeout 900 python bench.py > gpurun_out/r04_full/bench.json 2> gpurun_out/r04_full/bench.err
+tail -c 1500 gpurun_out/r04_full/bench.json
+tail -5 gpurun_out/r04_full/bench.err

@@ -306,8 +306,9 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
     what = (f"servo + contacts (stage C): as `dynamics`, plus contacts of the arm with the scene, the manipulated object as a free rigid body and "
             f"arm <-> object contacts, two-way coupled behind one soft-constraint solve per sub-step: {len(env.ct.pr_f)} directed geom pairs "
             f"({len(env.ct.ft_rad)} feature points in exact signed-distance functions), <= {env.ct.maxcon} contacts per env, MuJoCo's solref / solimp "
-            f"impedance model, pyramidal friction cones, PGS <= {env.ct.iterations} sweeps at tolerance {env.ct.tolerance:g} -- RESTATED FROM THE "
-            "PUBLISHED SOLVER, PARITY UNPINNED; not restated: elliptic cones, noslip, torsional / rolling friction") if contacts else (
+            f"impedance model, pyramidal friction cones, PGS <= {env.ct.iterations} sweeps at tolerance {env.ct.tolerance:g}, noslip pass of "
+            f"{env.ct.noslip_iterations} sweeps -- RESTATED FROM THE PUBLISHED SOLVER, PARITY UNPINNED; not restated: elliptic cones, "
+            "torsional / rolling friction") if contacts else (
            f"servo, contact-free: {nsub} sub-steps of h = {env.dyn.timestep} s per env.step on {nd} dofs (RNE bias + CRB inertia + "
            "implicit-damping Euler, kp / forcerange servos, lagged qfrc_bias as gravity compensation); joint limits = inelastic "
            "stop; the manipulated object does not move (no contacts) -- labelled, NOT MuJoCo's constraint solver")

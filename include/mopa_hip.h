@@ -408,6 +408,8 @@ typedef struct MopaCtDesc {
     int32_t precull_every;
     double precull_margin;
     int32_t warmstart;
+    int32_t noslip_iterations;       /* sweeps of the noslip pass after the main solve (0 = none) */
+    double noslip_tolerance;
 } MopaCtDesc;
 int mopa_env_attach_contacts(MopaEnv *env, const MopaCtDesc *desc);
 /* per-env counters of the last stepping launch: [E,4] int32 = contacts summed over the sub-steps, solver sweeps summed,

@@ -193,6 +193,8 @@ typedef struct OrcCtDesc {
     double tolerance, inv_scale;                 /* stop when improvement * inv_scale < tolerance; inv_scale = 1 / (meaninertia max(1, nv)) */
     int32_t precull_every; double precull_margin;
     int32_t warmstart;                           /* carry the pyramid forces of persisting contacts into the next sub-step */
+    int32_t noslip_iterations;                   /* sweeps of the noslip pass after the main solve (XML: 5; 0 = none) */
+    double noslip_tolerance;                     /* its early exit: improvement * inv_scale below this (MuJoCo default 1e-6) */
 } OrcCtDesc;
 typedef struct OrcCtStats { int64_t substeps, contacts, sweeps, dropped; int32_t max_contacts; int64_t hot_pairs, active_pairs; } OrcCtStats;
 /* n sub-steps with contacts; qvel [nd + 6]: dofs, then the object's (v of its COM, w) in the world; stats may be NULL (accumulated) */

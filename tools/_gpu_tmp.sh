@@ -1,1 +1,1 @@
-timeout 600 python tools/ct_tail.py lift 10 11 2>&1 | grep -v amdgpu | cut -c1-260
+bash tools/k1_knock.sh time "Sawyer|Pusher" 2>&1 | grep -v amdgpu

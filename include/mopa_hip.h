@@ -408,6 +408,7 @@ typedef struct MopaCtDesc {
     int32_t precull_every;
     double precull_margin;
     int32_t warmstart;
+    int32_t solver;                  /* 0: projected Gauss-Seidel, 1: Newton (MuJoCo's default) */
     int32_t noslip_iterations;       /* sweeps of the noslip pass after the main solve (0 = none) */
     double noslip_tolerance;
 } MopaCtDesc;

@@ -323,6 +323,7 @@ class CtFacts:
     warmstart: int
     noslip_iterations: int = 5    # sawyer_dependencies.xml:11 noslip_iterations="5"
     noslip_tolerance: float = 1e-6   # MuJoCo's default
+    solver: int = 1                  # 1: Newton (MuJoCo's default; the XML names no solver), 0: projected Gauss-Seidel
 
 
 def _joint_space_inertia_diag(dyn: DynFacts, qpos_row: np.ndarray) -> np.ndarray:
@@ -377,7 +378,7 @@ def _spread_order(n: int):
 
 def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpair: int = 4, iterations: int = 50,
                   tolerance: float = 1e-10, precull_every: int = 15, precull_margin: float = 0.15, warmstart: bool = True,
-                  noslip_iterations: int = 5, noslip_tolerance: float = 1e-6,
+                  noslip_iterations: int = 5, noslip_tolerance: float = 1e-6, solver: str = "newton",
                   qpos_ref: np.ndarray = None) -> CtFacts:
     from .mjcf import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_MESH, GEOM_PLANE, GEOM_SPHERE, JNT_FREE
     m = model
@@ -559,4 +560,5 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         obj_inv_mass=1.0 / mt, obj_inv_inertia=1.0 / prin, obj_inv_mass_d=1.0 / (mt + h * damp), obj_inv_inertia_d=1.0 / (prin + h * damp),
         maxcon=int(maxcon), maxpair=int(maxpair), iterations=int(iterations), tolerance=float(tolerance),
         inv_scale=1.0 / (float(dg.mean()) * max(1, nv)), precull_every=int(precull_every), precull_margin=float(precull_margin),
-        warmstart=int(bool(warmstart)), noslip_iterations=int(noslip_iterations), noslip_tolerance=float(noslip_tolerance))
+        warmstart=int(bool(warmstart)), noslip_iterations=int(noslip_iterations), noslip_tolerance=float(noslip_tolerance),
+        solver={"pgs": 0, "newton": 1}[solver])

@@ -298,6 +298,7 @@ class BatchKinematicEnv:
                 cd.tolerance, cd.inv_scale = float(ct.tolerance), float(ct.inv_scale)
                 cd.precull_every, cd.precull_margin, cd.warmstart = int(ct.precull_every), float(ct.precull_margin), int(ct.warmstart)
                 cd.noslip_iterations, cd.noslip_tolerance = int(ct.noslip_iterations), float(ct.noslip_tolerance)
+                cd.solver = int(ct.solver)
                 _lib.check(L.mopa_env_attach_contacts(self._h, C.byref(cd)))
             self.nv = int(L.mopa_env_dyn_qvel_width(self._h))
             assert self.nv == df.nd + (6 if contacts else 0)

@@ -193,6 +193,7 @@ typedef struct OrcCtDesc {
     double tolerance, inv_scale;                 /* stop when improvement * inv_scale < tolerance; inv_scale = 1 / (meaninertia max(1, nv)) */
     int32_t precull_every; double precull_margin;
     int32_t warmstart;                           /* carry the pyramid forces of persisting contacts into the next sub-step */
+    int32_t solver;                              /* 0: projected Gauss-Seidel, 1: Newton (MuJoCo's default; `iterations` caps either) */
     int32_t noslip_iterations;                   /* sweeps of the noslip pass after the main solve (XML: 5; 0 = none) */
     double noslip_tolerance;                     /* its early exit: improvement * inv_scale below this (MuJoCo default 1e-6) */
 } OrcCtDesc;

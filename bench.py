@@ -306,9 +306,9 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
     what = (f"servo + contacts (stage C): as `dynamics`, plus contacts of the arm with the scene, the manipulated object as a free rigid body and "
             f"arm <-> object contacts, two-way coupled behind one soft-constraint solve per sub-step: {len(env.ct.pr_f)} directed geom pairs "
             f"({len(env.ct.ft_rad)} feature points in exact signed-distance functions), <= {env.ct.maxcon} contacts per env, MuJoCo's solref / solimp "
-            f"impedance model, pyramidal friction cones, PGS <= {env.ct.iterations} sweeps at tolerance {env.ct.tolerance:g}, noslip pass of "
-            f"{env.ct.noslip_iterations} sweeps -- RESTATED FROM THE PUBLISHED SOLVER, PARITY UNPINNED; not restated: elliptic cones, "
-            "torsional / rolling friction") if contacts else (
+            f"impedance model, pyramidal friction cones, {'Newton solver (MuJoCo default)' if env.ct.solver == 1 else 'PGS'} <= {env.ct.iterations} iterations "
+            f"at tolerance {env.ct.tolerance:g}, noslip pass of {env.ct.noslip_iterations} sweeps -- RESTATED FROM THE PUBLISHED SOLVER, PARITY "
+            "UNPINNED; not restated: elliptic cones, torsional / rolling friction") if contacts else (
            f"servo, contact-free: {nsub} sub-steps of h = {env.dyn.timestep} s per env.step on {nd} dofs (RNE bias + CRB inertia + "
            "implicit-damping Euler, kp / forcerange servos, lagged qfrc_bias as gravity compensation); joint limits = inelastic "
            "stop; the manipulated object does not move (no contacts) -- labelled, NOT MuJoCo's constraint solver")
@@ -318,7 +318,7 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
            "gpu_ms_per_batch": ev0.elapsed_time(ev1) / steps,
            "algorithmic_bytes_per_env_step": bytes_per_step, "achieved_GBps": E * steps * bytes_per_step / dt / 1e9,
            "bound": ("latency: 16 lanes per env, one wave per SIMD (1024 workgroups of 4 envs): chain walk + contact culling / narrow phase + "
-                     "Gauss-Seidel sweeps of a sub-step; not HBM") if contacts else
+                     "constraint rows + solver iterations of a sub-step; not HBM") if contacts else
                     "latency of the serial chain walk + 9 x 9 solve of a sub-step (four waves share 64 envs; one workgroup per CU: 64 of 256 "
                     "CUs busy at 4096 envs); not HBM"}
     if contacts:

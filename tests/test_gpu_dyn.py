@@ -458,11 +458,14 @@ def _ct_states(env, orc, E, seed):
 
 
 @pytest.mark.parametrize("env_name", ENVS)
-@pytest.mark.parametrize("n", [1, 4, 75])
-def test_contact_substeps_bit_exact(oracle_mod, torch_mod, env_name, n):
+@pytest.mark.parametrize("n,solver", [(1, "newton"), (4, "newton"), (75, "newton"), (4, "pgs"), (75, "pgs")])
+def test_contact_substeps_bit_exact(oracle_mod, torch_mod, env_name, n, solver):
+    """sub-steps with contacts, both solvers (Newton: MuJoCo's default, what the reference runs; projected Gauss-Seidel: round 4's
+    first form), each followed by the noslip pass: state after n sub-steps bit for bit against the oracle"""
     torch = torch_mod
     E = 130                 # not a multiple of 4: the last workgroup carries idle groups
-    pi, orc, env, ref = _setup_ct(oracle_mod, env_name, E)
+    pi, orc, env, ref = _setup_ct(oracle_mod, env_name, E, contact_options={"solver": solver})
+    assert env.ct.solver == {"pgs": 0, "newton": 1}[solver]
     d = env.dyn
     q, v = _ct_states(env, orc, E, seed=10 + n)
     rng = np.random.default_rng(200 + n)

@@ -26,8 +26,13 @@ for env_name in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemb
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for t in range(steps):
+            if os.environ.get("CT_TRACE"):
+                torch.cuda.synchronize(); _t = time.perf_counter()
             env.step(acts[2 + t])
             s = stats.cpu().numpy().astype(np.float64)
+            if os.environ.get("CT_TRACE"):
+                sw = s[:, 1] / env.dyn.nsub
+                print(f"    step {t}: {(time.perf_counter() - _t) * 1e3:7.2f} ms, iterations / sub-step max {sw.max():.2f} (env {int(sw.argmax())}), finite {bool(torch.isfinite(env.qpos).all())}", flush=True)
             tot[:3] += s[:, :3].sum(0); tot[3] = max(tot[3], s[:, 3].max())
         ev1.record(); torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / steps
@@ -38,10 +43,10 @@ for env_name in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemb
         L = _lib.lib()
         if hasattr(L, "mopa_debug_ct_prof"):
             import ctypes
-            buf = (ctypes.c_ulonglong * 12)()
+            buf = (ctypes.c_ulonglong * 16)()
             L.mopa_debug_ct_prof(buf, 1)
             t = np.array(list(buf), dtype=np.float64)
             nw = (E + 3) // 4 * env.dyn.nsub * (steps + 2)
-            names = ["m-rows+frames", "precull", "cull", "rows", "pgs", "forces", "integrate", "narrow", "walk", "owner", "bias", "crb-acc"]
+            names = ["m-rows+frames", "precull", "cull", "rows", "solver", "forces", "integrate", "narrow", "walk", "owner", "bias", "crb-acc", "nt:rows+H", "nt:ldl+solve", "nt:linesearch", "nt:forces"]
             print("    us per sub-step (lane 0 of each wave, cycles / 2400): " + "  ".join(f"{n} {t[i] / nw / 2400:.2f}" for i, n in enumerate(names)), flush=True)
         env.close()

@@ -13,14 +13,14 @@ seed = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 E = 4096
 dev = torch.device("cuda:0")
 for ns in (0, 5):
-    env = make_env(name, E, device=dev, seed=seed, dynamics=True, contacts=True, max_episode_steps=250, contact_options={"noslip_iterations": ns})
+    env = make_env(name, E, device=dev, seed=seed, dynamics=True, contacts=True, max_episode_steps=250, contact_options=dict({"noslip_iterations": ns}, **({"maxpair": int(os.environ["CT_MAXPAIR"])} if os.environ.get("CT_MAXPAIR") else {})))
     env.reset()
     stats = torch.zeros(E, 4, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().mopa_env_set_contact_stats(env._h, stats.data_ptr()))
     g = torch.Generator(device=dev); g.manual_seed(seed + 1)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for t in range(steps):
-        a = (torch.rand(E, env.action_dim, generator=g, dtype=torch.float64, device=dev) * 2 - 1).contiguous()
+        a = ((torch.rand(E, env.action_dim, generator=g, dtype=torch.float64, device=dev) * 2 - 1) * float(os.environ.get("CT_SCALE", "1"))).contiguous()
         ev0.record(); env.step(a); ev1.record(); torch.cuda.synchronize()
         s = stats.cpu().numpy().astype(np.float64)
         sw = s[:, 1] / env.dyn.nsub

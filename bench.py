@@ -569,15 +569,35 @@ def lib_sha256():
     return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
 
 
+K1_SOURCES = ("mopa_rl_amd/csrc/mopa_hip.hip", "mopa_rl_amd/csrc/mopa_valid_v5.inc", "mopa_rl_amd/csrc/mopa_valid_v2.inc", "mopa_rl_amd/csrc/mopa_device.hpp",
+              "mopa_rl_amd/csrc/mopa_host.hpp", "mopa_rl_amd/csrc/mopa_planner.inc", "mopa_rl_amd/csrc/mopa_pullback.inc", "mopa_rl_amd/csrc/mopa_motion.inc",
+              "mopa_rl_amd/csrc/mopa_ik.inc", "mopa_rl_amd/csrc/mopa_paths.inc", "mopa_rl_amd/csrc/Makefile", "include/mopa_hip.h",
+              "mopa_rl_amd/scenes/sawyer_push_obstacle.json")
+
+
+def k1_sources_sha256():
+    """hash of everything the validity kernel's translation unit (mopa_hip.hip) and the bench scene are built from: a PMC pass stays
+    valid for a library whose OTHER translation unit (env / dynamics kernels) changed"""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in K1_SOURCES:
+        f = os.path.join(ROOT, rel)
+        h.update(rel.encode())
+        h.update(open(f, "rb").read() if os.path.exists(f) else b"<missing>")
+    return h.hexdigest()
+
+
 def committed_traffic(kernel, n_states):
     """HBM-side traffic / VALU counts of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile.sh ->
     tools/make_traffic_json.py -> profiles/rNN/k_is_valid_traffic.json); they cannot be collected from inside this process.
-    A file is used only if it was measured on THIS build of libmopa_hip.so (sha256 stamp), for this kernel and batch size."""
+    A file is used only if it was measured on THIS build of libmopa_hip.so (sha256 stamp) -- or on a build whose validity-kernel
+    translation unit and bench scene had the same sources (`k1_sources_sha256`) --, for this kernel and batch size."""
     import glob
-    sha = lib_sha256()
+    sha, src = lib_sha256(), k1_sources_sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "k_is_valid_traffic.json")), reverse=True):
         t = json.load(open(f))
-        if t.get("lib_sha256") == sha and t.get("states_per_launch") == n_states and t.get("kernel", "").startswith(kernel):
+        same_build = t.get("lib_sha256") == sha or (t.get("k1_sources_sha256") is not None and t.get("k1_sources_sha256") == src)
+        if same_build and t.get("states_per_launch") == n_states and t.get("kernel", "").startswith(kernel):
             t["source"] = os.path.relpath(f, ROOT)
             return t
     return None

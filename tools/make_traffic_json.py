@@ -42,8 +42,10 @@ if os.path.exists(ks):
 if fetch is None or write is None:
     sys.exit(f"no FETCH_SIZE / WRITE_SIZE rows for {prefix} under {src}")
 sha = hashlib.sha256(open(os.path.join(ROOT, "mopa_rl_amd", "csrc", "libmopa_hip.so"), "rb").read()).hexdigest()
+sys.path.insert(0, ROOT)
+import bench as _bench
 out = {
-    "kernel": kname, "states_per_launch": N, "lib_sha256": sha,
+    "kernel": kname, "states_per_launch": N, "lib_sha256": sha, "k1_sources_sha256": _bench.k1_sources_sha256(),
     "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "dispatches_averaged": [nf, nw, nv],
     "traffic_bytes_per_launch": int((fetch + write) * 1024),
     "algorithmic_bytes_per_launch": int(N * (7 * 8 + 1 + 36 * 8 / 256)),

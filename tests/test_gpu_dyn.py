@@ -488,6 +488,20 @@ def test_contact_substeps_bit_exact(oracle_mod, torch_mod, env_name, n, solver):
     assert touched > E // 4
 
 
+def test_newton_solver_refuses_more_than_eight_contacts(torch_mod):
+    """the Newton solver maps a contact's four pyramid rows onto the 16 lanes of an env, two rows per lane: maxcon <= 8 (the LDS holds no
+    more at 4096 envs either); the Gauss-Seidel form takes what the LDS takes"""
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.kinematic_env import make_env
+    with pytest.raises(_lib.MopaError, match="at most 8 contacts"):
+        make_env("SawyerPushObstacle-v0", 8, dynamics=True, contacts=True, contact_options={"maxcon": 12, "solver": "newton"})
+    env = make_env("SawyerPushObstacle-v0", 8, dynamics=True, contacts=True, contact_options={"maxcon": 12, "solver": "pgs"})
+    env.reset()
+    env.step(torch_mod.zeros(8, env.action_dim, dtype=torch_mod.float64, device=env.device))
+    assert bool(torch_mod.isfinite(env.qpos).all())
+    env.close()
+
+
 @pytest.mark.parametrize("env_name", ENVS)
 def test_contact_env_rollout_bit_identical_to_oracle(oracle_mod, torch_mod, env_name):
     torch = torch_mod

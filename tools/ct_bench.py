@@ -9,7 +9,7 @@ from mopa_rl_amd.kinematic_env import make_env
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-maxcon = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+maxcon = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 dev = torch.device("cuda:0")
 for env_name in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"):
     for scale in (1.0, 0.0):

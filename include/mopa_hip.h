@@ -409,6 +409,8 @@ typedef struct MopaCtDesc {
     double precull_margin;
     int32_t warmstart;
     int32_t solver;                  /* 0: projected Gauss-Seidel, 1: Newton (MuJoCo's default) */
+    int32_t limit_rows;              /* joint limits as rows of the Newton solver (MuJoCo) instead of an inelastic stop */
+    double lim_par[8];               /* their parameters in a pair record's layout: -, margin 0, K, B, d0, dmax, width, - */
     int32_t noslip_iterations;       /* sweeps of the noslip pass after the main solve (0 = none) */
     double noslip_tolerance;
 } MopaCtDesc;

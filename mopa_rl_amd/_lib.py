@@ -117,7 +117,7 @@ class MopaCtDesc(C.Structure):
         ("obj_inv_mass_d", C.c_double), ("obj_inv_inertia_d", C.c_double * 3),
         ("maxcon", C.c_int32), ("maxpair", C.c_int32), ("iterations", C.c_int32), ("tolerance", C.c_double), ("inv_scale", C.c_double),
         ("precull_every", C.c_int32), ("precull_margin", C.c_double), ("warmstart", C.c_int32),
-        ("solver", C.c_int32), ("noslip_iterations", C.c_int32), ("noslip_tolerance", C.c_double),
+        ("solver", C.c_int32), ("limit_rows", C.c_int32), ("lim_par", C.c_double * 8), ("noslip_iterations", C.c_int32), ("noslip_tolerance", C.c_double),
     ]
 
 

@@ -324,6 +324,8 @@ class CtFacts:
     noslip_iterations: int = 5    # sawyer_dependencies.xml:11 noslip_iterations="5"
     noslip_tolerance: float = 1e-6   # MuJoCo's default
     solver: int = 1                  # 1: Newton (MuJoCo's default; the XML names no solver), 0: projected Gauss-Seidel
+    limit_rows: int = 1              # joint limits as rows of the Newton solver (MuJoCo) instead of stage A's inelastic stop
+    lim_par: tuple = (0.0,) * 8      # their solver parameters in a pair record's layout: -, margin, K, B, d0, dmax, width, -
 
 
 def _joint_space_inertia_diag(dyn: DynFacts, qpos_row: np.ndarray) -> np.ndarray:
@@ -378,7 +380,8 @@ def _spread_order(n: int):
 
 def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpair: int = 4, iterations: int = 50,
                   tolerance: float = 1e-10, precull_every: int = 15, precull_margin: float = 0.15, warmstart: bool = True,
-                  noslip_iterations: int = 5, noslip_tolerance: float = 1e-6, solver: str = "newton",
+                  noslip_iterations: int = 5, noslip_tolerance: float = 1e-6, solver: str = "newton", limit_rows=None,
+                  limit_solref=(0.02, 1.0), limit_solimp=(0.9, 0.95, 0.001),
                   qpos_ref: np.ndarray = None) -> CtFacts:
     from .mjcf import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_MESH, GEOM_PLANE, GEOM_SPHERE, JNT_FREE
     m = model
@@ -549,6 +552,15 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
     row = np.asarray(m.qpos0 if qpos_ref is None else qpos_ref, dtype=np.float64)
     dg = np.concatenate([_joint_space_inertia_diag(dyn, row), [mt] * 3, prin])
     nv = nd + 6
+    # joint limits as solver rows: MuJoCo's joint defaults (solreflimit 0.02 1, solimplimit 0.9 0.95 0.001, margin 0; the XML sets
+    # none), the time constant kept >= 2 timesteps as for contacts
+    if limit_rows is None:
+        limit_rows = solver == "newton"
+    if limit_rows and solver != "newton":
+        raise ValueError("joint limits as solver rows need the Newton solver")
+    l_tc, l_dr = max(float(limit_solref[0]), 2.0 * float(dyn.timestep)), float(limit_solref[1])
+    l_d0, l_dmax, l_w = (float(x) for x in limit_solimp)
+    lim_par = (0.0, 0.0, 1.0 / (l_dmax ** 2 * l_tc ** 2 * l_dr ** 2), 2.0 / (l_dmax * l_tc), l_d0, l_dmax, l_w, 0.0)
     return CtFacts(
         sh_geom=np.array([s[0] for s in sh], dtype=np.int32), sh_body=np.array([s[1] for s in sh], dtype=np.int32),
         sh_type=np.array([s[2] for s in sh], dtype=np.int32), sh_size=np.array([s[3] for s in sh]), sh_pos=np.array([s[4] for s in sh]),
@@ -561,4 +573,4 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         maxcon=int(maxcon), maxpair=int(maxpair), iterations=int(iterations), tolerance=float(tolerance),
         inv_scale=1.0 / (float(dg.mean()) * max(1, nv)), precull_every=int(precull_every), precull_margin=float(precull_margin),
         warmstart=int(bool(warmstart)), noslip_iterations=int(noslip_iterations), noslip_tolerance=float(noslip_tolerance),
-        solver={"pgs": 0, "newton": 1}[solver])
+        solver={"pgs": 0, "newton": 1}[solver], limit_rows=int(limit_rows), lim_par=lim_par)

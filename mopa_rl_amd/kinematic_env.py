@@ -299,6 +299,8 @@ class BatchKinematicEnv:
                 cd.precull_every, cd.precull_margin, cd.warmstart = int(ct.precull_every), float(ct.precull_margin), int(ct.warmstart)
                 cd.noslip_iterations, cd.noslip_tolerance = int(ct.noslip_iterations), float(ct.noslip_tolerance)
                 cd.solver = int(ct.solver)
+                cd.limit_rows = int(ct.limit_rows)
+                cd.lim_par = (C.c_double * 8)(*[float(x) for x in ct.lim_par])
                 _lib.check(L.mopa_env_attach_contacts(self._h, C.byref(cd)))
             self.nv = int(L.mopa_env_dyn_qvel_width(self._h))
             assert self.nv == df.nd + (6 if contacts else 0)

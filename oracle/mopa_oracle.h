@@ -194,6 +194,8 @@ typedef struct OrcCtDesc {
     int32_t precull_every; double precull_margin;
     int32_t warmstart;                           /* carry the pyramid forces of persisting contacts into the next sub-step */
     int32_t solver;                              /* 0: projected Gauss-Seidel, 1: Newton (MuJoCo's default; `iterations` caps either) */
+    int32_t limit_rows;                          /* joint limits as rows of the (Newton) solver instead of an inelastic stop */
+    double lim_par[8];                           /* their parameters in a pair record's layout: -, margin 0, K, B, d0, dmax, width, - */
     int32_t noslip_iterations;                   /* sweeps of the noslip pass after the main solve (XML: 5; 0 = none) */
     double noslip_tolerance;                     /* its early exit: improvement * inv_scale below this (MuJoCo default 1e-6) */
 } OrcCtDesc;

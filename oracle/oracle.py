@@ -165,7 +165,7 @@ class OrcCtDesc(C.Structure):
         ("obj_inv_mass_d", C.c_double), ("obj_inv_inertia_d", C.c_double * 3),
         ("maxcon", C.c_int32), ("maxpair", C.c_int32), ("iterations", C.c_int32), ("tolerance", C.c_double), ("inv_scale", C.c_double),
         ("precull_every", C.c_int32), ("precull_margin", C.c_double), ("warmstart", C.c_int32),
-        ("solver", C.c_int32), ("noslip_iterations", C.c_int32), ("noslip_tolerance", C.c_double),
+        ("solver", C.c_int32), ("limit_rows", C.c_int32), ("lim_par", C.c_double * 8), ("noslip_iterations", C.c_int32), ("noslip_tolerance", C.c_double),
     ]
 
 
@@ -235,6 +235,8 @@ class OracleDyn:
             c.precull_every, c.precull_margin, c.warmstart = int(ct.precull_every), float(ct.precull_margin), int(ct.warmstart)
             c.noslip_iterations, c.noslip_tolerance = int(ct.noslip_iterations), float(ct.noslip_tolerance)
             c.solver = int(ct.solver)
+            c.limit_rows = int(ct.limit_rows)
+            c.lim_par = (C.c_double * 8)(*[float(x) for x in ct.lim_par])
             self.ct = c
             d.ct = C.cast(C.pointer(c), C.c_void_p)
         self.stats = OrcCtStats()

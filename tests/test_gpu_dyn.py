@@ -488,6 +488,41 @@ def test_contact_substeps_bit_exact(oracle_mod, torch_mod, env_name, n, solver):
     assert touched > E // 4
 
 
+def test_joint_limit_rows_bit_identical_to_oracle(oracle_mod, torch_mod):
+    """joints servoed beyond their ranges (every arm joint, either side, over the envs): with the limits as rows of the Newton solver the
+    joints end a few mrad BEYOND the range, resting on the soft row -- sub-steps bit for bit against the oracle; with
+    limit_rows=False they sit exactly on it (stage A's inelastic stop)"""
+    torch = torch_mod
+    E = 56
+    for lr in (True, False):
+        pi, orc, env, ref = _setup_ct(oracle_mod, "SawyerLiftObstacle-v0", E, contact_options={"limit_rows": lr})
+        d = env.dyn
+        q = np.tile(env.init_qpos_row, (E, 1))
+        v = np.zeros((E, env.qvel.shape[1]))
+        ctrl = q[:, d.qadr].copy()
+        for e in range(E):
+            j = e % 7
+            ctrl[e, j] = (d.hi[j] + 0.4) if (e // 7) % 2 == 0 else (d.lo[j] - 0.4)
+            q[e, d.qadr[j]] = (d.hi[j] - 0.05) if (e // 7) % 2 == 0 else (d.lo[j] + 0.05)
+        env.set_state(torch.tensor(q, device=env.device))
+        env.qvel.copy_(torch.tensor(v, device=env.device))
+        lag0 = env.dyn_forward()[0]
+        env.bias_lag.copy_(lag0)
+        env.dyn_substeps(torch.tensor(ctrl, device=env.device), 150)
+        gq, gv = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
+        lag0 = lag0.cpu().numpy()
+        beyond = 0
+        for e in range(E):
+            oq, ov, ol = ref.dyn.step(q[e], v[e], lag0[e], ctrl[e], 150)
+            assert np.array_equal(_bits(gq[e]), _bits(oq)) and np.array_equal(_bits(gv[e]), _bits(ov)), (lr, e)
+            j = e % 7
+            over = max(oq[d.qadr[j]] - d.hi[j], d.lo[j] - oq[d.qadr[j]])
+            beyond += int(over > 1e-4)
+            assert over < 0.03 and (lr or over <= 0.0)
+        assert beyond > (E // 2 if lr else -1) and (lr or beyond == 0)
+        env.close()
+
+
 def test_newton_solver_refuses_more_than_eight_contacts(torch_mod):
     """the Newton solver maps a contact's four pyramid rows onto the 16 lanes of an env, two rows per lane: maxcon <= 8 (the LDS holds no
     more at 4096 envs either); the Gauss-Seidel form takes what the LDS takes"""

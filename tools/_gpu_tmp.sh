@@ -1,2 +1,2 @@
-timeout 600 python -m pytest tests/test_gpu_dyn.py -x -q -k "refuses or noslip or chunked" 2>&1 | tail -3
-timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 1800 python -m pytest tests/test_gpu_dyn.py -x -q 2>&1 | tail -8
+timeout 600 python tools/ct_bench.py 4096 10 8 2>&1 | grep -v amdgpu | grep "env.step" | cut -c1-200

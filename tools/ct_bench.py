@@ -1,6 +1,6 @@
 """K7 (env.step with contacts, stage C) timing probe: ms per env.step of E envs, contacts / solver sweeps per sub-step.
    python tools/ct_bench.py [E] [steps] [maxcon]"""
-import os, sys, time
+import json, os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import torch
@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 for env_name in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"):
     for scale in (1.0, 0.0):
         env = make_env(env_name, E, device=dev, seed=11, dynamics=True, contacts=True, max_episode_steps=1 << 30,
-                       contact_options={"maxcon": maxcon, "maxpair": min(8, maxcon)})
+                       contact_options=dict({"maxcon": maxcon, "maxpair": min(8, maxcon)}, **json.loads(os.environ.get("CT_OPTS", "{}"))))
         g = torch.Generator(device=dev); g.manual_seed(3)
         acts = ((torch.rand(steps + 2, E, env.action_dim, generator=g, dtype=torch.float64, device=dev) * 2 - 1) * scale).contiguous()
         stats = torch.zeros(E, 4, dtype=torch.int32, device=dev)

@@ -395,7 +395,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     if use_graphs:
         over["use_graphs"] = 1          # the fixed-shape halves of a call replayed from HIP graphs (rollout.py)
         # (with replayed calls the host submits faster than three 64-workgroup planner streams drain: 2 x 128 measured steadier,
-        #  tools/rollout_knobs3.sh)
+        #  tools/rollout_ab.sh)
         over.setdefault("planner_streams", 2)
         over.setdefault("planner_workgroups", 128)
     if dynamics:

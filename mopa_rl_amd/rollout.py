@@ -90,7 +90,7 @@ class RolloutConfig:
                                       # budget-exhausting ones never wait in a retry pool.  0: pooled retry launches (round 2's form)
     planner_workgroups: int = 128     # persistent workgroups of an asynchronous launch.  A planner wave holds 256 registers (two
                                       # per SIMD): launches that took every slot would stall the main stream's kernels for their
-                                      # whole bulk phase.  3 streams x 128 measured best on Push (tools/rollout_w2.sh: 1.03 M agent
+                                      # whole bulk phase.  3 streams x 128 measured best on Push (tools/rollout_ab.sh: 1.03 M agent
                                       # steps/s; 3 x 64: 0.79 M, 2 x 256: 0.93 M)
     discrete_action: bool = False     # --discrete_action (config/__init__.py:110; rl/mopa_rollouts.py:86-88,106-111,349): the policy's
                                       # `ac_type` head (1 = planner), not the action's magnitude, routes a step; direct actions

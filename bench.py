@@ -293,14 +293,23 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
     q_init = env.qpos.clone()
     env.step(acts[0]); env.step(acts[1])
     torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for t in range(steps):
-        env.step(acts[2 + t])
-    ev1.record()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    q_warm = [x.clone() for x in (env.qpos, env.qvel, env.bias_lag, env.prev_state, env.has_prev, env.ep_len)]
+    # the same `steps` steps twice from the same state (the GPU boxes are shared: a pass next to another tenant's burst takes 2-3x as
+    # long); both times are reported, the rate is the faster pass's
+    passes = []
+    for rep in range(2):
+        for dst, src in zip((env.qpos, env.qvel, env.bias_lag, env.prev_state, env.has_prev, env.ep_len), q_warm):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for t in range(steps):
+            env.step(acts[2 + t])
+        ev1.record()
+        torch.cuda.synchronize()
+        passes.append((time.perf_counter() - t0, ev0.elapsed_time(ev1)))
+    dt, gpu_ms = min(passes)
     nd, nsub = env.dyn.nd, env.dyn.nsub
     bytes_per_step = 6 * nd * 8 + 2 * env.action_dim * 8 + env.obs_dim * 8 + 18       # q / qvel / lagged bias in+out, action, prev_state, obs, flags
     what = (f"servo + contacts (stage C): as `dynamics`, plus contacts of the arm with the scene, the manipulated object as a free rigid body and "
@@ -315,7 +324,7 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
     blk = {"dynamics": what,
            "config": f"{env_name} env.step with servo dynamics, {E} envs, uniform policy actions in [-1,1]",
            "steps_per_s": E * steps / dt, "ms_per_batch": dt / steps * 1e3, "substeps_per_s": E * steps * nsub / dt,
-           "gpu_ms_per_batch": ev0.elapsed_time(ev1) / steps,
+           "gpu_ms_per_batch": gpu_ms / steps, "ms_per_batch_passes": [p[0] / steps * 1e3 for p in passes],
            "algorithmic_bytes_per_env_step": bytes_per_step, "achieved_GBps": E * steps * bytes_per_step / dt / 1e9,
            "bound": ("latency: 16 lanes per env, one wave per SIMD (1024 workgroups of 4 envs): chain walk + contact culling / narrow phase + "
                      "constraint rows + solver iterations of a sub-step; not HBM") if contacts else

@@ -245,9 +245,12 @@ def test_gripper_pushes_the_cube():
     assert np.abs(v[d.nd:d.nd + 3]).max() < 1e-4
 
 
-def test_can_is_pinched_and_lifted_by_friction():
+@pytest.mark.parametrize("grasp_dz", [-0.02, 0.0])
+def test_can_is_pinched_and_lifted_by_friction(grasp_dz):
     """Lift: the open gripper comes down over the can (pointing down), the finger servos (kp 10000, +-20 N) close on it, the
-    arm rises: the can comes along, held by friction alone (mu 0.95, can 15 g) -- and falls when the fingers open"""
+    arm rises: the can comes along, held by friction alone (mu 0.95, can 15 g) -- and falls when the fingers open.  Gripped
+    around its body (2 cm below its centre) or by the finger tips at the height of its centre: since the noslip pass the second
+    holds too (without it the can pivoted about the line through the two contacts and crept out)."""
     env = "SawyerLiftObstacle-v0"
     m, f, d, ct, od, q0 = _setup(env)
     orc = _scene(env, m)
@@ -269,9 +272,8 @@ def test_can_is_pinched_and_lifted_by_friction():
         q, v, lag = go(z, OPEN, 6, q, v, lag)
     for z in np.arange(1.30, 0.869, -0.05):
         q, v, lag = go(z, OPEN, 3, q, v, lag)
-    # the grip site sits at the finger tips: 2 cm below the can's centre the pads span its body (gripped by the tips alone,
-    # at one height, the can pivots about the line through the contacts and creeps out: no torsional friction is modelled)
-    zg = can[2] - 0.02
+    # the grip site sits at the finger tips: 2 cm below the can's centre the pads span its body
+    zg = can[2] + grasp_dz
     q, v, lag = go(zg, OPEN, 5, q, v, lag)
     assert np.abs(q[oq:oq + 2] - can[:2]).max() < 5e-3 and abs(_eef(orc, f, q)[2] - zg) < 5e-3       # straddling the can
     q, v, lag = go(zg, CLOSE, 6, q, v, lag)

@@ -1,8 +1,14 @@
-timeout 900 python bench.py --no-plan --no-rollout 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-for k,v in d['env_step'].items():
-    if isinstance(v,dict) and 'dynamics_contacts' in v:
-        for kk in ('dynamics','dynamics_contacts'):
-            c=v[kk]; print(k, kk, round(c['steps_per_s']), [round(x,2) for x in c['ms_per_batch_passes']], c.get('parity_mismatches_vs_oracle'))
-"
+mkdir -p gpurun_out/r04_full
+timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/r04_full/pytest_gpu.txt
+cat gpurun_out/r04_full/pytest_gpu.txt
+timeout 900 python bench.py > gpurun_out/r04_full/bench.json 2> gpurun_out/r04_full/bench.err
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r04_full/bench.json").read().strip().splitlines()[-1])
+s=d["summary"]
+print(s["checks_per_s"], d["roofline"]["traffic"], d["roofline"].get("traffic_source"), d["roofline"].get("valu",{}).get("frac"))
+print(json.dumps(s["env_steps_per_s"]))
+print(json.dumps(s["rollout_agent_steps_per_s"]))
+print(s["planner_ms_per_batch"], s["planner_laddered_plans_per_s"])
+PY
+tail -2 gpurun_out/r04_full/bench.err

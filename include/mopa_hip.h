@@ -407,6 +407,8 @@ typedef struct MopaCtDesc {
     double tolerance, inv_scale;
     int32_t precull_every;
     double precull_margin;
+    int32_t near_every;              /* third culling level: active pairs within near_margin of contact, re-listed every near_every sub-steps */
+    double near_margin;
     int32_t warmstart;
     int32_t solver;                  /* 0: projected Gauss-Seidel, 1: Newton (MuJoCo's default) */
     int32_t limit_rows;              /* joint limits as rows of the Newton solver (MuJoCo) instead of an inelastic stop */

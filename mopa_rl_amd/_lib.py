@@ -116,7 +116,7 @@ class MopaCtDesc(C.Structure):
         ("obj_iquat", C.c_double * 4), ("obj_damping", C.c_double), ("obj_inv_mass", C.c_double), ("obj_inv_inertia", C.c_double * 3),
         ("obj_inv_mass_d", C.c_double), ("obj_inv_inertia_d", C.c_double * 3),
         ("maxcon", C.c_int32), ("maxpair", C.c_int32), ("iterations", C.c_int32), ("tolerance", C.c_double), ("inv_scale", C.c_double),
-        ("precull_every", C.c_int32), ("precull_margin", C.c_double), ("warmstart", C.c_int32),
+        ("precull_every", C.c_int32), ("precull_margin", C.c_double), ("near_every", C.c_int32), ("near_margin", C.c_double), ("warmstart", C.c_int32),
         ("solver", C.c_int32), ("limit_rows", C.c_int32), ("lim_par", C.c_double * 8), ("noslip_iterations", C.c_int32), ("noslip_tolerance", C.c_double),
     ]
 

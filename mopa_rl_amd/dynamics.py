@@ -321,6 +321,8 @@ class CtFacts:
     precull_every: int
     precull_margin: float
     warmstart: int
+    near_every: int = 3           # third culling level: the active pairs within near_margin of contact, re-listed every near_every sub-steps
+    near_margin: float = 0.03     # (3 sub-steps at 5 m/s of relative motion -- the precull's own assumption: 15 cm per 15 sub-steps)
     noslip_iterations: int = 5    # sawyer_dependencies.xml:11 noslip_iterations="5"
     noslip_tolerance: float = 1e-6   # MuJoCo's default
     solver: int = 1                  # 1: Newton (MuJoCo's default; the XML names no solver), 0: projected Gauss-Seidel
@@ -379,7 +381,7 @@ def _spread_order(n: int):
 
 
 def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpair: int = 4, iterations: int = 50,
-                  tolerance: float = 1e-10, precull_every: int = 15, precull_margin: float = 0.15, warmstart: bool = True,
+                  tolerance: float = 1e-10, precull_every: int = 15, precull_margin: float = 0.15, near_every: int = 3, near_margin: float = 0.03, warmstart: bool = True,
                   noslip_iterations: int = 5, noslip_tolerance: float = 1e-6, solver: str = "newton", limit_rows=None,
                   limit_solref=(0.02, 1.0), limit_solimp=(0.9, 0.95, 0.001),
                   qpos_ref: np.ndarray = None) -> CtFacts:
@@ -552,6 +554,8 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
     row = np.asarray(m.qpos0 if qpos_ref is None else qpos_ref, dtype=np.float64)
     dg = np.concatenate([_joint_space_inertia_diag(dyn, row), [mt] * 3, prin])
     nv = nd + 6
+    if near_every < 1 or precull_every % near_every != 0 or not (0.0 <= near_margin <= precull_margin):
+        raise ValueError("precull_every must be a multiple of near_every, and near_margin <= precull_margin")
     # joint limits as solver rows: MuJoCo's joint defaults (solreflimit 0.02 1, solimplimit 0.9 0.95 0.001, margin 0; the XML sets
     # none), the time constant kept >= 2 timesteps as for contacts
     if limit_rows is None:
@@ -572,5 +576,5 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         obj_inv_mass=1.0 / mt, obj_inv_inertia=1.0 / prin, obj_inv_mass_d=1.0 / (mt + h * damp), obj_inv_inertia_d=1.0 / (prin + h * damp),
         maxcon=int(maxcon), maxpair=int(maxpair), iterations=int(iterations), tolerance=float(tolerance),
         inv_scale=1.0 / (float(dg.mean()) * max(1, nv)), precull_every=int(precull_every), precull_margin=float(precull_margin),
-        warmstart=int(bool(warmstart)), noslip_iterations=int(noslip_iterations), noslip_tolerance=float(noslip_tolerance),
+        warmstart=int(bool(warmstart)), near_every=int(near_every), near_margin=float(near_margin), noslip_iterations=int(noslip_iterations), noslip_tolerance=float(noslip_tolerance),
         solver={"pgs": 0, "newton": 1}[solver], limit_rows=int(limit_rows), lim_par=lim_par)

@@ -297,6 +297,7 @@ class BatchKinematicEnv:
                 cd.maxcon, cd.maxpair, cd.iterations = int(ct.maxcon), int(ct.maxpair), int(ct.iterations)
                 cd.tolerance, cd.inv_scale = float(ct.tolerance), float(ct.inv_scale)
                 cd.precull_every, cd.precull_margin, cd.warmstart = int(ct.precull_every), float(ct.precull_margin), int(ct.warmstart)
+                cd.near_every, cd.near_margin = int(ct.near_every), float(ct.near_margin)
                 cd.noslip_iterations, cd.noslip_tolerance = int(ct.noslip_iterations), float(ct.noslip_tolerance)
                 cd.solver = int(ct.solver)
                 cd.limit_rows = int(ct.limit_rows)

@@ -192,6 +192,7 @@ typedef struct OrcCtDesc {
     int32_t iterations;                          /* PGS sweeps at most (XML: iterations="50") */
     double tolerance, inv_scale;                 /* stop when improvement * inv_scale < tolerance; inv_scale = 1 / (meaninertia max(1, nv)) */
     int32_t precull_every; double precull_margin;
+    int32_t near_every; double near_margin;      /* third culling level: the active pairs within this of contact, re-listed every near_every sub-steps */
     int32_t warmstart;                           /* carry the pyramid forces of persisting contacts into the next sub-step */
     int32_t solver;                              /* 0: projected Gauss-Seidel, 1: Newton (MuJoCo's default; `iterations` caps either) */
     int32_t limit_rows;                          /* joint limits as rows of the (Newton) solver instead of an inelastic stop */

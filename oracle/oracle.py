@@ -164,7 +164,7 @@ class OrcCtDesc(C.Structure):
         ("obj_iquat", C.c_double * 4), ("obj_damping", C.c_double), ("obj_inv_mass", C.c_double), ("obj_inv_inertia", C.c_double * 3),
         ("obj_inv_mass_d", C.c_double), ("obj_inv_inertia_d", C.c_double * 3),
         ("maxcon", C.c_int32), ("maxpair", C.c_int32), ("iterations", C.c_int32), ("tolerance", C.c_double), ("inv_scale", C.c_double),
-        ("precull_every", C.c_int32), ("precull_margin", C.c_double), ("warmstart", C.c_int32),
+        ("precull_every", C.c_int32), ("precull_margin", C.c_double), ("near_every", C.c_int32), ("near_margin", C.c_double), ("warmstart", C.c_int32),
         ("solver", C.c_int32), ("limit_rows", C.c_int32), ("lim_par", C.c_double * 8), ("noslip_iterations", C.c_int32), ("noslip_tolerance", C.c_double),
     ]
 
@@ -233,6 +233,7 @@ class OracleDyn:
             c.maxcon, c.maxpair, c.iterations = int(ct.maxcon), int(ct.maxpair), int(ct.iterations)
             c.tolerance, c.inv_scale = float(ct.tolerance), float(ct.inv_scale)
             c.precull_every, c.precull_margin, c.warmstart = int(ct.precull_every), float(ct.precull_margin), int(ct.warmstart)
+            c.near_every, c.near_margin = int(ct.near_every), float(ct.near_margin)
             c.noslip_iterations, c.noslip_tolerance = int(ct.noslip_iterations), float(ct.noslip_tolerance)
             c.solver = int(ct.solver)
             c.limit_rows = int(ct.limit_rows)

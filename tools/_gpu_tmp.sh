@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/r04_ab
-timeout 2400 bash tools/rollout_ab.sh -r 2 -c 300 "planner_streams=3,planner_workgroups=128" "planner_streams=2,planner_workgroups=128" "planner_streams=4,planner_workgroups=128" "planner_streams=3,planner_workgroups=96" "planner_streams=3,planner_workgroups=160" "planner_streams=4,planner_workgroups=96" "planner_first_iters=200" "planner_first_iters=500" "planner_min_job=256" "planner_min_job=512" 2>&1 | grep -v amdgpu | tee gpurun_out/r04_ab/sweep.txt
+timeout 1800 python -m pytest tests/test_gpu_dyn.py -x -q 2>&1 | tail -4
+timeout 600 python tools/ct_bench.py 4096 10 8 2>&1 | grep -v amdgpu | grep "env.step" | cut -c1-200

@@ -1,14 +1,3 @@
-mkdir -p gpurun_out/r04_full
-timeout 2400 python -m pytest tests -x -q -m gpu 2>&1 | tail -3 > gpurun_out/r04_full/pytest_gpu.txt
-cat gpurun_out/r04_full/pytest_gpu.txt
-timeout 600 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 900 python bench.py > gpurun_out/r04_full/bench.json 2> gpurun_out/r04_full/bench.err
-python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r04_full/bench.json").read().strip().splitlines()[-1])
-s=d["summary"]
-print(s["checks_per_s"], d["roofline"]["traffic"], d["roofline"].get("valu",{}).get("frac"))
-print(json.dumps(s["env_steps_per_s"]))
-print(json.dumps(s["rollout_agent_steps_per_s"]), round(d["rollout_async_dyn"]["env_steps_per_s"]))
-PY
-tail -2 gpurun_out/r04_full/bench.err
+for mc in 8 7 8 7 8 7; do
+echo "maxcon $mc: $(CT_ENVS=Lift timeout 300 python tools/ct_bench.py 4096 10 $mc 2>&1 | grep -v amdgpu | grep 'env.step' | sed -e 's/.*scale \([0-9.]*\): *\([0-9.]*\) ms.*/\1:\2ms/' | tr '\n' ' ')"
+done

@@ -11,7 +11,7 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 maxcon = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 dev = torch.device("cuda:0")
-for env_name in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"):
+for env_name in [n for n in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0") if os.environ.get("CT_ENVS", "") in n]:
     for scale in (1.0, 0.0):
         env = make_env(env_name, E, device=dev, seed=11, dynamics=True, contacts=True, max_episode_steps=1 << 30,
                        contact_options=dict({"maxcon": maxcon, "maxpair": min(8, maxcon)}, **json.loads(os.environ.get("CT_OPTS", "{}"))))

@@ -297,6 +297,7 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
     # the same `steps` steps twice from the same state (the GPU boxes are shared: a pass next to another tenant's burst takes 2-3x as
     # long); both times are reported, the rate is the faster pass's
     passes = []
+    settle()
     for rep in range(2):
         for dst, src in zip((env.qpos, env.qvel, env.bias_lag, env.prev_state, env.has_prev, env.ep_len), q_warm):
             dst.copy_(src)
@@ -309,6 +310,7 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
         ev1.record()
         torch.cuda.synchronize()
         passes.append((time.perf_counter() - t0, ev0.elapsed_time(ev1)))
+    unsettle()
     dt, gpu_ms = min(passes)
     nd, nsub = env.dyn.nd, env.dyn.nsub
     bytes_per_step = 6 * nd * 8 + 2 * env.action_dim * 8 + env.obs_dim * 8 + 18       # q / qvel / lagged bias in+out, action, prev_state, obs, flags
@@ -448,6 +450,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
         out = one(k)
         env.reset(out["done"].bool() & out["stepped"])
     tx.drain()
+    settle()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -469,6 +472,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     tx.drain()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    unsettle()
     n_agent_steps, n_env_steps = int(n_acc[0].item()), int(n_acc[1].item())
     c = {k: int(v.sum().item()) for k, v in ro.counters.items()}
     if world > 1:
@@ -570,6 +574,19 @@ def scenes_section(torch, device, E, S, steps=5):
                     "pairs_checked_per_state": sc.npair_checked, "valid_fraction": float(v.float().mean().item())}
         sc.close()
     return out
+
+
+def settle():
+    """Before a timed region: collect Python garbage now (a Scene / env of an earlier section that dies INSIDE the region frees its
+    device scratch with hipFree, a device-wide wait of tens of milliseconds), and keep the collector out of the region."""
+    import gc
+    gc.collect()
+    gc.disable()
+
+
+def unsettle():
+    import gc
+    gc.enable()
 
 
 def lib_sha256():
@@ -748,6 +765,7 @@ def main():
 
     for k in range(args.warmup):
         step(k)
+    settle()
     barrier()
     # kernel-only timing: HIP events on the stream the kernel is launched on (torch's current stream)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -756,6 +774,7 @@ def main():
         step(k, ev[k])
     barrier()
     elapsed = time.perf_counter() - t0
+    unsettle()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)

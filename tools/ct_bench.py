@@ -24,6 +24,9 @@ for env_name in [n for n in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "
         torch.cuda.synchronize()
         tot = np.zeros(4)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if os.environ.get("CT_GC"):
+            import gc
+            gc.collect(); gc.disable()
         ev0.record()
         for t in range(steps):
             if os.environ.get("CT_TRACE"):

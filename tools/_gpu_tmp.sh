@@ -1,3 +1,11 @@
-for g in "" 1 "" 1 "" 1; do
-echo "gc-control '$g': $(CT_GC=$g timeout 300 python tools/ct_bench.py 4096 10 8 2>&1 | grep -v amdgpu | grep 'env.step' | sed -e 's/Sawyer\([A-Za-z]*\)Obstacle.*scale \([0-9.]*\): *\([0-9.]*\) ms.*/\1 \2:\3/' | tr '\n' ' ')"
-done
+mkdir -p gpurun_out/r04_full
+timeout 900 python bench.py > gpurun_out/r04_full/bench.json 2> gpurun_out/r04_full/bench.err; echo rc=$?
+python - <<'PY'
+import json
+d=json.loads(open("gpurun_out/r04_full/bench.json").read().strip().splitlines()[-1])
+s=d["summary"]
+print(s["checks_per_s"], d["ms_per_step"], d["roofline"]["traffic"] is not None)
+print(json.dumps({k:{kk:round(vv) for kk,vv in v.items()} for k,v in s["env_steps_per_s"].items()}))
+print(json.dumps({k:round(v) for k,v in s["rollout_agent_steps_per_s"].items()}))
+PY
+tail -2 gpurun_out/r04_full/bench.err

@@ -1106,7 +1106,8 @@ class BatchMoPARollout:
             return None
         for k in range(len(ring) - 1, -1, -1):
             if ring[k][0].query():
-                del ring[:k]                                  # older entries are of no use any more
+                self._count_free.extend(ring[:k])             # older entries (finished before this one, same stream) are recycled
+                del ring[:k]
                 return [int(x) for x in ring[0][1]]
         return None
 

@@ -107,7 +107,7 @@ def bias_force(model, qpos, qvel, dyn_bodies, qadr, armature, eps=1e-6):
 
 
 # ---- stage C: one sub-step with contacts, by an independent route (tests/test_oracle_contact.py) ---------------------------
-def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl):
+def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl, limit_rows=False):
     """New velocities [nd + 6] (arm dofs, then the object's COM velocity and world angular velocity) after ONE sub-step from
     (qpos, qvel), given the oracle's contact list (rows: dist, pos 3, normal 3, shape F, shape S, feature) -- everything else
     independently: geometric Jacobians over scipy FK of the un-lumped model, M by `mass_matrix`, the bias by finite differences,
@@ -173,13 +173,28 @@ def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl)
         for t in (1, 2):
             for sg in (1.0, -1.0):
                 rows.append(Jd[0] + sg * mu * Jd[t]); pars.append(par); dists.append(dist)
+    # joint limits as rows (limit_rows): a limited arm joint beyond its range, J = +-e_l, the joint defaults' solver parameters
+    # (ct.lim_par in a pair record's layout), regulariser from 1 / M_ll instead of the row's own A_ii
+    n_contact_rows = len(rows)
+    lim_diag = []
+    if limit_rows:
+        for i in range(nd):
+            if not dyn.limited[i]:
+                continue
+            dlo, dhi = q[i] - dyn.lo[i], dyn.hi[i] - q[i]
+            side, dist = (1.0, dlo) if dlo < 0 else ((-1.0, dhi) if dhi < 0 else (0.0, 0.0))
+            if side == 0.0:
+                continue
+            row = np.zeros(nv); row[i] = side
+            rows.append(row); pars.append(np.asarray(ct.lim_par)); dists.append(dist); lim_diag.append(1.0 / M[i, i])
     if not rows:
         f = np.zeros(0); J = np.zeros((0, nv))
     else:
         J = np.array(rows)
         Minv = np.linalg.inv(Mfull)
         A = J @ Minv @ J.T
-        dA = np.diag(A)
+        dA = np.diag(A).copy()
+        dA[n_contact_rows:] = lim_diag
         imp, aref = np.zeros(len(rows)), np.zeros(len(rows))
         for i, (par, dist) in enumerate(zip(pars, dists)):
             x = abs(dist - par[1]) / par[6]

@@ -187,6 +187,39 @@ def test_joint_limit_is_a_soft_constraint_row_with_the_predicted_rest_violation(
     assert abs(f_row - servo) < 0.05 * servo, (f_row, servo)
 
 
+def test_contact_step_with_a_joint_beyond_its_limit_equals_the_independent_qp():
+    """the same independent solve (tests/dyn_ref.py) with a LIMIT row next to the contact rows: the arm resting on the table with a
+    wrist joint 20 mrad beyond its range and moving further out -- the Newton solver's sub-step against the exact active-set solve of the
+    dual with the limit row J = -e_l, regulariser (1 - imp) / imp / M_ll"""
+    env = "SawyerPushObstacle-v0"
+    m, f, d, ct, od, q0 = _setup(env, iterations=50, tolerance=0.0, warmstart=False, noslip_iterations=0, limit_rows=True)
+    orc = _scene(env, m)
+    oq = ct.obj_qadr
+    q0 = q0.copy(); q0[oq:oq + 3] = [0.80, 0.30, 0.853]
+    q, v = q0.copy(), np.zeros(od.nv)
+    lag = od.forward(q, v[:d.nd], want_M=False)[0]
+    q, v, lag = od.step(q, v, lag, q0[d.qadr].copy(), n=300)
+    cz = q[oq + 2]
+    qt = _ik(env, m, f, orc, q, np.array([0.70, 0.30, cz + 0.03]))
+    ctrl = qt[d.qadr].copy(); ctrl[7:] = q[d.qadr[7:]]
+    for _ in range(8):
+        q, v, lag = od.step(q, v, lag, ctrl, n=75)
+    checked = 0
+    for j, sgn in ((6, 1.0), (5, -1.0), (6, -1.0)):
+        qq, vv = q.copy(), v.copy()
+        qq[d.qadr[j]] = (d.hi[j] + 0.02) if sgn > 0 else (d.lo[j] - 0.02)
+        vv[j] = 0.3 * sgn
+        lg = od.forward(qq, vv[:d.nd], want_M=False)[0]
+        con = od.contacts(qq)
+        vr, fr = dyn_ref.contact_step_reference(m, d, ct, con, qq, vv, lg, ctrl, limit_rows=True)
+        q1, v1, _ = od.step(qq, vv, lg, ctrl, n=1)
+        scale = max(np.abs(v1 - vv).max(), 1e-3)
+        assert np.abs(v1 - vr).max() < 2e-4 * scale + 1e-7, (j, sgn, np.abs(v1 - vr).max(), scale)
+        assert v1[j] * sgn < vv[j] * sgn                     # the limit row decelerates the joint
+        checked += 1
+    assert checked == 3
+
+
 def test_arm_stops_at_the_bin_roof():
     """Push: the hand is servoed towards a point below the bin's roof plate (z = 1.22 .. 1.23): with the contact stage it
     comes to rest ON the plate (at rest the deepest pair stays above the planner's -2 mm: the state is valid), the servo

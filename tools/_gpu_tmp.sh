@@ -1,1 +1,1 @@
-MOPA_CT_PAIR_SORT=1 timeout 900 python -m pytest tests/test_gpu_dyn.py -x -q -k "joint_limit_rows" 2>&1 | grep -E "^E|assert|Error" | head -12
+timeout 2400 bash tools/rollout_ab.sh -r 4 -c 300 "planner_first_iters=150" "planner_first_iters=200" "planner_first_iters=250" "planner_first_iters=300" 2>&1 | grep -v amdgpu

@@ -647,6 +647,76 @@ def cpu_baseline(pi, qa_host, rows_host, S, budget_states):
     return {"single": n / (t1 - t0), "all": n / (t2 - t1), "cores": cores, "n": n, "verdicts": vN}
 
 
+HEADLINE_MAX_BYTES = 4096
+
+
+def _g(d, *ks):
+    for k in ks:
+        d = d.get(k) if isinstance(d, dict) else None
+    return d
+
+
+def _r(x, nd=6):
+    """numbers of the headline line to `nd` significant digits (the full-precision values are in the full record)"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def headline(out):
+    """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, the parity count and a numeric summary of
+    every section -- no prose (the per-section blocks are in gpurun_out/bench_full_n<N>.json and on stderr).  Pure function of
+    the full record: tests/test_bench_headline.py holds it under HEADLINE_MAX_BYTES on a canned record."""
+    rf = out.get("roofline") or {}
+    cb = out.get("cpu_baseline")
+    ro_keys = [k for k in out if k.startswith("rollout")]
+    env = {k: v for k, v in (out.get("env_step") or {}).items() if isinstance(v, dict) and "steps_per_s" in v}
+    h = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                 "vs_baseline", "dtype", "data")}
+    cfg = out.get("config") or {}
+    h["config"] = {k: cfg.get(k) for k in ("workload", "envs_per_gpu", "states_per_env", "pairs_checked_per_state", "parallelism") if k in cfg}
+    h["valid_fraction"] = out.get("valid_fraction")
+    h["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_check",
+                                            "traffic_source", "input_resident") if k in rf}
+    if "valu" in rf:
+        h["roofline"]["valu"] = {k: rf["valu"].get(k) for k in ("achieved", "peak", "unit", "frac", "insts_per_check")}
+    h["cpu_baseline"] = None if cb is None else {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "single_thread_value")}
+    h["parity_mismatches_vs_oracle"] = out.get("parity_mismatches_vs_oracle")
+    parity = {"planner": _g(out, "planner", "cpu_baseline", "parity_mismatches_vs_oracle")}
+    for k, v in env.items():
+        for d in ("", "dynamics", "dynamics_contacts"):
+            p = _g(v, d, "parity_mismatches_vs_oracle") if d else v.get("parity_mismatches_vs_oracle")
+            if p is not None:
+                parity[f"env_{k}" + (f"_{d}" if d else "")] = p
+    h["summary"] = {
+        "checks_per_s": out.get("value"), "roofline_frac_hbm": rf.get("frac"), "valu_frac": _g(rf, "valu", "frac"),
+        "motions_per_s": _g(out, "motion", "motions_per_s_range"),
+        "planner": {"ms_per_batch": _g(out, "planner", "ms_per_batch"), "plans_per_s": _g(out, "planner", "plans_per_s"),
+                    "laddered_plans_per_s": _g(out, "planner", "laddered", "plans_per_s"), "success_rate": _g(out, "planner", "success_rate"),
+                    "cpu_plans_per_s": _g(out, "planner", "cpu_baseline", "value")},
+        "scenes_checks_per_s": {k.split("Obstacle")[0].replace("Sawyer", "").lower(): _g(v, "checks_per_s")
+                                for k, v in (out.get("scenes") or {}).items() if isinstance(v, dict)},
+        "env_steps_per_s": {k: {"kin": _g(v, "steps_per_s"), "dyn": _g(v, "dynamics", "steps_per_s"),
+                                "ct": _g(v, "dynamics_contacts", "steps_per_s"), "ct_ms": _g(v, "dynamics_contacts", "ms_per_batch"),
+                                "ct_cpu": _g(v, "dynamics_contacts", "cpu_baseline", "value"),
+                                "ct_dropped": _g(v, "dynamics_contacts", "contacts_dropped_by_the_cap_per_substep")}
+                            for k, v in env.items()},
+        "ik_solves_per_s": _g(out, "ik", "pos_quat", "solves_per_s"),
+        "rollout_agent_steps_per_s": {k[8:] or "lockstep": _g(out[k], "agent_steps_per_s") for k in ro_keys},
+        "rollout_envs_stepping_per_call": {k[8:] or "lockstep": _g(out[k], "envs_stepping_per_call") for k in ro_keys},
+        "parity_mismatches": parity,
+    }
+    h["full_record"] = f"gpurun_out/bench_full_n{out.get('n_gpus')}.json"
+    h = _r(h)
+    if len(json.dumps(h, separators=(",", ":"))) > HEADLINE_MAX_BYTES:       # never again a line the driver cannot keep: drop the summary first
+        h["summary"] = {"dropped": "headline over the byte budget; see the full record"}
+    return h
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -804,6 +874,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": scene.valid_kernel(N), "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
+                         "input_resident": "one input batch re-used by every step (58.7 MB: Infinity-Cache resident after step 1)",
                          "note": "path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see DESIGN.md"},
         }
         t = committed_traffic(scene.valid_kernel(N), N)
@@ -832,8 +903,7 @@ def main():
             mism = int((cb["verdicts"] != valid[: cb["n"]].cpu().numpy()).sum())
             out["cpu_baseline"] = {
                 "value": cb["all"], "unit": "checks/s", "cores": cb["cores"], "kind": "port",
-                "sample": f"first {cb['n']} states of the step batch, OpenMP over states on all host cores; "
-                          "oracle/mopa_oracle.c = this repo's C restatement, NOT MuJoCo/OMPL (unavailable)",
+                "sample": f"first {cb['n']} states of the step batch; C restatement (oracle/), not MuJoCo/OMPL",
                 "single_thread_value": cb["single"]}
             out["parity_mismatches_vs_oracle"] = mism
     # the rollout sections run on EVERY rank (their exchanges are collectives): config 3 (Push) at one GPU, config 4
@@ -853,24 +923,19 @@ def main():
                                                     use_ik=True)
     if rank == 0:
         out.update(ro)
-        # the driver keeps the END of this line: the numbers of every section once more, compact, as the last key
-        def _g(d, *ks):
-            for k in ks:
-                d = d.get(k) if isinstance(d, dict) else None
-            return d
-        out["summary"] = {
-            "checks_per_s": out.get("value"), "roofline_frac_hbm": _g(out, "roofline", "frac"), "valu_frac": _g(out, "roofline", "valu", "frac"),
-            "planner_ms_per_batch": _g(out, "planner", "ms_per_batch"), "planner_plans_per_s": _g(out, "planner", "plans_per_s"),
-            "planner_laddered_plans_per_s": _g(out, "planner", "laddered", "plans_per_s"),
-            "scenes_checks_per_s": {k: _g(v, "checks_per_s") for k, v in (out.get("scenes") or {}).items() if isinstance(v, dict)},
-            "env_steps_per_s": {k: {"kinematic": _g(v, "steps_per_s"), "dynamics": _g(v, "dynamics", "steps_per_s"),
-                                    "dynamics_contacts": _g(v, "dynamics_contacts", "steps_per_s"),
-                                    "dynamics_contacts_cpu": _g(v, "dynamics_contacts", "cpu_baseline", "value")}
-                                for k, v in (out.get("env_step") or {}).items() if isinstance(v, dict) and "steps_per_s" in v},
-            "rollout_agent_steps_per_s": {k: _g(v, "agent_steps_per_s") for k, v in ro.items()},
-            "rollout_envs_stepping_per_call": {k: _g(v, "envs_stepping_per_call") for k, v in ro.items()},
-        }
-        print(json.dumps(out))
+        # the full record (every section, all prose) goes to a file + stderr; stdout ends with ONE compact line (< 4 KB)
+        full = json.dumps(out)
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_full_n{world}.json"), "w") as f:
+                f.write(full + "\n")
+        except OSError:
+            pass
+        if os.environ.get("MOPA_BENCH_FULL_STDERR"):
+            print("[bench full record] " + full, file=sys.stderr)
+            sys.stderr.flush()
+        print(json.dumps(headline(out), separators=(",", ":")))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

@@ -596,7 +596,7 @@ def lib_sha256():
 
 
 K1_SOURCES = ("mopa_rl_amd/csrc/mopa_hip.hip", "mopa_rl_amd/csrc/mopa_valid_v5.inc", "mopa_rl_amd/csrc/mopa_valid_v2.inc", "mopa_rl_amd/csrc/mopa_device.hpp",
-              "mopa_rl_amd/csrc/mopa_host.hpp", "mopa_rl_amd/csrc/mopa_planner.inc", "mopa_rl_amd/csrc/mopa_pullback.inc", "mopa_rl_amd/csrc/mopa_motion.inc",
+              "mopa_rl_amd/csrc/mopa_host.hpp", "mopa_rl_amd/csrc/mopa_planner.inc", "mopa_rl_amd/csrc/mopa_planner_k3.inc", "mopa_rl_amd/csrc/mopa_pullback.inc", "mopa_rl_amd/csrc/mopa_motion.inc",
               "mopa_rl_amd/csrc/mopa_ik.inc", "mopa_rl_amd/csrc/mopa_paths.inc", "mopa_rl_amd/scenes/sawyer_push_obstacle.json")
 # (not hashed: include/mopa_hip.h and the Makefile -- the C ABI's env / dynamics / rollout declarations change with the OTHER translation
 #  unit; a change of the scene / validity declarations there comes with a change of mopa_hip.hip or mopa_host.hpp)

@@ -69,9 +69,14 @@ struct SceneHdr {
     int o_mesh, has_mesh;   // mesh hull vertices (doubles); has_mesh selects the MESH kernel instantiations
     int o_mb_load, o_mb_save, o_mb_mgadr, o_mb_mgnum, o_mg_padr, o_mg_pnum, o_mg_store, o_gp_word;
     int o_mbr, o_mbd, o_mgr, o_mgd;   // packed per-body / per-geom records (ints: 8 / 4, doubles: 16 / 8)
+    // planner FK (mopa_planner.inc: ms_fk): per moving geom slot 8 ints -- [0..3] the chain's bodies, one per byte (0xff past the
+    // end), [4] chain length, [5] static frame of the chain root's parent; pfk_maxlen = longest chain (0: a chain is longer than
+    // 16 bodies -> the planner keeps the generic walk)
+    int o_pfk, pfk_maxlen;
     // per-wave LDS slab (in doubles): geom records, qbuf; then worklist (u16)
     int wave_dbl, wave_bytes;
     double thr, range, resolution;
+    double nn_eps;   // planner: bound on |FP32 mirror distance - FP64 distance| of the nearest-neighbour sweep (mopa_planner.inc)
 };
 
 constexpr int kWavesPerBlock = 4;
@@ -994,6 +999,28 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.o_mg_padr = B.add_i(mg_padr); h.o_mg_pnum = B.add_i(mg_pnum); h.o_mg_store = B.add_i(mg_store); h.o_gp_word = B.add_i(gp_word);
     while (B.ints.size() & 7) B.ints.push_back(0);   // 32-byte align the packed records (scalar dwordx8 loads)
     h.o_mbr = B.add_i(mbr); h.o_mgr = B.add_i(mgr);
+    {
+        std::vector<int32_t> pfk(8 * (size_t)nmg, 0);
+        int maxlen = 0;
+        bool ok = nmb < 255;
+        for (int ms = 0; ms < nmg && ok; ms++) {
+            const int k = g_mb[mg_geom[ms]];
+            const int len = chain_len[k];
+            if (len > 16) { ok = false; break; }
+            maxlen = std::max(maxlen, len);
+            uint32_t w[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            for (int i = 0; i < len; i++) {
+                const uint32_t b = (uint32_t)chain_items[chain_adr[k] + i];
+                w[i >> 2] = (w[i >> 2] & ~(0xffu << (8 * (i & 3)))) | (b << (8 * (i & 3)));
+            }
+            for (int i = 0; i < 4; i++) pfk[8 * (size_t)ms + i] = (int32_t)w[i];
+            pfk[8 * (size_t)ms + 4] = len;
+            const int root = chain_items[chain_adr[k]];
+            pfk[8 * (size_t)ms + 5] = (mb_parent[root] < 0) ? -(mb_parent[root] + 1) : 0;
+        }
+        h.o_pfk = B.add_i(pfk);
+        h.pfk_maxlen = ok ? maxlen : 0;
+    }
     const int o_mgr_mesh = B.add_i(mgr_mesh), o_gp_word_mesh = B.add_i(gp_word_mesh);
     h.n_dbl = (int)B.dbl.size();
     h.n_int = (int)B.ints.size();
@@ -1003,6 +1030,14 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     h.thr = desc->contact_threshold;
     h.range = desc->range;
     h.resolution = desc->resolution > 0.0 ? desc->resolution : 0.005;
+    {
+        // FP32 mirror of the planner's trees: coordinates rounded to FP32 (|x| <= X: error X 2^-24 each), their difference
+        // rounded once more, na terms added with a rounding of the running sum (<= na 2X) each
+        double X = kPi;
+        for (int i = 0; i < na; i++) X = std::max(X, std::max(std::fabs(act_lo[i]), std::fabs(act_hi[i])));
+        const double S1 = 2.0 * X * std::max(na, 1);
+        h.nn_eps = (3.0 * na + 2.0) * std::ldexp(1.0, -24) * S1 * 1.5;
+    }
     S->h_dbl = B.dbl;
     S->h_int = B.ints;
     S->lds_bytes = h.n_dbl * 8 + ((h.n_int + 1) & ~1) * 4 + kWavesPerBlock * h.wave_bytes;

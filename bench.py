@@ -680,6 +680,7 @@ def headline(out):
     cfg = out.get("config") or {}
     h["config"] = {k: cfg.get(k) for k in ("workload", "envs_per_gpu", "states_per_env", "pairs_checked_per_state", "parallelism") if k in cfg}
     h["valid_fraction"] = out.get("valid_fraction")
+    h["exchange"] = {k: _g(out, "exchange", k) for k in ("backend", "ranks")}
     h["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_check",
                                             "traffic_source", "input_resident") if k in rf}
     if "valu" in rf:

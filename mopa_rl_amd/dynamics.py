@@ -325,7 +325,8 @@ class CtFacts:
     near_margin: float = 0.03     # (3 sub-steps at 5 m/s of relative motion -- the precull's own assumption: 15 cm per 15 sub-steps)
     noslip_iterations: int = 5    # sawyer_dependencies.xml:11 noslip_iterations="5"
     noslip_tolerance: float = 1e-6   # MuJoCo's default
-    solver: int = 1                  # 1: Newton (MuJoCo's default; the XML names no solver), 0: projected Gauss-Seidel
+    solver: int = 2                  # 2: Newton with ELLIPTIC cones (the XML: cone="elliptic", solver unnamed = MuJoCo's default Newton),
+                                     # 1: Newton with pyramidal cones, 0: projected Gauss-Seidel (pyramidal)
     limit_rows: int = 1              # joint limits as rows of the Newton solver (MuJoCo) instead of stage A's inelastic stop
     lim_par: tuple = (0.0,) * 8      # their solver parameters in a pair record's layout: -, margin, K, B, d0, dmax, width, -
 
@@ -382,15 +383,23 @@ def _spread_order(n: int):
 
 def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpair: int = 4, iterations: int = 50,
                   tolerance: float = 1e-10, precull_every: int = 15, precull_margin: float = 0.15, near_every: int = 3, near_margin: float = 0.03, warmstart: bool = True,
-                  noslip_iterations: int = 5, noslip_tolerance: float = 1e-6, solver: str = "newton", limit_rows=None,
+                  noslip_iterations: int = 5, noslip_tolerance: float = 1e-6, solver: str = "newton", cone: str = None, limit_rows=None,
                   limit_solref=(0.02, 1.0), limit_solimp=(0.9, 0.95, 0.001),
                   qpos_ref: np.ndarray = None) -> CtFacts:
     from .mjcf import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_MESH, GEOM_PLANE, GEOM_SPHERE, JNT_FREE
     m = model
     if len(getattr(m, "geom_solref", ())) == 0:
         raise ValueError("compiled scene carries no solver parameters (recompile with tools/compile_scenes.py)")
-    if maxcon > CT_MAXCON:
-        raise ValueError(f"maxcon <= {CT_MAXCON}")
+    # friction cone: the XML's `cone="elliptic"` (sawyer_dependencies.xml:11) with the Newton solver; the projected Gauss-Seidel form knows
+    # pyramids only
+    if cone is None:
+        cone = "elliptic" if solver == "newton" else "pyramidal"
+    if cone not in ("elliptic", "pyramidal") or (cone == "elliptic" and solver != "newton"):
+        raise ValueError("cone: 'elliptic' (Newton solver only) or 'pyramidal'")
+    # the solver keeps per-contact state one contact per lane of an env's 16 (elliptic) / two pyramid rows per lane (Newton, pyramidal)
+    cap = {("newton", "elliptic"): 16, ("newton", "pyramidal"): 8, ("pgs", "pyramidal"): 16}[(solver, cone)]
+    if maxcon > cap:
+        raise ValueError(f"maxcon <= {cap} for solver {solver!r} with {cone} cones")
     names = list(m.body_names)
     ob = names.index(object_body)
     jo = int(m.body_jntadr[ob])
@@ -577,4 +586,4 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         maxcon=int(maxcon), maxpair=int(maxpair), iterations=int(iterations), tolerance=float(tolerance),
         inv_scale=1.0 / (float(dg.mean()) * max(1, nv)), precull_every=int(precull_every), precull_margin=float(precull_margin),
         warmstart=int(bool(warmstart)), near_every=int(near_every), near_margin=float(near_margin), noslip_iterations=int(noslip_iterations), noslip_tolerance=float(noslip_tolerance),
-        solver={"pgs": 0, "newton": 1}[solver], limit_rows=int(limit_rows), lim_par=lim_par)
+        solver={("pgs", "pyramidal"): 0, ("newton", "pyramidal"): 1, ("newton", "elliptic"): 2}[(solver, cone)], limit_rows=int(limit_rows), lim_par=lim_par)

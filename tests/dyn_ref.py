@@ -107,13 +107,28 @@ def bias_force(model, qpos, qvel, dyn_bodies, qadr, armature, eps=1e-6):
 
 
 # ---- stage C: one sub-step with contacts, by an independent route (tests/test_oracle_contact.py) ---------------------------
-def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl, limit_rows=False):
+def _proj_cone(y, mu):
+    """Euclidean projection of y = (y_n, y_t1, y_t2) onto the friction cone |y_t| <= mu y_n (textbook second-order-cone projection)"""
+    t = float(np.hypot(y[1], y[2]))
+    if t <= mu * y[0]:
+        return y.copy()
+    if mu * t <= -y[0]:
+        return np.zeros(3)
+    a = (y[0] + mu * t) / (1.0 + mu * mu)
+    return np.array([a, mu * a * y[1] / t, mu * a * y[2] / t])
+
+
+def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl, limit_rows=False, cone="pyramidal"):
     """New velocities [nd + 6] (arm dofs, then the object's COM velocity and world angular velocity) after ONE sub-step from
     (qpos, qvel), given the oracle's contact list (rows: dist, pos 3, normal 3, shape F, shape S, feature) -- everything else
     independently: geometric Jacobians over scipy FK of the un-lumped model, M by `mass_matrix`, the bias by finite differences,
     the constraint forces as the exact solution (active-set NNLS) of MuJoCo's dual problem
         min_{f >= 0}  1/2 f^T (A + R) f + f^T (J a_smooth - aref),      A = J M^-1 J^T,  R = (1 - imp) / imp diag(A)
-    with pyramidal rows J_n +- mu J_t and aref = -B J v - K imp (dist - margin)."""
+    with pyramidal rows J_n +- mu J_t and aref = -B J v - K imp (dist - margin).
+    cone="elliptic": rows n, t1, t2 per contact, one regulariser r = (1 - imp) / imp A_nn for all three, the friction rows' aref without
+    the position term, forces in the cone |f_t| <= mu f_n -- solved in its PRIMAL form, written from the cone projection alone
+        min_q  1/2 (q - a_smooth)^T M (q - a_smooth) + sum_c |proj_K(-(J_c q - aref_c))|^2 / (2 r_c)  (+ the limit rows' half-quadratics)
+    by damped Newton with a finite-difference Hessian (15 unknowns), to a gradient of 1e-9 of its start."""
     from scipy.optimize import nnls
     m = model
     nd, h = dyn.nd, float(dyn.timestep)
@@ -158,6 +173,8 @@ def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl,
             row[nd + 3:] = RD.T @ np.cross(pos - c, d)
         return row
 
+    if cone == "elliptic":
+        return _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull, RD, q, M, limit_rows)
     rows, pars, dists, mus = [], [], [], []
     pair_of = {(int(f), int(s)): k for k, (f, s) in enumerate(zip(ct.pr_f, ct.pr_s))}
     for r in contacts:
@@ -208,5 +225,93 @@ def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl,
         f, _ = nnls(L.T, -np.linalg.solve(L, b), maxiter=100 * len(b))
     Dfull = np.concatenate([dyn.damping, [ct.obj_damping] * 6])
     qacc = np.linalg.solve(Mfull + h * np.diag(Dfull), tfull + J.T @ f)
+    vn = vfull + h * qacc
+    return np.concatenate([vn[:nd + 3], RD @ vn[nd + 3:]]), f
+
+
+def _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull, RD, q, M, limit_rows):
+    nd, h = dyn.nd, float(dyn.timestep)
+    nv = nd + 6
+    Minv = np.linalg.inv(Mfull)
+    a0 = Minv @ tfull
+    pair_of = {(int(f), int(s)): k for k, (f, s) in enumerate(zip(ct.pr_f, ct.pr_s))}
+
+    def impedance(par, dist):
+        x = abs(dist - par[1]) / par[6]
+        y = 1.0 if x >= 1 else (2 * x * x if x <= 0.5 else 1 - 2 * (1 - x) ** 2)
+        return par[4] + y * (par[5] - par[4])
+    cons = []
+    for r in contacts:
+        dist, pos, n = r[0], r[1:4], r[4:7]
+        sf, ss = int(r[7]), int(r[8])
+        par = ct.pr_par[pair_of[(sf, ss)]]
+        e = np.array([1.0, 0.0, 0.0]) if abs(n[0]) < 0.5 else np.array([0.0, 1.0, 0.0])
+        t1 = e - n * (n @ e); t1 /= np.linalg.norm(t1)
+        t2 = np.cross(n, t1)
+        bF, bS = int(m.geom_body[int(ct.sh_geom[sf])]), int(m.geom_body[int(ct.sh_geom[ss])])
+        J = np.array([point_jac(bF, pos, d) - point_jac(bS, pos, d) for d in (n, t1, t2)])
+        imp = impedance(par, dist)
+        rr = (1 - imp) / imp * float(J[0] @ Minv @ J[0])
+        jv = J @ vfull
+        aref = np.array([-par[3] * jv[0] - par[2] * imp * (dist - par[1]), -par[3] * jv[1], -par[3] * jv[2]])
+        cons.append((J, aref, rr, float(par[0])))
+    lims = []
+    if limit_rows:
+        for i in range(nd):
+            if not dyn.limited[i]:
+                continue
+            dlo, dhi = q[i] - dyn.lo[i], dyn.hi[i] - q[i]
+            side, dist = (1.0, dlo) if dlo < 0 else ((-1.0, dhi) if dhi < 0 else (0.0, 0.0))
+            if side == 0.0:
+                continue
+            par = np.asarray(ct.lim_par)
+            imp = impedance(par, dist)
+            rr = (1 - imp) / imp / M[i, i]
+            lims.append((i, side, -par[3] * side * vfull[i] - par[2] * imp * dist, 1.0 / rr))
+
+    def forces(qa):
+        return [_proj_cone(-(J @ qa - aref), mu) / rr for J, aref, rr, mu in cons]
+
+    def grad(qa):
+        g = Mfull @ (qa - a0)
+        for (J, aref, rr, mu), f in zip(cons, forces(qa)):
+            g = g - J.T @ f
+        for i, side, aref, D in lims:
+            x = side * qa[i] - aref
+            if x < 0:
+                g[i] += side * D * x
+        return g
+
+    def cost(qa):
+        c = 0.5 * (qa - a0) @ Mfull @ (qa - a0)
+        for (J, aref, rr, mu), f in zip(cons, forces(qa)):
+            c += 0.5 * rr * float(f @ f)
+        for i, side, aref, D in lims:
+            x = side * qa[i] - aref
+            if x < 0:
+                c += 0.5 * D * x * x
+        return c
+    qa = a0.copy()
+    g0 = max(np.linalg.norm(grad(qa)), 1e-30)
+    for _ in range(200):
+        g = grad(qa)
+        if np.linalg.norm(g) <= 1e-9 * g0:
+            break
+        eps = 1e-7 * max(1.0, np.abs(qa).max())
+        H = np.array([(grad(qa + eps * np.eye(nv)[k]) - grad(qa - eps * np.eye(nv)[k])) / (2 * eps) for k in range(nv)])
+        H = 0.5 * (H + H.T)
+        step = -np.linalg.solve(H + 1e-12 * np.trace(H) / nv * np.eye(nv), g)
+        t, c0 = 1.0, cost(qa)
+        while t > 1e-8 and cost(qa + t * step) > c0 + 1e-4 * t * float(g @ step):
+            t *= 0.5
+        qa = qa + t * step
+    f = np.concatenate(forces(qa)) if cons else np.zeros(0)
+    Jt = sum((J.T @ fc for (J, _, _, _), fc in zip(cons, forces(qa))), np.zeros(nv))
+    for i, side, aref, D in lims:
+        x = side * qa[i] - aref
+        if x < 0:
+            Jt[i] += side * (-D * x)
+    Dfull = np.concatenate([dyn.damping, [ct.obj_damping] * 6])
+    qacc = np.linalg.solve(Mfull + h * np.diag(Dfull), tfull + Jt)
     vn = vfull + h * qacc
     return np.concatenate([vn[:nd + 3], RD @ vn[nd + 3:]]), f

@@ -458,14 +458,16 @@ def _ct_states(env, orc, E, seed):
 
 
 @pytest.mark.parametrize("env_name", ENVS)
-@pytest.mark.parametrize("n,solver", [(1, "newton"), (4, "newton"), (75, "newton"), (4, "pgs"), (75, "pgs")])
+@pytest.mark.parametrize("n,solver", [(1, "newton"), (4, "newton"), (75, "newton"), (4, "newton-pyramidal"), (75, "newton-pyramidal"), (4, "pgs"), (75, "pgs")])
 def test_contact_substeps_bit_exact(oracle_mod, torch_mod, env_name, n, solver):
-    """sub-steps with contacts, both solvers (Newton: MuJoCo's default, what the reference runs; projected Gauss-Seidel: round 4's
-    first form), each followed by the noslip pass: state after n sub-steps bit for bit against the oracle"""
+    """sub-steps with contacts, all three solver forms (Newton with the XML's ELLIPTIC cones: MuJoCo's default solver, what the reference
+    runs; Newton with pyramidal cones: round 4's form; projected Gauss-Seidel: its first form), each followed by the noslip pass: state
+    after n sub-steps bit for bit against the oracle"""
     torch = torch_mod
     E = 130                 # not a multiple of 4: the last workgroup carries idle groups
-    pi, orc, env, ref = _setup_ct(oracle_mod, env_name, E, contact_options={"solver": solver})
-    assert env.ct.solver == {"pgs": 0, "newton": 1}[solver]
+    opts = {"newton": {"solver": "newton"}, "newton-pyramidal": {"solver": "newton", "cone": "pyramidal"}, "pgs": {"solver": "pgs"}}[solver]
+    pi, orc, env, ref = _setup_ct(oracle_mod, env_name, E, contact_options=opts)
+    assert env.ct.solver == {"pgs": 0, "newton-pyramidal": 1, "newton": 2}[solver]
     d = env.dyn
     q, v = _ct_states(env, orc, E, seed=10 + n)
     rng = np.random.default_rng(200 + n)
@@ -523,14 +525,15 @@ def test_joint_limit_rows_bit_identical_to_oracle(oracle_mod, torch_mod):
         env.close()
 
 
-def test_newton_solver_refuses_more_than_eight_contacts(torch_mod):
-    """the Newton solver maps a contact's four pyramid rows onto the 16 lanes of an env, two rows per lane: maxcon <= 8 (the LDS holds no
-    more at 4096 envs either); the Gauss-Seidel form takes what the LDS takes"""
-    from mopa_rl_amd import _lib
+def test_contact_caps_per_solver_form(torch_mod):
+    """Newton with pyramidal cones maps a contact's four pyramid rows onto the 16 lanes of an env, two rows per lane: maxcon <= 8; with
+    elliptic cones a contact's cone lives on one lane: maxcon <= 16, as for the Gauss-Seidel form"""
     from mopa_rl_amd.kinematic_env import make_env
-    with pytest.raises(_lib.MopaError, match="at most 8 contacts"):
-        make_env("SawyerPushObstacle-v0", 8, dynamics=True, contacts=True, contact_options={"maxcon": 12, "solver": "newton"})
-    env = make_env("SawyerPushObstacle-v0", 8, dynamics=True, contacts=True, contact_options={"maxcon": 12, "solver": "pgs"})
+    with pytest.raises(ValueError, match="maxcon <= 8"):
+        make_env("SawyerPushObstacle-v0", 8, dynamics=True, contacts=True, contact_options={"maxcon": 12, "solver": "newton", "cone": "pyramidal"})
+    with pytest.raises(ValueError, match="maxcon <= 16"):
+        make_env("SawyerPushObstacle-v0", 8, dynamics=True, contacts=True, contact_options={"maxcon": 20})
+    env = make_env("SawyerPushObstacle-v0", 8, dynamics=True, contacts=True, contact_options={"maxcon": 12})
     env.reset()
     env.step(torch_mod.zeros(8, env.action_dim, dtype=torch_mod.float64, device=env.device))
     assert bool(torch_mod.isfinite(env.qpos).all())

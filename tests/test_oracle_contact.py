@@ -92,13 +92,14 @@ def test_objects_come_to_rest(env, solver):
     assert od.stats.sweeps / max(od.stats.substeps, 1) < (3 if solver == "newton" else 15)
 
 
-@pytest.mark.parametrize("solver", ["newton", "pgs"])
+@pytest.mark.parametrize("solver", ["newton", "newton-pyramidal", "pgs"])
 def test_one_contact_step_equals_an_independent_qp_solve(solver):
     """states with arm-table, arm-cube and cube-floor contacts at once: the oracle's sub-step (PGS run to convergence) against
     tests/dyn_ref.contact_step_reference (independent FK / Jacobians / M / bias, exact active-set solve of the dual)"""
     env = "SawyerPushObstacle-v0"
+    cone = "elliptic" if solver == "newton" else "pyramidal"      # (the default pairing: the XML's elliptic cones with the Newton solver)
     m, f, d, ct, od, q0 = _setup(env, iterations=3000 if solver == "pgs" else 50, tolerance=0.0, warmstart=False, noslip_iterations=0,
-                                 solver=solver, limit_rows=False)     # (the contact solve alone, run to convergence)
+                                 solver=solver.split("-")[0], cone=cone, limit_rows=False)     # (the contact solve alone, run to convergence)
     orc = _scene(env, m)
     oq = ct.obj_qadr
     q0 = q0.copy(); q0[oq:oq + 3] = [0.80, 0.30, 0.853]
@@ -115,7 +116,7 @@ def test_one_contact_step_equals_an_independent_qp_solve(solver):
             con = od.contacts(q)
             arm = [r for r in con if ct.sh_body[int(r[7])] in range(d.nd) or ct.sh_body[int(r[8])] in range(d.nd)]
             if i >= 2 and arm:
-                vr, fr = dyn_ref.contact_step_reference(m, d, ct, con, q, v, lag, ctrl)
+                vr, fr = dyn_ref.contact_step_reference(m, d, ct, con, q, v, lag, ctrl, cone=cone)
                 q1, v1, _ = od.step(q, v, lag, ctrl, n=1)
                 scale = max(np.abs(v1 - v).max(), 1e-3)
                 free = np.ones(od.nv, dtype=bool)          # (a dof the sub-step ends ON its joint stop is not the reference's business)
@@ -211,7 +212,7 @@ def test_contact_step_with_a_joint_beyond_its_limit_equals_the_independent_qp():
         vv[j] = 0.3 * sgn
         lg = od.forward(qq, vv[:d.nd], want_M=False)[0]
         con = od.contacts(qq)
-        vr, fr = dyn_ref.contact_step_reference(m, d, ct, con, qq, vv, lg, ctrl, limit_rows=True)
+        vr, fr = dyn_ref.contact_step_reference(m, d, ct, con, qq, vv, lg, ctrl, limit_rows=True, cone="elliptic")
         q1, v1, _ = od.step(qq, vv, lg, ctrl, n=1)
         scale = max(np.abs(v1 - vv).max(), 1e-3)
         assert np.abs(v1 - vr).max() < 2e-4 * scale + 1e-7, (j, sgn, np.abs(v1 - vr).max(), scale)
@@ -252,10 +253,13 @@ def test_arm_stops_at_the_bin_roof():
 
 
 def test_gripper_pushes_the_cube():
-    """the cube set on the open table (outside the bin tunnel); the hand comes down behind it and moves along +x: the cube
-    is pushed ahead, stays on the table, and stops when the hand stops"""
+    """the cube set on the open table (outside the bin tunnel); the hand comes down behind it (its claw rests on the table) and moves along
+    +x.  With the XML's elliptic cones friction is fully effective (mu = 1 under the cube, 1 at the claw, which meets the cube's face 4.8 cm
+    up): the cube does not slide out from under the push, it TIPS over its front edge onto its next face -- 0.4 N tips it, 0.64 N would slide
+    it -- and is then pushed ahead; it stays on the table and stops when the hand stops.  (Pyramidal cones let it slide from the start.)"""
     env = "SawyerPushObstacle-v0"
     m, f, d, ct, od, q0 = _setup(env)
+    assert ct.solver == 2                            # Newton with elliptic cones: the default
     orc = _scene(env, m)
     oq = ct.obj_qadr
     q0 = q0.copy(); q0[oq:oq + 3] = [0.84, 0.30, 0.853]     # (clear of the descending hand: landing ON the cube, the claw sticks to it -- noslip)
@@ -264,6 +268,34 @@ def test_gripper_pushes_the_cube():
     q, v, lag = od.step(q, v, lag, q0[d.qadr].copy(), n=300)
     cz, x0 = q[oq + 2], q[oq]
     assert abs(cz - 0.85) < 1e-3                     # table top 0.82 + half the cube
+    way = [np.array([0.68, 0.30, cz + 0.15]), np.array([0.68, 0.30, cz + 0.03])] + [np.array([0.68 + 0.01 * k, 0.30, cz + 0.03]) for k in range(1, 22)]
+    tipped = False
+    for i, tg in enumerate(way):
+        qt = _ik(env, m, f, orc, q, tg)
+        ctrl = qt[d.qadr].copy(); ctrl[7:] = q[d.qadr[7:]]
+        for _ in range(8 if i < 2 else 2):
+            q, v, lag = od.step(q, v, lag, ctrl, n=75)
+        assert np.all(np.isfinite(q))
+        tipped = tipped or abs(q[oq + 3]) < 0.8       # more than ~70 degrees off its first face
+    assert tipped
+    assert 0.05 < q[oq] - x0 < 0.25 and abs(q[oq + 2] - cz) < 3e-3 and abs(q[oq + 1] - 0.30) < 0.05 and orc.is_valid(q)[0]
+    ctrl = q[d.qadr].copy()                          # the hand holds where it is: friction stops the cube
+    for _ in range(6):
+        q, v, lag = od.step(q, v, lag, ctrl, n=75)
+    assert np.abs(v[d.nd:d.nd + 3]).max() < 1e-4 and abs(q[oq + 2] - cz) < 1e-3
+
+
+def test_gripper_slides_the_cube_with_pyramidal_cones():
+    """the same push with pyramidal cones (selectable; round 4's default): the cube slides ahead of the hand on the face it stands on"""
+    env = "SawyerPushObstacle-v0"
+    m, f, d, ct, od, q0 = _setup(env, cone="pyramidal")
+    orc = _scene(env, m)
+    oq = ct.obj_qadr
+    q0 = q0.copy(); q0[oq:oq + 3] = [0.84, 0.30, 0.853]
+    q, v = q0.copy(), np.zeros(od.nv)
+    lag = od.forward(q, v[:d.nd], want_M=False)[0]
+    q, v, lag = od.step(q, v, lag, q0[d.qadr].copy(), n=300)
+    cz, x0 = q[oq + 2], q[oq]
     way = [np.array([0.68, 0.30, cz + 0.15]), np.array([0.68, 0.30, cz + 0.03])] + [np.array([0.68 + 0.01 * k, 0.30, cz + 0.03]) for k in range(1, 13)]
     for i, tg in enumerate(way):
         qt = _ik(env, m, f, orc, q, tg)
@@ -271,11 +303,7 @@ def test_gripper_pushes_the_cube():
         for _ in range(8 if i < 2 else 2):
             q, v, lag = od.step(q, v, lag, ctrl, n=75)
         assert np.all(np.isfinite(q)) and orc.is_valid(q)[0]
-    assert 0.015 < q[oq] - x0 < 0.15 and abs(q[oq + 2] - cz) < 2e-3 and abs(q[oq + 1] - 0.30) < 0.03      # (the forearm meets the bin: the push ends there)
-    ctrl = q[d.qadr].copy()                          # the hand holds where it is: friction stops the cube
-    for _ in range(6):
-        q, v, lag = od.step(q, v, lag, ctrl, n=75)
-    assert np.abs(v[d.nd:d.nd + 3]).max() < 1e-4
+    assert 0.015 < q[oq] - x0 < 0.15 and abs(q[oq + 2] - cz) < 2e-3 and abs(q[oq + 1] - 0.30) < 0.03 and q[oq + 3] > 0.99
 
 
 @pytest.mark.parametrize("grasp_dz", [-0.02, 0.0])

@@ -86,6 +86,7 @@ struct StreamScratch {
     DevBuf slab;        // lane-per-state kernels: pose slabs of the launch's waves + [profile words | tile counter]
     DevBuf mpr;         // v5: per-wave ring of deferred cylinder pairs
     DevBuf cen;         // v5, scenes whose FP32 centre table does not fit LDS: the per-wave tables in global memory
+    DevBuf k1_ctr;      // validity kernels' tile counter + exit count (self-resetting: tile_ctr_release)
     DevBuf mesh_list;   // [0] = count, then the states with a mesh pair past the main pass's broad phase
     size_t slab_waves = 0;
     DevBuf mv_cnt, mv_off, mv_env, mv_q, mv_valid, mv_scan;   // expanded motion validation (mopa_motion.inc)
@@ -182,6 +183,18 @@ MOPA_D double wave_min(double v) {
         v = (o < v) ? o : v;
     }
     return v;
+}
+
+// A persistent kernel's work counter that needs no zeroing launch: ctr[0] hands out the work items, ctr[1] counts the waves that have
+// found none left; the last of the grid's waves to say so puts both back to zero for the next launch on the stream.
+MOPA_D void tile_ctr_release(unsigned long long *ctr, int lane) {
+    if (lane == 0) {
+        const unsigned long long done = atomicAdd(ctr + 1, 1ull);
+        if (done + 1ull == (unsigned long long)gridDim.x * (blockDim.x >> 6)) {
+            atomicExch(ctr, 0ull);
+            atomicExch(ctr + 1, 0ull);
+        }
+    }
 }
 
 struct LdsView {
@@ -1205,11 +1218,15 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             HIP_TRY(grow(S, sc.cen, want * (size_t)S->hdr.nmg * 3 * 64 * sizeof(float)));
             sc.slab_waves = want;
         }
+        if (!sc.k1_ctr.p) {
+            HIP_TRY(grow(S, sc.k1_ctr, 64));
+            HIP_TRY(hipMemsetAsync(sc.k1_ctr.p, 0, 64, st));
+        }
+        unsigned long long *const d_ctr = sc.k1_ctr.as<unsigned long long>();
         double *const d_slab = sc.slab.as<double>();
         dim3 grid((unsigned)blocks);
         // [6 profile words | 2 pad | tile counter] live right behind the slabs of this launch's waves
         double *d_tail = d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride;
-        HIP_TRY(zero_async(d_tail + 8, 8, st));
 #ifdef MOPA_V2_PROFILE
         unsigned long long *d_prof = (unsigned long long *)d_tail;
         (void)zero_async(d_prof, 6 * 8, st);
@@ -1233,16 +1250,15 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             if (min_dist) hk.v5_ent_cap = S->v5_ent_cap_md;
             hipLaunchKernelGGL(k5, grid, block, min_dist ? S->v5_lds_bytes_md : S->v5_lds_bytes, st, hk, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
                                (long long)N, (long long)samples_per_env, valid, min_dist, d_slab, env_idx, sc.mpr.as<double>(), mesh_list, sc.cen.as<float>(),
-                               n_dev);
+                               n_dev, d_ctr);
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                           (long long)samples_per_env, valid, min_dist, d_slab, 0, env_idx, (const long long *)nullptr);
+                           (long long)samples_per_env, valid, min_dist, d_slab, 0, env_idx, (const long long *)nullptr, d_ctr);
         if (S->n_mesh_gp > 0) {
             // second pass: the mesh pairs only (MESH instantiation), verdict AND-ed / depth min-ed into the first pass's
-            HIP_TRY(zero_async(d_tail + 8, 8, st));
             auto km = min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>;
             hipLaunchKernelGGL(km, grid, block, S->v2_lds_bytes, st, S->hdr_mesh, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                               (long long)samples_per_env, valid, min_dist, d_slab, 1, env_idx, (const long long *)mesh_list);
+                               (long long)samples_per_env, valid, min_dist, d_slab, 1, env_idx, (const long long *)mesh_list, d_ctr);
         }
         HIP_TRY(hipGetLastError());
         if (mesh_list && std::getenv("MOPA_DEBUG_MESH")) {     // diagnostics: how many states the gate lets through

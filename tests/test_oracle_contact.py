@@ -128,6 +128,47 @@ def test_one_contact_step_equals_an_independent_qp_solve(solver):
     assert checked >= 6
 
 
+@pytest.mark.parametrize("env", ENVS)
+def test_resting_objects_do_not_spin_with_elliptic_cones(env):
+    """cube, can and furniture at rest on their supports under the default solver form (Newton, elliptic cones, noslip): no residual motion
+    at all -- with pyramidal cones the can kept turning at 2e-4 rad/s on its rim contacts (round 4)"""
+    m, f, d, ct, od, q0 = _setup(env)
+    assert ct.solver == 2
+    q, v = q0.copy(), np.zeros(od.nv)
+    lag = od.forward(q, v[:d.nd], want_M=False)[0]
+    ctrl = q[d.qadr].copy()
+    for _ in range(10):
+        q, v, lag = od.step(q, v, lag, ctrl, n=75)
+    assert np.abs(v[d.nd:d.nd + 3]).max() < 1e-6 and np.abs(v[d.nd + 3:]).max() < 1e-5
+
+
+def test_cube_on_a_tilt_at_0_9_mu_does_not_creep():
+    """gravity tilted by atan(0.9) against friction 1 (the cube also stands: it tips at atan(1)): with elliptic cones + noslip the cube
+    stays put -- 20 micrometres in two seconds at most --, with pyramidal cones (inscribed in the cone: weaker off the axes' sum) it
+    slides; at atan(1.1) it must slide either way"""
+    import dataclasses
+    env = "SawyerPushObstacle-v0"
+    g = 9.81
+    drift = {}
+    for cone, frac in (("elliptic", 0.9), ("pyramidal", 0.9), ("elliptic", 1.1)):
+        m, f, d, ct, od, q0 = _setup(env, cone=cone)
+        oq = ct.obj_qadr
+        q, v = q0.copy(), np.zeros(od.nv)
+        lag = od.forward(q, v[:d.nd], want_M=False)[0]
+        ctrl = q[d.qadr].copy()
+        q, v, lag = od.step(q, v, lag, ctrl, n=300)
+        th = np.arctan(frac)
+        tilted = O.OracleDyn(dataclasses.replace(d, gravity=np.array([g * np.sin(th), 0.0, -g * np.cos(th)])), ct=ct)
+        lag = tilted.forward(q, v[:d.nd], want_M=False)[0]
+        q, v, lag = tilted.step(q, v, lag, ctrl, n=250)          # the transient of the tilt
+        p0 = q[oq:oq + 3].copy()
+        q, v, lag = tilted.step(q, v, lag, ctrl, n=250 if frac > 1 else 1000)
+        drift[(cone, frac)] = q[oq:oq + 3] - p0
+    assert np.abs(drift[("elliptic", 0.9)]).max() < 2e-5
+    assert drift[("pyramidal", 0.9)][0] > 5e-3
+    assert drift[("elliptic", 1.1)][0] > 5e-2
+
+
 def test_noslip_pass_stops_the_creep_of_a_loaded_friction_contact():
     """Gravity tilted by atan(0.5) against a friction coefficient of 1: the cube must stick.  The soft friction rows alone let
     it creep (4 mm/s -- what MuJoCo's regularised friction does too); the noslip pass (`noslip_iterations="5"`,

@@ -1,5 +1,5 @@
 """K7 against the oracle over many envs: `env.step` rollouts (obs, qpos incl. the object's pose, qvel, flags) bit for bit, all three envs,
-both solvers, several seeds; initial states as tests/test_gpu_dyn.py::_ct_states (rest, impact, sliding, arm-object and arm-scene
+the three solver forms (Newton + elliptic cones: the default; Newton + pyramidal; Gauss-Seidel), several seeds; initial states as tests/test_gpu_dyn.py::_ct_states (rest, impact, sliding, arm-object and arm-scene
 contacts, joints near their limits).  Needs the oracle: test infrastructure, run on the GPU box with the repo.
    python tools/ct_parity_sweep.py [E] [steps] > profiles/rNN/ct_parity_sweep.txt"""
 import os, sys, time
@@ -16,9 +16,10 @@ bits = lambda a: np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
 total = bad = 0
 t00 = time.perf_counter()
 for env_name in T.ENVS:
-    for solver in ("newton", "pgs"):
+    for solver in ("newton", "newton-pyramidal", "pgs"):
         for seed in (31, 32):
-            pi, orc, env, ref = T._setup_ct(O, env_name, E, contact_options={"solver": solver}, max_episode_steps=1 << 20)
+            pi, orc, env, ref = T._setup_ct(O, env_name, E, contact_options={"newton": {"solver": "newton"}, "newton-pyramidal": {"solver": "newton", "cone": "pyramidal"}, "pgs": {"solver": "pgs"}}[solver],
+                                             max_episode_steps=1 << 20)
             q, v = T._ct_states(env, orc, E, seed=seed)
             env.set_state(torch.tensor(q, device=env.device)); env.qvel.copy_(torch.tensor(v, device=env.device))
             ref.set_state(q); ref.qvel[:] = v
@@ -38,7 +39,7 @@ for env_name in T.ENVS:
                     mism += int((bits(g.cpu().numpy()) != bits(r)).sum())
                 mism += int((env.done.cpu().numpy() != ref.done).sum())
             total += E * steps; bad += mism
-            print(f"{env_name:28s} solver {solver:6s} seed {seed}: {E} envs x {steps} env.steps ({E * steps * env.dyn.nsub} sub-steps, "
+            print(f"{env_name:28s} solver {solver:16s} seed {seed}: {E} envs x {steps} env.steps ({E * steps * env.dyn.nsub} sub-steps, "
                   f"{con / (E * steps * env.dyn.nsub):.2f} contacts and {its / (E * steps * env.dyn.nsub):.2f} solver iterations per sub-step): "
                   f"{mism} mismatching words", flush=True)
             env.close()

@@ -273,6 +273,10 @@ def env_step_section(torch, E, device, steps, with_cpu):
                                                  "(OpenMP over envs); our C restatement, not MuJoCo"}
         blk["dynamics"] = env_dynamics_block(torch, env_name, E, device, g, with_cpu and tag == "push")
         blk["dynamics_contacts"] = env_dynamics_block(torch, env_name, E, device, g, with_cpu, contacts=True, steps=6)
+        if tag == "push":
+            # K6 is latency-bound at BASELINE's 4096 envs (64 of 256 CUs hold its waves): its rate with the chip filled, next to it
+            sat = env_dynamics_block(torch, env_name, 4 * E, device, g, False, steps=10)
+            blk["dynamics_saturated"] = {"envs": 4 * E, "steps_per_s": sat["steps_per_s"], "ms_per_batch": sat["ms_per_batch"]}
         out[tag] = blk
     out["steps_per_s"] = out["push"]["steps_per_s"]
     out["steps_per_s_dynamics"] = out["push"]["dynamics"]["steps_per_s"]
@@ -701,7 +705,7 @@ def headline(out):
                     "cpu_plans_per_s": _g(out, "planner", "cpu_baseline", "value")},
         "scenes_checks_per_s": {k.split("Obstacle")[0].replace("Sawyer", "").lower(): _g(v, "checks_per_s")
                                 for k, v in (out.get("scenes") or {}).items() if isinstance(v, dict)},
-        "env_steps_per_s": {k: {"kin": _g(v, "steps_per_s"), "dyn": _g(v, "dynamics", "steps_per_s"),
+        "env_steps_per_s": {k: {"kin": _g(v, "steps_per_s"), "dyn": _g(v, "dynamics", "steps_per_s"), "dyn_sat": _g(v, "dynamics_saturated", "steps_per_s"),
                                 "ct": _g(v, "dynamics_contacts", "steps_per_s"), "ct_ms": _g(v, "dynamics_contacts", "ms_per_batch"),
                                 "ct_cpu": _g(v, "dynamics_contacts", "cpu_baseline", "value"),
                                 "ct_dropped": _g(v, "dynamics_contacts", "contacts_dropped_by_the_cap_per_substep")}

@@ -169,7 +169,7 @@ class BatchKinematicEnv:
     def __init__(self, env_name: str, num_envs: int, device=None, seed: int = 0, max_episode_steps: int = 250,
                  distance_threshold: float = 0.06, success_reward: float = 150.0, ac_scale: Optional[float] = None,
                  block_invalid: bool = False, model=None, dynamics: bool = False, frame_dt: float = 0.15, contacts=False,
-                 contact_options: dict = None):
+                 contact_options: dict = None, dyn_lanes: int = 1):
         torch = _torch()
         if env_name not in ENV_KIND:
             raise _lib.MopaError(f"no batched kinematic env for {env_name!r}")
@@ -280,6 +280,24 @@ class BatchKinematicEnv:
                 self.ct = contact_facts(self.model, df, OBJECT_BODY[f.kind], qpos_ref=self.init_qpos_row, **(contact_options or {}))
             _lib.check(L.mopa_env_attach_dynamics(self._h, C.byref(dd)))
             assert L.mopa_env_dyn_dofs(self._h) == df.nd
+            if dyn_lanes not in (1, 16):
+                raise _lib.MopaError("dyn_lanes: 16 (lanes per env: the contact kernel's mapping) or 1 (K6: a lane per env)")
+            self.dyn_lanes = 16 if self.ct is not None else (1 if self.obj is not None else int(dyn_lanes))
+            if self.ct is None and self.obj is None and dyn_lanes == 16:
+                # contact-free servo dynamics in the 16-lanes-per-env mapping of the contact kernel: a contact stage with no object, no
+                # pairs, limits as inelastic stops.  Same results; measured (tools/dyn_lanes_ab.py) it is NOT faster than K6 at 4096 envs
+                # (1.58 vs 1.54 ms per env.step: either way a sub-step is one env's serial chain, ~20 us) and a quarter of K6's rate
+                # once K6 has 16 384 envs to fill the chip with (2.7 vs 10.6 M env-steps/s) -- hence not the default
+                cd = _lib.MopaCtDesc()
+                cd.ns = cd.nf = cd.np = 0
+                cd.obj_qadr = -1
+                cd.maxcon, cd.maxpair, cd.iterations = 0, 1, 1
+                cd.tolerance, cd.inv_scale = 0.0, 1.0
+                cd.precull_every, cd.precull_margin, cd.warmstart = 15, 0.0, 0
+                cd.near_every, cd.near_margin = 3, 0.0
+                cd.noslip_iterations, cd.noslip_tolerance = 0, 0.0
+                cd.solver, cd.limit_rows = 0, 0
+                _lib.check(L.mopa_env_attach_contacts(self._h, C.byref(cd)))
             if self.ct is not None:
                 ct = self.ct
                 cd = _lib.MopaCtDesc()

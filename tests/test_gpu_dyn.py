@@ -618,3 +618,23 @@ def test_arm_stops_at_the_bin_roof_on_the_gpu(oracle_mod, torch_mod):
         b = int(f.frame_body[0])
         eef = xp[b] + _quat_to_mat(xq[b]) @ f.frame_off[0]
         assert eef[2] > 1.2 and orc.is_valid(gq[e])[0] and np.abs(gq[e, d.qadr[:7]] - ctrl[e, :7]).max() > 0.1
+
+
+def test_contact_free_dynamics_in_the_16_lane_mapping_equals_k6(torch_mod):
+    """dyn_lanes=16: stage A's contact-free servo dynamics through the contact kernel's mapping (16 lanes per env, no object, no pairs,
+    joint limits as inelastic stops) -- env.step rollouts bit-identical to K6's lane-per-env form"""
+    torch = torch_mod
+    from mopa_rl_amd.kinematic_env import make_env
+    E = 70
+    for env_name in ENVS:
+        a = make_env(env_name, E, dynamics=True, seed=3, max_episode_steps=1 << 20)
+        b = make_env(env_name, E, dynamics=True, seed=3, max_episode_steps=1 << 20, dyn_lanes=16)
+        assert a.dyn_lanes == 1 and b.dyn_lanes == 16
+        a.reset(); b.reset()
+        g = torch.Generator(device=a.device); g.manual_seed(5)
+        for t in range(4):
+            act = (torch.rand(E, a.action_dim, generator=g, dtype=torch.float64, device=a.device) * 3 - 1.5)
+            a.step(act); b.step(act)
+            for x, y in ((a.qpos, b.qpos), (a.qvel, b.qvel), (a.bias_lag, b.bias_lag), (a.obs, b.obs), (a.reward, b.reward)):
+                assert torch.equal(x.view(torch.int64), y.view(torch.int64)), (env_name, t)
+        a.close(); b.close()

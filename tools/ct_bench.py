@@ -46,10 +46,12 @@ for env_name in [n for n in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "
         L = _lib.lib()
         if hasattr(L, "mopa_debug_ct_prof"):
             import ctypes
-            buf = (ctypes.c_ulonglong * 16)()
+            buf = (ctypes.c_ulonglong * 32)()
             L.mopa_debug_ct_prof(buf, 1)
             t = np.array(list(buf), dtype=np.float64)
             nw = (E + 3) // 4 * env.dyn.nsub * (steps + 2)
             names = ["m-rows+frames", "precull", "cull", "rows", "solver", "forces", "integrate", "narrow", "walk", "owner", "bias", "crb-acc", "nt:rows+H", "nt:ldl+solve", "nt:linesearch", "nt:forces"]
             print("    us per sub-step (lane 0 of each wave, cycles / 2400): " + "  ".join(f"{n} {t[i] / nw / 2400:.2f}" for i, n in enumerate(names)), flush=True)
+            if t[20]:
+                print(f"    cull trips per sub-step {t[20] / nw:.2f}; us per trip: list walk {t[16] / t[20] / 2400:.2f}  record load {t[17] / t[20] / 2400:.2f}  bound {t[18] / t[20] / 2400:.2f}  reverse bound {t[19] / t[20] / 2400:.2f}  between trips {t[25] / t[20] / 2400:.2f}", flush=True)
         env.close()

@@ -380,8 +380,14 @@ int mopa_env_attach_dynamics(MopaEnv *env, const MopaDynDesc *desc);
  * `sim.step()` of the reference's `_do_simulation` loop (env/sawyer/sawyer_push_obstacle.py:186-203, sawyer_lift_obstacle.py:
  * 218-236, sawyer_assembly_obstacle.py:121-139; options env/assets/xml/common/sawyer_dependencies.xml:11), [3P] MuJoCo 2.0's
  * mj_collision + mj_makeConstraint + the constraint solver + mj_Euler.  RESTATED FROM THE PUBLISHED SOLVER, PARITY UNPINNED:
- * soft constraints with solref / solimp impedance, pyramidal friction cones (the XML's elliptic cones, noslip pass, and
- * torsional / rolling friction are not restated), projected Gauss-Seidel with the XML's `iterations` cap and `tolerance`.
+ * soft constraints with solref / solimp impedance; the default pipeline (`solver` 2) is the XML's: ELLIPTIC friction cones
+ * (`cone="elliptic"`, condim 3: MuJoCo's primal elliptic-cone cost) in the Newton solver (the XML names no solver = MuJoCo's
+ * default) with `iterations="50"` / `tolerance="1e-10"`, then the noslip pass (`noslip_iterations="5"`: friction re-solved
+ * without the regulariser inside the friction disc), joint limits as solver rows (`limit_rows`).  Selectable: Newton with
+ * pyramidal cones (`solver` 1), projected Gauss-Seidel with pyramidal cones (`solver` 0).  Not restated: torsional / rolling
+ * friction (condim 4 / 6 pairs are solved as condim 3), MuJoCo's own pair functions (see "Collision geometry").
+ * obj_qadr < 0 (with np = 0, limit_rows = 0): NO contact stage and no object -- the contact-free servo dynamics of stage A in this
+ * kernel's 16-lanes-per-env mapping (qvel rows stay [nd]).
  * Collision geometry: sampled feature points of one geom in the exact signed-distance function of the other (plane, sphere,
  * capsule, cylinder, box; the can as the bounding cylinder of its hull).
  * Bodies: 0 .. nd-1 the lumped dynamic bodies of the arm, nd the object, -1 the world.  Shapes are posed in the frame of
@@ -389,7 +395,7 @@ int mopa_env_attach_dynamics(MopaEnv *env, const MopaDynDesc *desc);
  * pr_par rows: mu, margin, K, B, d0, dmax, width, 0 (MuJoCo's per-pair mix of friction / margin / solref / solimp, formed on
  * the host).  Call after mopa_env_attach_dynamics (without MopaObjDesc); qvel rows become [nd + 6]: the dofs, then the
  * object's (velocity of its COM, angular velocity) in the world. */
-#define MOPA_CT_MAXCON 24
+#define MOPA_CT_MAXCON 16      /* contacts kept per env and sub-step: <= 16 (solver 0, 2: one contact per lane of an env's 16), <= 8 for solver 1 */
 typedef struct MopaCtDesc {
     int32_t ns;
     const int32_t *sh_body, *sh_type;                       /* [ns] */
@@ -410,13 +416,15 @@ typedef struct MopaCtDesc {
     int32_t near_every;              /* third culling level: active pairs within near_margin of contact, re-listed every near_every sub-steps */
     double near_margin;
     int32_t warmstart;
-    int32_t solver;                  /* 0: projected Gauss-Seidel, 1: Newton (MuJoCo's default) */
-    int32_t limit_rows;              /* joint limits as rows of the Newton solver (MuJoCo) instead of an inelastic stop */
+    int32_t solver;                  /* 2: Newton + elliptic cones (the XML's model; default of the Python host), 1: Newton + pyramidal cones,
+                                        0: projected Gauss-Seidel + pyramidal cones */
+    int32_t limit_rows;              /* joint limits as rows of the Newton solver (MuJoCo) instead of an inelastic stop (solver 1 / 2) */
     double lim_par[8];               /* their parameters in a pair record's layout: -, margin 0, K, B, d0, dmax, width, - */
     int32_t noslip_iterations;       /* sweeps of the noslip pass after the main solve (0 = none) */
     double noslip_tolerance;
 } MopaCtDesc;
 int mopa_env_attach_contacts(MopaEnv *env, const MopaCtDesc *desc);
+int mopa_ct_desc_size(void);           /* sizeof(MopaCtDesc) as the library was built (binding self-check) */
 /* per-env counters of the last stepping launch: [E,4] int32 = contacts summed over the sub-steps, solver sweeps summed,
  * contacts dropped by the caps, largest contact count of a sub-step (NULL: not recorded) */
 int mopa_env_set_contact_stats(MopaEnv *env, int32_t *stats_dev);

@@ -278,7 +278,7 @@ def obj_facts(model, dyn: DynFacts, geom_name: str = "cube", kn: float = 500.0, 
 
 
 # ---- stage C: contacts of the arm and of the manipulated object, behind one constraint solve -----------------------------
-CT_MAXCON = 24        # contacts the C ABI / the test oracle keep per env and sub-step at most (array bound)
+CT_MAXCON = 16        # contacts the C ABI / the test oracle keep per env and sub-step at most (one per lane of an env's 16)
 
 
 @dataclass
@@ -520,13 +520,20 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         sh.append((g, own, t, size, gp, R.ravel(), rbound(t, size)))
         feats_of.append((gp + pts @ R.T, rad))
 
-    never = {tuple(sorted((int(a), int(b)))) for a, b in (m.meta.get("never_violating_pairs") or [])}
+    # Pairs left out of the contact tables: only those PROVEN to stay beyond this stage's own reach -- tools/prove_separated_pairs.py shows
+    # dist > floor (2 mm) over the joint ranges + guard band for them; a pair goes only if its margin (+ 0.5 mm slack) is inside that floor.
+    # (The planner's `never_violating_pairs` proof only shows dist > 0.1 mm: enough for a threshold <= 0, not for contacts made at 1 mm.)
+    nwm = m.meta.get("never_within_margin_pairs") or {}
+    never_floor = float(nwm.get("floor", 0.0))
+    never = {tuple(sorted((int(a), int(b)))) for a, b in (nwm.get("pairs") or [])}
     round_t = (GEOM_SPHERE, GEOM_CAPSULE)
     pairs = []
     used_as_f = set()
     for a, b in m.pair_geom:
         a, b = int(a), int(b)
-        if a not in shape_of or b not in shape_of or tuple(sorted((a, b))) in never:
+        if a not in shape_of or b not in shape_of:
+            continue
+        if tuple(sorted((a, b))) in never and max(float(m.geom_margin[a]), float(m.geom_margin[b])) + 5e-4 <= never_floor:
             continue
         sa, sb = shape_of[a], shape_of[b]
         if sh[sa][1] < 0 and sh[sb][1] < 0:

@@ -554,6 +554,10 @@ class _Builder:
             size = [size[0], 0.0, 0.0]
         elif gtype in (GEOM_CAPSULE, GEOM_CYLINDER):
             size = [size[0], size[1], 0.0]
+        _si = _floats(at.get("solimp", "0.9 0.95 0.001"))
+        if (len(_si) > 3 and abs(_si[3] - 0.5) > 1e-12) or (len(_si) > 4 and abs(_si[4] - 2.0) > 1e-12):
+            # the impedance curve restated by the contact stage is MuJoCo's default one (midpoint 0.5, power 2)
+            raise ValueError(f"geom {at.get('name', '')!r}: solimp with midpoint != 0.5 or power != 2 is not supported")
         g = {"name": at.get("name", ""), "type": gtype, "body": bid, "size": np.array(size, dtype=np.float64),
              "pos": pos, "quat": quat, "contype": int(at.get("contype", "1")),
              "conaffinity": int(at.get("conaffinity", "1")), "margin": float(at.get("margin", "0")),

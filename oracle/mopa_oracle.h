@@ -173,7 +173,7 @@ typedef struct OrcDynDesc {
  * Shapes: the collidable geoms (plane / sphere / capsule / cylinder / box; a mesh enters as its bounding cylinder), posed in
  * the frame of their body.  Features: points (with a radius: sphere-swept) sampled on a shape, in the same body frame.
  * Directed pairs (F, S): the features of shape F are tested against the signed-distance function of shape S. */
-#define ORC_CT_MAXCON 24
+#define ORC_CT_MAXCON 16
 typedef struct OrcCtDesc {
     int32_t ns;
     const int32_t *sh_body, *sh_type;            /* [ns] */
@@ -202,6 +202,7 @@ typedef struct OrcCtDesc {
 } OrcCtDesc;
 typedef struct OrcCtStats { int64_t substeps, contacts, sweeps, dropped; int32_t max_contacts; int64_t hot_pairs, active_pairs; } OrcCtStats;
 /* n sub-steps with contacts; qvel [nd + 6]: dofs, then the object's (v of its COM, w) in the world; stats may be NULL (accumulated) */
+int orc_ct_desc_size(void);      /* sizeof(OrcCtDesc): binding self-check */
 void orc_ct_step(const OrcDynDesc *d, double *qpos, double *qvel, double *bias_lag, const double *ctrl, int n, OrcCtStats *stats);
 /* the contacts of one configuration (no step): rows of [dist, pos 3, normal 3, shape F, shape S, feature] -> out [maxcon,10]; returns the count */
 int orc_ct_contacts(const OrcDynDesc *d, const double *qpos, double *out);

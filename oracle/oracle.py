@@ -102,6 +102,8 @@ def lib():
         L.orc_dyn_step_obj.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp, C.c_int, _dp]
         L.orc_ct_step.restype = None
         L.orc_ct_step.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp, _dp, _dp, C.c_int, C.c_void_p]
+        L.orc_ct_desc_size.restype = C.c_int
+        L.orc_ct_desc_size.argtypes = []
         L.orc_ct_contacts.restype = C.c_int
         L.orc_ct_contacts.argtypes = [C.POINTER(OrcDynDesc), _dp, _dp]
         L.orc_env_step_dyn_batch.restype = None

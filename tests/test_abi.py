@@ -78,3 +78,12 @@ def test_rollout_step_struct_layout_matches_the_library():
     import ctypes as C
     from mopa_rl_amd import _lib
     assert _lib.lib().mopa_rollout_step_size() == C.sizeof(_lib.MopaRolloutStep)
+
+
+def test_contact_desc_struct_layouts_match_the_libraries():
+    """MopaCtDesc / OrcCtDesc (about 40 mixed int32 / double / array fields) are mirrored by hand in ctypes on both sides"""
+    import ctypes as C
+    from mopa_rl_amd import _lib
+    from oracle import oracle as O
+    assert _lib.lib().mopa_ct_desc_size() == C.sizeof(_lib.MopaCtDesc)
+    assert O.lib().orc_ct_desc_size() == C.sizeof(O.OrcCtDesc)

@@ -162,6 +162,9 @@ def pair_setup(m, a, b):
     return joints, (t1, s1), (t2, s2), ia, ib
 
 
+CT_FLOOR = 2.0e-3      # proven lower bound required before the contact stage drops a pair (its margins are 1 mm)
+
+
 def prove_pair(m, orc, q0, a, b, max_evals, floor=MARGIN):
     """floor: the proof shows dist > floor everywhere.  MARGIN (> 0: never even touching) is valid for every pair type;
     a negative floor (contact_threshold + MARGIN: touching allowed, the threshold never reached) only where the oracle's
@@ -247,7 +250,7 @@ def main():
         orc = O.OracleScene(m, pi.passive_joint_idx, pi.ignored_contacts, spec.contact_threshold)
         ign = set(tuple(p) for p in pi.ignored_contacts)
         q0 = np.array(m.qpos0, dtype=np.float64)
-        proven, proven_thr, radii = [], [], []
+        proven, proven_thr, radii, proven_ct = [], [], [], []
         t0 = time.time()
         for a, b in m.pair_geom:
             a, b = int(a), int(b)
@@ -278,9 +281,14 @@ def main():
             if res:
                 proven.append([a, b])
                 print(f"  {env}: PROVEN separated  {name(a)} / {name(b)}: {why}", flush=True)
+                # the contact stage of env.step (mopa_rl_amd/dynamics.py: contact_facts) makes contacts at dist < the pair's margin
+                # (1 mm in the reference's scenes): a pair leaves ITS table only when proven to stay beyond CT_FLOOR
+                res2, why2 = prove_pair(m, orc, q0, a, b, args.max_evals, floor=CT_FLOOR)
+                if res2:
+                    proven_ct.append([a, b])
             elif res is None and why not in ("type", "free joint", "rigid", "unlimited slide") and "joints" not in why:
                 print(f"  {env}: undecided        {name(a)} / {name(b)}: {why}", flush=True)
-        print(f"{env}: {len(radii)} tightened cull radii; {len(proven)} (+ {len(proven_thr)} that may touch) of {len(m.pair_geom)} candidate pairs proven never to violate the threshold ({time.time() - t0:.0f} s)", flush=True)
+        print(f"{env}: {len(radii)} tightened cull radii; {len(proven)} (+ {len(proven_thr)} that may touch) of {len(m.pair_geom)} candidate pairs proven never to violate the threshold, {len(proven_ct)} to stay beyond {CT_FLOOR} m ({time.time() - t0:.0f} s)", flush=True)
         if not args.dry:
             path = scene_path(spec.scene)
             cm = CompiledModel.load(path)
@@ -290,6 +298,7 @@ def main():
             # [geom a, geom b, radius]: the pair can only reach `threshold` while its geom centres are within `radius`
             cm.meta["pair_cull_radius"] = {"threshold": spec.contact_threshold, "pairs": radii}
             cm.meta["prune_guard_band"] = {"hinge": BAND_HINGE, "slide": BAND_SLIDE}
+            cm.meta["never_within_margin_pairs"] = {"floor": CT_FLOOR, "pairs": proven_ct}
             cm.meta["never_violating_pairs_note"] = ("tools/prove_separated_pairs.py: branch-and-bound Lipschitz proof over the joint ranges inflated by "
                                                      f"the guard band ({BAND_HINGE} rad / {BAND_SLIDE} m), margin {MARGIN} m; valid for joint values "
                                                      "inside range + band -- the runtime sends states beyond that through the unpruned pair list")

@@ -318,12 +318,11 @@ def env_dynamics_block(torch, env_name, E, device, g, with_cpu, steps=20, contac
     dt, gpu_ms = min(passes)
     nd, nsub = env.dyn.nd, env.dyn.nsub
     bytes_per_step = 6 * nd * 8 + 2 * env.action_dim * 8 + env.obs_dim * 8 + 18       # q / qvel / lagged bias in+out, action, prev_state, obs, flags
-    what = (f"servo + contacts (stage C): as `dynamics`, plus contacts of the arm with the scene, the manipulated object as a free rigid body and "
-            f"arm <-> object contacts, two-way coupled behind one soft-constraint solve per sub-step: {len(env.ct.pr_f)} directed geom pairs "
-            f"({len(env.ct.ft_rad)} feature points in exact signed-distance functions), <= {env.ct.maxcon} contacts per env, MuJoCo's solref / solimp "
-            f"impedance model, pyramidal friction cones, {'Newton solver (MuJoCo default)' if env.ct.solver == 1 else 'PGS'} <= {env.ct.iterations} iterations "
-            f"at tolerance {env.ct.tolerance:g}, noslip pass of {env.ct.noslip_iterations} sweeps -- RESTATED FROM THE PUBLISHED SOLVER, PARITY "
-            "UNPINNED; not restated: elliptic cones, torsional / rolling friction") if contacts else (
+    what = (f"servo + contacts (stage C): {len(env.ct.pr_f)} directed geom pairs ({len(env.ct.ft_rad)} feature points in exact signed-distance functions), "
+            f"<= {env.ct.maxcon} contacts per env, MuJoCo's solref / solimp impedance model, "
+            f"{['Gauss-Seidel + pyramidal cones', 'Newton + pyramidal cones', 'Newton + ELLIPTIC cones (the XML model)'][env.ct.solver]}, <= {env.ct.iterations} iterations at tolerance "
+            f"{env.ct.tolerance:g}, noslip pass of {env.ct.noslip_iterations} sweeps, limit rows {env.ct.limit_rows} -- RESTATED FROM THE PUBLISHED SOLVER, PARITY UNPINNED; "
+            f"{env.ct.condim_downgraded} pairs ask for condim 4 / 6 and are solved as condim 3") if contacts else (
            f"servo, contact-free: {nsub} sub-steps of h = {env.dyn.timestep} s per env.step on {nd} dofs (RNE bias + CRB inertia + "
            "implicit-damping Euler, kp / forcerange servos, lagged qfrc_bias as gravity compensation); joint limits = inelastic "
            "stop; the manipulated object does not move (no contacts) -- labelled, NOT MuJoCo's constraint solver")

@@ -73,6 +73,12 @@ struct SceneHdr {
     // end), [4] chain length, [5] static frame of the chain root's parent; pfk_maxlen = longest chain (0: a chain is longer than
     // 16 bodies -> the planner keeps the generic walk)
     int o_pfk, pfk_maxlen;
+    // k_is_valid_v5, tiles whose 64 states share one env row: the moving bodies no ACTIVE coordinate reaches (a manipulated object's free
+    // body and what is welded to it: Assembly's furniture = 21 bodies, 20 geoms) are posed ONCE per tile, one body per lane, level by level,
+    // instead of by every lane in its walk.  o_pas_b: the bodies (moving-body ids) in level order, o_pas_lv [n_pas_lv + 1]: level starts,
+    // o_mb_pas [nmb]: position in that list or -1 (bit 16: nothing continues from this body's registers), o_pas_g: the moving-geom slots
+    // on them, o_mg_pas [nmg]: position or -1.  n_pas_b = 0: off.
+    int n_pas_b, n_pas_g, n_pas_lv, o_pas_b, o_pas_lv, o_mb_pas, o_pas_g, o_mg_pas;
     // per-wave LDS slab (in doubles): geom records, qbuf; then worklist (u16)
     int wave_dbl, wave_bytes;
     double thr, range, resolution;
@@ -1013,6 +1019,41 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     while (B.ints.size() & 7) B.ints.push_back(0);   // 32-byte align the packed records (scalar dwordx8 loads)
     h.o_mbr = B.add_i(mbr); h.o_mgr = B.add_i(mgr);
     {
+        // tile-shared passive bodies (see SceneHdr)
+        std::vector<char> pas(nmb, 0);
+        std::vector<int> lvl(nmb, 0);
+        int nlv = 0;
+        for (int k = 0; k < nmb; k++) {
+            bool p = true, is_free = false;
+            for (int j = mb_jntadr[k]; j < mb_jntadr[k] + mb_jntnum[k]; j++) {
+                if (mj_type[j] == J_FREE) is_free = true;
+                else if (mj_qsrc[j] < na) p = false;
+            }
+            if (mb_parent[k] >= 0 && !is_free) { p = p && pas[mb_parent[k]]; lvl[k] = lvl[mb_parent[k]] + 1; }
+            pas[k] = p ? 1 : 0;
+            if (p) nlv = std::max(nlv, lvl[k] + 1);
+        }
+        std::vector<int32_t> pas_b, pas_lv, mb_pas(nmb, -1), pas_g, mg_pas(nmg, -1);
+        for (int L = 0; L < nlv; L++) {
+            pas_lv.push_back((int)pas_b.size());
+            for (int k = 0; k < nmb; k++)
+                if (pas[k] && lvl[k] == L) { mb_pas[k] = (int)pas_b.size(); pas_b.push_back(k); }
+        }
+        pas_lv.push_back((int)pas_b.size());
+        for (int ms = 0; ms < nmg; ms++)
+            if (pas[g_mb[mg_geom[ms]]]) { mg_pas[ms] = (int)pas_g.size(); pas_g.push_back(ms); }
+        for (int k = 0; k < nmb; k++) {
+            if (mb_pas[k] < 0) continue;
+            bool cont = false;       // does a body that is NOT posed by the tile continue from this one's registers / saved pose?
+            for (int c = 0; c < nmb; c++)
+                if (mb_parent[c] == k && !pas[c]) cont = true;
+            if (!cont) mb_pas[k] |= 1 << 16;
+        }
+        const bool on = pas_b.size() >= 4 && pas_b.size() <= 64 && pas_g.size() <= 64 && nlv <= 8 && !std::getenv("MOPA_V5_NO_TILE_POSES");
+        h.n_pas_b = on ? (int)pas_b.size() : 0; h.n_pas_g = on ? (int)pas_g.size() : 0; h.n_pas_lv = on ? nlv : 0;
+        h.o_pas_b = B.add_i(pas_b); h.o_pas_lv = B.add_i(pas_lv); h.o_mb_pas = B.add_i(mb_pas); h.o_pas_g = B.add_i(pas_g); h.o_mg_pas = B.add_i(mg_pas);
+    }
+    {
         std::vector<int32_t> pfk(8 * (size_t)nmg, 0);
         int maxlen = 0;
         bool ok = nmb < 255;
@@ -1088,10 +1129,12 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
             const int budget = std::max(S->v5_lds_bytes_md, 80 * 1024);
             while (cap + 64 <= kEntCapV5Max && fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap + 64, false) <= budget) cap += 64;
             h.v5_ent_cap = cap;
+            // (the tile's passive poses overlay the entry buffer during the FK phase)
+            if ((h.n_pas_b + h.n_pas_g) * 7 * 8 > 4 * std::min(cap, S->v5_ent_cap_md)) { h.n_pas_b = 0; h.n_pas_g = 0; h.n_pas_lv = 0; }
             S->v5_lds_bytes = fixed + kWavesPerBlock * v5_lds_per_wave(cen_lds ? nmg : 0, cap, false);
             if (std::getenv("MOPA_DEBUG"))
-                fprintf(stderr, "[mopa] scene: nmg %d nmb %d save slots %d pairs %d (+%d mesh) lds: wave-per-state %d, v2 %d, v5 %d (entry cap %d, fixed %d, centres in %s)\n", nmg, nmb, n_save,
-                        (int)gp_word.size(), (int)gp_word_mesh.size(), S->lds_bytes, S->v2_lds_bytes, S->v5_lds_bytes, cap, fixed, cen_lds ? "LDS" : "slab");
+                fprintf(stderr, "[mopa] scene: nmg %d nmb %d save slots %d pairs %d (+%d mesh) lds: wave-per-state %d, v2 %d, v5 %d (entry cap %d / %d, fixed %d, centres in %s); tile-posed bodies %d geoms %d levels %d\n", nmg, nmb, n_save,
+                        (int)gp_word.size(), (int)gp_word_mesh.size(), S->lds_bytes, S->v2_lds_bytes, S->v5_lds_bytes, cap, S->v5_ent_cap_md, fixed, cen_lds ? "LDS" : "slab", h.n_pas_b, h.n_pas_g, h.n_pas_lv);
         }
         // third generation (FP32 broad phase out of LDS): default wherever it applies; MOPA_VALID_KERNEL=v2 keeps the second
         // ... unless it would get one workgroup per CU where the second generation still gets two (LDS: the FP32 centre

@@ -329,6 +329,7 @@ class CtFacts:
                                      # 1: Newton with pyramidal cones, 0: projected Gauss-Seidel (pyramidal)
     limit_rows: int = 1              # joint limits as rows of the Newton solver (MuJoCo) instead of stage A's inelastic stop
     lim_par: tuple = (0.0,) * 8      # their solver parameters in a pair record's layout: -, margin, K, B, d0, dmax, width, -
+    condim_downgraded: int = 0       # directed pairs whose geoms ask for condim 4 / 6 (torsional / rolling friction) and are solved as condim 3
 
 
 def _joint_space_inertia_diag(dyn: DynFacts, qpos_row: np.ndarray) -> np.ndarray:
@@ -528,6 +529,7 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
     never = {tuple(sorted((int(a), int(b)))) for a, b in (nwm.get("pairs") or [])}
     round_t = (GEOM_SPHERE, GEOM_CAPSULE)
     pairs = []
+    n_downgraded = 0
     used_as_f = set()
     for a, b in m.pair_geom:
         a, b = int(a), int(b)
@@ -556,6 +558,8 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         for f_, s_ in dirs:
             if sh[f_][2] == GEOM_PLANE:
                 continue
+            if len(getattr(m, "geom_condim", ())) and max(int(m.geom_condim[a]), int(m.geom_condim[b])) > 3:
+                n_downgraded += 1
             pairs.append((f_, s_, [mu, margin, K, B, d0, dmax, width, 0.0]))
             used_as_f.add(f_)
     # features only of shapes that appear as F
@@ -593,4 +597,5 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         maxcon=int(maxcon), maxpair=int(maxpair), iterations=int(iterations), tolerance=float(tolerance),
         inv_scale=1.0 / (float(dg.mean()) * max(1, nv)), precull_every=int(precull_every), precull_margin=float(precull_margin),
         warmstart=int(bool(warmstart)), near_every=int(near_every), near_margin=float(near_margin), noslip_iterations=int(noslip_iterations), noslip_tolerance=float(noslip_tolerance),
-        solver={("pgs", "pyramidal"): 0, ("newton", "pyramidal"): 1, ("newton", "elliptic"): 2}[(solver, cone)], limit_rows=int(limit_rows), lim_par=lim_par)
+        solver={("pgs", "pyramidal"): 0, ("newton", "pyramidal"): 1, ("newton", "elliptic"): 2}[(solver, cone)], limit_rows=int(limit_rows), lim_par=lim_par,
+        condim_downgraded=n_downgraded)

@@ -92,6 +92,9 @@ class RolloutConfig:
                                       # per SIMD): launches that took every slot would stall the main stream's kernels for their
                                       # whole bulk phase.  3 streams x 128 measured best on Push (tools/rollout_ab.sh: 1.03 M agent
                                       # steps/s; 3 x 64: 0.79 M, 2 x 256: 0.93 M)
+    planner_exclusive: int = 0        # 1: the full-budget launches (continuation of a first-phase launch / pooled retries), 2: every asynchronous
+                                      # planner launch keeps its CUs to itself (C ABI `exclusive_cu`): the one-wave-per-SIMD build of K3 with the
+                                      # FP32 tree mirror in the CU's whole LDS (a budget-exhausting query: 41 instead of 46+ ms)
     discrete_action: bool = False     # --discrete_action (config/__init__.py:110; rl/mopa_rollouts.py:86-88,106-111,349): the policy's
                                       # `ac_type` head (1 = planner), not the action's magnitude, routes a step; direct actions
                                       # are then NOT divided by omega
@@ -335,7 +338,8 @@ class BatchMoPARollout:
             with torch.cuda.stream(stream):
                 res = self.bp.plan(cur_f, target_f, max_iters=iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path, seed=cfg.seed,
                                    env_ids=gids, seeds=seeds, stream=stream, max_workgroups=cfg.planner_workgroups,
-                                   keep_state=keep, resume=resume)
+                                   keep_state=keep, resume=resume,
+                                   exclusive=cfg.planner_exclusive >= 2 or (cfg.planner_exclusive == 1 and (resume is not None or not keep) and iters == self.main_iters))
                 job["path"], job["plen"], job["status"] = res[0], res[1], res[2]
                 if keep:
                     job["pstate"] = res[4]      # trees + counters of the queries this budget leaves unsolved (see _seg_plan)
@@ -345,7 +349,7 @@ class BatchMoPARollout:
                     job["event"].record(stream)
                     rb = self.bp.plan(cur_f, target_f, max_iters=self.main_iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path,
                                       seed=cfg.seed, env_ids=gids, seeds=seeds, stream=stream, max_workgroups=cfg.planner_workgroups,
-                                      resume=res[4])
+                                      resume=res[4], exclusive=cfg.planner_exclusive >= 1)
                     ev_b = torch.cuda.Event()
                     ev_b.record(stream)
                     job["chain"] = {"path": rb[0], "plen": rb[1], "status": rb[2], "event": ev_b}

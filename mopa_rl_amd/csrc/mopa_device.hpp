@@ -82,8 +82,14 @@ MOPA_HD Q4 quat_mul(Q4 a, Q4 b) {
     return r;
 }
 // [3P] mju_normalize4
+// A product of unit quaternions has |n - 1| <= 1e-15 nearly every time, and is then left alone: that case is decided on n^2 without the
+// square root (~20 instructions on the critical path of every body of a kinematic chain).  sqrt is correctly rounded and monotonic, so
+// { s : |sqrt(s) - 1| <= mjMINVAL } is an interval of doubles -- its end points below, checked value by value in tests/test_oracle_fk.py.
+constexpr double kNormSqLo = 0x1.fffffffffffeep-1, kNormSqHi = 0x1.0000000000009p+0;
 MOPA_HD Q4 quat_normalize(Q4 q) {
-    double n = sqrt(fma(q.z, q.z, fma(q.y, q.y, fma(q.x, q.x, q.w * q.w))));
+    const double s = fma(q.z, q.z, fma(q.y, q.y, fma(q.x, q.x, q.w * q.w)));
+    if (s >= kNormSqLo && s <= kNormSqHi) return q;
+    double n = sqrt(s);
     if (n < kMinVal) return Q4{1.0, 0.0, 0.0, 0.0};
     if (fabs(n - 1.0) > kMinVal) {
         double inv = 1.0 / n;
@@ -938,6 +944,12 @@ MOPA_HD uint64_t mix64(uint64_t z) {
     z ^= z >> 27; z *= 0x94D049BB133111EBULL;
     z ^= z >> 31;
     return z;
+}
+// (the stream's key once, then a value per counter: the same two steps as rng_uniform)
+MOPA_HD uint64_t rng_key(uint64_t seed, uint64_t stream) { return mix64(seed + 0x9E3779B97F4A7C15ULL * (stream + 1)); }
+MOPA_HD double rng_uniform_k(uint64_t key, uint64_t counter) {
+    const uint64_t r = mix64(key + 0x9E3779B97F4A7C15ULL * (counter + 1));
+    return (double)(r >> 11) * 0x1.0p-53;
 }
 MOPA_HD double rng_uniform(uint64_t seed, uint64_t stream, uint64_t counter) {
     uint64_t k = mix64(seed + 0x9E3779B97F4A7C15ULL * (stream + 1));

@@ -1,3 +1,4 @@
+import os
 """Pin the oracle's forward kinematics against (i) an independent numpy/scipy composition of the
 compiled body tree and (ii) the self-derived anchors of SURVEY.md Appendix C.  (The reference ships
 no FK golden values and MuJoCo is unavailable: parity vs MuJoCo is unpinned.)"""
@@ -138,3 +139,21 @@ def test_fk_with_offcentre_joint_anchors(env, oracle_mod):
         P0, _ = independent_fk(pi.model, q)
         moved = max(moved, np.abs(P - P0).max())
     assert moved > 0.01      # the anchors really changed the kinematics
+
+
+def test_the_square_root_free_shortcut_of_quat_normalize_is_exact():
+    """csrc/mopa_device.hpp: quat_normalize leaves q alone iff |sqrt(s) - 1| <= 1e-15 (mjMINVAL) and decides that on s = |q|^2 between two
+    constants: every double around the interval's ends, by the definition"""
+    import re
+    src = open(os.path.join(os.path.dirname(__file__), "..", "mopa_rl_amd", "csrc", "mopa_device.hpp")).read()
+    lo, hi = (float.fromhex(x) for x in re.search(r"kNormSqLo = (0x[0-9a-fp+.-]+), kNormSqHi = (0x[0-9a-fp+.-]+);", src).groups())
+    s = np.float64(lo)
+    for _ in range(64):
+        s = np.nextafter(s, -np.inf)
+    n_in = 0
+    for _ in range(64 + 64 + 64):
+        by_definition = not (abs(np.sqrt(s) - 1.0) > 1e-15)
+        assert by_definition == (lo <= s <= hi), float(s).hex()
+        n_in += int(by_definition)
+        s = np.nextafter(s, np.inf)
+    assert n_in == 28

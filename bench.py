@@ -175,7 +175,7 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
     nb = 24         # (the last retry launch drains alone for one straggler's latency, ~46 ms: 8 batches measured 14.6, 32 batches 11.6 ms per batch)
     batches = [dict(start=start, goal=goal, seed=7 + 13 * i) for i in range(nb)]
     lad_kw = dict(max_iters=prm["max_iters"], first_iters=200, max_nodes=prm["max_nodes"], max_path=prm["max_path"],
-                  first_stream=streams[0], retry_streams=streams[1:3])
+                  first_stream=streams[0], retry_streams=streams[1:3], retry_exclusive=bool(int(os.environ.get("MOPA_LADDER_EXCL", "0"))))
     bp.plan_laddered(batches, **lad_kw)        # untimed: per-stream scratch (trees of the pooled retry launches) grows to its final size
     torch.cuda.synchronize()
     t0 = _t.perf_counter()

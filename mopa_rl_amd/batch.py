@@ -182,7 +182,8 @@ class BatchPlanner:
         return (path, plen, status, nchk, ps) if keep_state else (path, plen, status, nchk)
 
     def plan_laddered(self, batches, max_iters: int = 2000, first_iters: int = 300, max_nodes: int = 1024, max_path: int = 256,
-                      retry_streams=None, first_stream=None, max_workgroups_first: int = -1, retry_min: int = 512, resume: bool = True):
+                      retry_streams=None, first_stream=None, max_workgroups_first: int = -1, retry_min: int = 512, resume: bool = True,
+                      retry_exclusive: bool = False):
         """A stream of query batches through RRT-Connect with an iteration ladder.  `batches`: list of dicts with `start`,
         `goal` ([E, nq] tensors), `seed` and optionally `env_ids` / `seeds` as for `plan`.  Every batch first runs with
         `first_iters`; the queries that come back "no exact solution" (a few %: the ones that would have kept the whole
@@ -214,8 +215,8 @@ class BatchPlanner:
             with torch.cuda.stream(sb):
                 cat = lambda k: torch.cat([w[k] for w in wait]).contiguous()
                 r2 = self.plan(cat("start"), cat("goal"), max_iters=max_iters, max_nodes=max_nodes, max_path=max_path, seed=0,
-                               env_ids=cat("ids"), seeds=cat("seeds"), stream=sb, max_workgroups=-1,
-                               resume=PlanState.cat([w["state"] for w in wait]) if resume else None)
+                               env_ids=cat("ids"), seeds=cat("seeds"), stream=sb, max_workgroups=0 if retry_exclusive else -1,
+                               exclusive=retry_exclusive, resume=PlanState.cat([w["state"] for w in wait]) if resume else None)
             # the pooled slices were allocated on `sa` and are read by the cat on `sb`: tell the caching allocator, or the
             # next first launch on `sa` may be handed their blocks while `sb` still waits behind an earlier retry
             for w in wait:

@@ -261,10 +261,40 @@ class CompiledModel:
         with open(path, "w") as f:
             f.write(self.to_json())
 
+    # what the separation proofs in `meta` (tools/prove_separated_pairs.py) were derived from: kinematic tree, joints and their
+    # ranges, collidable geoms, candidate pairs.  The proof keys are only honoured while this hash is the one they were stamped with.
+    PROOF_KEYS = ("never_violating_pairs", "never_violating_pairs_thr", "pair_cull_radius", "prune_guard_band", "never_within_margin_pairs",
+                  "never_violating_pairs_note")
+
+    def geometry_sha256(self) -> str:
+        import hashlib
+        h = hashlib.sha256()
+        for name in ("body_parent", "body_pos", "body_quat", "body_jntadr", "body_jntnum", "jnt_type", "jnt_qposadr", "jnt_body", "jnt_axis",
+                     "jnt_pos", "jnt_ref", "jnt_limited", "jnt_range", "geom_type", "geom_body", "geom_size", "geom_pos", "geom_quat",
+                     "geom_margin", "pair_geom", "mesh_vert"):
+            a = np.ascontiguousarray(getattr(self, name))
+            h.update(name.encode()); h.update(str(a.dtype).encode()); h.update(str(a.shape).encode()); h.update(a.tobytes())
+        return h.hexdigest()
+
+    def drop_stale_proofs(self) -> bool:
+        """remove the proof keys from `meta` if they were stamped for another geometry (or never stamped); True if anything was dropped"""
+        if not any(k in self.meta for k in self.PROOF_KEYS):
+            return False
+        if self.meta.get("proof_geometry_sha256") == self.geometry_sha256():
+            return False
+        for k in self.PROOF_KEYS + ("proof_geometry_sha256",):
+            self.meta.pop(k, None)
+        return True
+
     @classmethod
     def load(cls, path: str) -> "CompiledModel":
         with open(path) as f:
-            return cls.from_json(f.read())
+            m = cls.from_json(f.read())
+        if m.drop_stale_proofs():
+            import warnings
+            warnings.warn(f"{path}: the separation proofs in its meta were made for another geometry and are ignored "
+                          "(rerun tools/prove_separated_pairs.py)")
+        return m
 
 
 # --------------------------------------------------------------------------

@@ -111,3 +111,20 @@ def test_committed_pruning_is_a_subset_of_what_the_tool_proves_today(env, oracle
     assert done == 5
     # and an unlimited slide can never be part of a proof (its box would be empty)
     assert all(P.joint_box(m, j) is not None or int(m.jnt_type[j]) == 2 for j in range(len(m.jnt_names)))
+
+
+def test_separation_proofs_are_bound_to_the_geometry_they_were_made_for():
+    """the proof keys in a scene's meta carry the hash of the kinematic tree / ranges / geoms / pairs they were derived from: the
+    committed scenes match their stamp; a changed joint range drops the proofs at load time (and in tools/compile_scenes.py)"""
+    import warnings
+    from mopa_rl_amd.mjcf import CompiledModel
+    from mopa_rl_amd.scene import ENV_SPECS, scene_path
+    for env, spec in ENV_SPECS.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            m = CompiledModel.load(scene_path(spec.scene))
+        assert m.meta.get("proof_geometry_sha256") == m.geometry_sha256() and len(m.meta["never_violating_pairs"]) > 0
+    m.jnt_range = np.array(m.jnt_range, dtype=np.float64).copy()
+    m.jnt_range[0, 1] += 0.1
+    assert m.drop_stale_proofs() and "never_violating_pairs" not in m.meta and "never_within_margin_pairs" not in m.meta
+    assert not m.drop_stale_proofs()

@@ -29,6 +29,8 @@ def main():
         if os.path.exists(out):      # keep what later tools wrote into the scene's meta (tools/prove_separated_pairs.py)
             from mopa_rl_amd.mjcf import CompiledModel
             m.meta = {**CompiledModel.load(out).meta, **m.meta}
+            if m.drop_stale_proofs():      # the MJCF changed under the proofs: they go, tools/prove_separated_pairs.py has to run again
+                print(f"    {s}: geometry changed -- separation proofs dropped from the meta; rerun tools/prove_separated_pairs.py")
         m.save(out)
         print(f"{s}: nq={m.nq} bodies={len(m.body_names)} geoms={len(m.all_geom_names)} "
               f"collidable={len(m.geom_type)} pairs={len(m.pair_geom)} -> {out} ({os.path.getsize(out)} B)")

@@ -299,6 +299,7 @@ def main():
             cm.meta["pair_cull_radius"] = {"threshold": spec.contact_threshold, "pairs": radii}
             cm.meta["prune_guard_band"] = {"hinge": BAND_HINGE, "slide": BAND_SLIDE}
             cm.meta["never_within_margin_pairs"] = {"floor": CT_FLOOR, "pairs": proven_ct}
+            cm.meta["proof_geometry_sha256"] = cm.geometry_sha256()
             cm.meta["never_violating_pairs_note"] = ("tools/prove_separated_pairs.py: branch-and-bound Lipschitz proof over the joint ranges inflated by "
                                                      f"the guard band ({BAND_HINGE} rad / {BAND_SLIDE} m), margin {MARGIN} m; valid for joint values "
                                                      "inside range + band -- the runtime sends states beyond that through the unpruned pair list")

@@ -873,3 +873,42 @@ def test_states_outside_the_joint_ranges_take_the_full_pair_list(env, oracle_mod
         assert a == ov[i] and np.float64(d).view(np.uint64) == omd[i].view(np.uint64)
     assert (~ov).sum() > 20 and ov.sum() > 20
     sc.close()
+
+
+def test_nearest_neighbour_mirror_sizes_do_not_change_plans(oracle_mod, monkeypatch):
+    """K3's one-wave-per-SIMD build sweeps an FP32 mirror of the trees in LDS and the part a tree outgrows in FP64 from HBM; the answer is
+    the exact sweep's whatever the mirror holds (unique-candidate test, FP64 fallback): no mirror, 64 slots, all the LDS -- and the
+    two-waves-per-SIMD build, which has none -- give the same trees, paths and consumed checks on queries whose trees grow to hundreds of nodes"""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk("SawyerPushObstacle-v0", oracle_mod)
+    bp = BatchPlanner(sc)
+    E = 48
+    qa, row = sample_states(pi, 8000, 77, "uniform")
+    ov, _ = orc.is_valid_batch(qa, row, samples_per_env=len(qa))
+    good = qa[ov == 1]
+    starts = np.repeat(row, E, axis=0)
+    goals = starts.copy()
+    starts[:, pi.ref_joint_pos_indexes] = good[:E]
+    goals[:, pi.ref_joint_pos_indexes] = good[E:2 * E]          # far-apart uniform samples: long searches, many run out the budget
+    s, g = torch.from_numpy(starts).cuda(), torch.from_numpy(goals).cuda()
+    prm = dict(max_iters=1200, max_nodes=2048, max_path=256, seed=11)
+    out = {}
+    for name, cap, kw in (("all", None, {}), ("none", "0", {}), ("64", "64", {}), ("w2", None, {"max_workgroups": -1})):
+        if cap is None:
+            monkeypatch.delenv("MOPA_PLAN_NN_CAP", raising=False)
+        else:
+            monkeypatch.setenv("MOPA_PLAN_NN_CAP", cap)
+        out[name] = [t.cpu().numpy() for t in bp.plan(s, g, **prm, **kw)]
+    torch.cuda.synchronize()
+    st = out["all"][2]
+    assert (st != 0).sum() >= 4 and out["all"][3].max() > 1500          # budget-exhausting queries with big trees are in the set
+    for name in ("none", "64", "w2"):
+        assert np.array_equal(out[name][2], st) and np.array_equal(out[name][1], out["all"][1]) and np.array_equal(out[name][3], out["all"][3]), name
+        for e in range(E):
+            n = int(out["all"][1][e])
+            assert np.array_equal(_bits(out[name][0][e, :n]), _bits(out["all"][0][e, :n])), (name, e)
+    # ... and the oracle agrees on a few of them
+    for e in range(0, E, 12):
+        ost, opath, ochk, _ = orc.plan(starts[e], goals[e], pi.spec.range, 0.005, max_iters=1200, max_nodes=2048, seed=11, env_id=e, max_path=256)
+        assert ost == st[e] and ochk == out["all"][3][e]

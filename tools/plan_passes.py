@@ -21,7 +21,7 @@ for e in f: print(e, chk[e], npass[e], nst[e], n0[e], n1[e])
 import ctypes
 lib = _lib.lib()
 if hasattr(lib, "mopa_debug_plan_times"):
-    buf = (ctypes.c_ulonglong * 48)()
+    buf = (ctypes.c_ulonglong * 64)()
     lib.mopa_debug_plan_times(buf, 1)
     fi = torch.nonzero(torch.tensor(st != 0)).flatten().to(start.device)
     bp.plan(start[fi].contiguous(), goal[fi].contiguous(), max_iters=2000, max_nodes=4096, max_path=256, seed=7, env_ids=fi.contiguous())
@@ -31,7 +31,7 @@ if hasattr(lib, "mopa_debug_plan_times"):
         t[0] / n / 100, t[1] / n / 100, t[2] / n / 100, t[3] / max(t[4], 1), t[5] / max(t[4], 1), t[4] / n))
     print("  pose+fk split (cumulative): after the state fill %.0f, after sin/cos %.0f, after the chain walk %.0f us per env" % (t[42] / n / 100, t[43] / n / 100, t[0] / n / 100))
     print("  whole query %.0f us per env; inside growTree %.0f us (%.0f calls per env)" % (t[44] / n / 100, t[45] / n / 100, t[46] / n))
-    print("  growTree: node fetch + distance + steer %.0f us, checkMotion (passes included) %.0f us, tree append %.0f us per env" % (t[32] / n / 100, t[33] / n / 100, t[34] / n / 100))
+    print("  growTree: node fetch + distance + steer %.0f us, checkMotion (passes included) %.0f us, tree append %.0f us per env" % (t[48] / n / 100, t[49] / n / 100, t[50] / n / 100))
     print("  nearest-neighbour sweeps that fell back to the exact FP64 sweep: %.1f per env" % (t[47] / n))
     if t[40]:
         print("  narrow phase split (cumulative from the start of the collision sweep): after broad %.0f, after closed forms %.0f, after refinement %.0f us per env" % (t[1] / n / 100, t[40] / n / 100, t[2] / n / 100))

@@ -917,6 +917,9 @@ def main():
         if world == 1:
             ro["rollout"] = rollout_section(torch, ENV, args.envs, device, 3)
             ro["rollout_async"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True)     # (a retry launch lives ~25 calls: 300 calls = 12 of its cycles)
+            # the same at twice the envs per GPU: at 4096 half the envs wait for an RRT-Connect query in any call and the call
+            # is bound by host dispatch; the agent-step rate levels off near 8192-16384 resident envs (tools/rollout_envs_sweep.py)
+            ro["rollout_async_2x"] = rollout_section(torch, ENV, 2 * args.envs, device, 200, async_planner=True)
             if args.graphs:          # (HIP-graph replay no longer pays: DESIGN 8; kept behind the flag)
                 ro["rollout_async_graphs"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True, use_graphs=True)
             # the same rollout where a Push policy could actually be trained: the env with dynamics + contacts (stage C)

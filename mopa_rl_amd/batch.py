@@ -31,9 +31,12 @@ def _check_f64(t, name, cols=None):
 
 
 def _stream_handle(stream) -> C.c_void_p:
-    torch = _torch()
-    s = stream if stream is not None else torch.cuda.current_stream()
-    return C.c_void_p(s.cuda_stream)
+    if stream is not None:
+        return C.c_void_p(stream.cuda_stream)
+    # the current stream's raw handle without building a torch.cuda.Stream object (a dozen lookups per agent_step call:
+    # ~9 us each through torch.cuda.current_stream(), well under 1 us this way)
+    tc = _torch()._C
+    return C.c_void_p(tc._cuda_getCurrentRawStream(tc._cuda_getDevice()))
 
 
 class PlanState:

@@ -47,9 +47,10 @@ from . import _lib
 from .batch import BatchPlanner, _ptr, _stream_handle, _torch
 from .scene import ENV_SPECS, load_scene, planner_inputs, qpos_joint_arrays
 
-KIND_PUSH, KIND_LIFT, KIND_ASSEMBLY = 0, 1, 2
+KIND_PUSH, KIND_LIFT, KIND_ASSEMBLY, KIND_PUSHER = 0, 1, 2, 3
 OBJECT_BODY = {KIND_PUSH: "cube", KIND_LIFT: "cube", KIND_ASSEMBLY: "furniture"}     # the manipulated object's free body (stage C)
-ENV_KIND = {"SawyerPushObstacle-v0": KIND_PUSH, "SawyerLiftObstacle-v0": KIND_LIFT, "SawyerAssemblyObstacle-v0": KIND_ASSEMBLY}
+ENV_KIND = {"SawyerPushObstacle-v0": KIND_PUSH, "SawyerLiftObstacle-v0": KIND_LIFT, "SawyerAssemblyObstacle-v0": KIND_ASSEMBLY,
+            "PusherObstacle-v0": KIND_PUSHER}
 
 # observation layouts == the reference's OrderedDict order (sawyer.py:317-338, then the env's own `_get_obs`)
 _COMMON = [("joint_pos", 7), ("joint_vel", 7), ("gripper_qpos", 2), ("gripper_qvel", 2), ("eef_pos", 3), ("eef_quat", 4)]
@@ -57,6 +58,8 @@ OBS_LAYOUTS = {
     KIND_PUSH: OrderedDict(_COMMON + [("target_pos", 3), ("cube_pos", 3), ("cube_quat", 4), ("gripper_to_cube", 3), ("cube_to_target", 2)]),
     KIND_LIFT: OrderedDict(_COMMON + [("cube_pos", 3), ("cube_quat", 4), ("gripper_to_cube", 3)]),
     KIND_ASSEMBLY: OrderedDict(_COMMON + [("hole", 3), ("pegHead", 3), ("pegEnd", 3), ("peg_quat", 4)]),
+    # env/pusher/pusher_obstacle.py:183-204: default = [cos theta 4, sin theta 4, box qpos 2, joint vel 4, box vel 2]
+    KIND_PUSHER: OrderedDict([("default", 16), ("fingertip", 2), ("goal", 2)]),
 }
 OBS_LAYOUT = OBS_LAYOUTS[KIND_PUSH]
 OBS_DIM = 40
@@ -70,7 +73,8 @@ class EnvFacts:
       all       frame 0 = site grip_site,  quat 0 = body right_ee_attchment
       push      frames 1 right_eef, 2 left_eef (sites), 3 cube, 4 target (bodies);  quat 1 = cube
       lift      frames 1 cube, 2 bin1 (bodies);  quat 1 = cube;  touch geoms = [can, left-finger geoms, right-finger geoms]
-      assembly  frames 1 hole, 2 hole_bottom, 3 pegHead, 4 pegEnd (sites);  quat 1 = peg"""
+      assembly  frames 1 hole, 2 hole_bottom, 3 pegHead, 4 pegEnd (sites);  quat 1 = peg
+      pusher    frames 0 site fingertip, 1 body fingertip, 2 box, 3 target (bodies);  quats = fingertip, box (unused)"""
     kind: int
     arm_qpos_idx: np.ndarray
     grip_qpos_idx: np.ndarray
@@ -123,6 +127,20 @@ def env_facts(env_name: str, model) -> EnvFacts:
     def cgeom(name):          # index among the collidable geoms
         return int(np.where(m.geom_mjid == m.geom_name2id(name))[0][0])
 
+    if kind == KIND_PUSHER:
+        # env/pusher/pusher_obstacle.py: four hinges (joint0 unlimited) under torque motors driven by the env's PID loop
+        # (env/base.py:200-209); kinematic limit: the joints reach `desired_state` (no ctrl range: the ctrl is a torque)
+        arm = np.array([m.get_joint_qpos_addr(j) for j in spec.robot_joints], dtype=np.int32)
+        frames = [site("fingertip"), body("fingertip"), body("box"), body("target")]
+        jidx, jlo, jhi, jlim = qpos_joint_arrays(m)
+        return EnvFacts(
+            kind=kind, arm_qpos_idx=arm, grip_qpos_idx=np.zeros(0, dtype=np.int32), act_qpos_idx=arm.copy(),
+            act_lo=np.full(len(arm), -np.inf), act_hi=np.full(len(arm), np.inf),
+            frame_body=np.array([f[0] for f in frames], dtype=np.int32), frame_off=np.array([f[1] for f in frames], dtype=np.float64),
+            quat_body=np.array([m.body_names.index("fingertip"), m.body_names.index("box")], dtype=np.int32),
+            touch_geom=np.zeros(0, dtype=np.int32), n_touch_left=0,
+            qpos_min=jlo[jidx].astype(np.float64), qpos_max=jhi[jidx].astype(np.float64), qpos_limited=jlim[jidx].astype(np.int32),
+            reset_jitter_idx=np.zeros(0, dtype=np.int64))
     frames = [site("grip_site")]
     quats = [m.body_names.index("right_ee_attchment")]
     touch, n_left, jitter = [], 0, []

@@ -1525,6 +1525,7 @@ static int env_touch(const OrcScene *s, int g_obj, int g_fin, const double *xpos
 }
 
 int orc_env_obs_dim(const OrcEnvDesc *d) {
+    if (d->kind == 3) return 3 * d->n_arm + 8;      /* cos, sin, box 2, joint vel, box vel 2, fingertip 2, goal 2 */
     const int base = 2 * d->n_arm + 2 * d->n_grip + 7;
     return base + (d->kind == 0 ? 15 : (d->kind == 1 ? 10 : 13));
 }
@@ -1550,7 +1551,8 @@ static void env_step_impl(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDe
             const int adr = d->arm_qpos_idx[j];
             const double prev = (is_planner && *has_prev) ? prev_state[j] : qpos[adr];
             const double a = is_planner ? action[j] : action[j] * d->ac_scale;
-            const double desired = prev + clampd(a, -d->ac_scale, d->ac_scale);
+            /* Pusher (pusher_obstacle.py:262-266): `desired_state = self._prev_state + action` overrides both scaled forms */
+            const double desired = d->kind == 3 ? prev + action[j] : prev + clampd(a, -d->ac_scale, d->ac_scale);
             ctrl[j] = desired;
             prev_state[j] = desired;
         }
@@ -1570,6 +1572,7 @@ static void env_step_impl(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDe
         if (move)
             for (int k = 0; k < d->n_act; k++) qpos[d->act_qpos_idx[k]] = clampd(ctrl[k], d->act_lo[k], d->act_hi[k]);
         *has_prev = 1;
+        if (d->kind != 3)       /* (Pusher: no servo range stops a joint at its limit -- the clamp comes after the obs, as in the reference) */
         for (int i = 0; i < s->nq; i++)
             if (d->qpos_limited[i]) qpos[i] = clampd(qpos[i], d->qpos_min[i], d->qpos_max[i]);
         }
@@ -1584,6 +1587,27 @@ static void env_step_impl(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDe
     double r = 0.0;
     int succ = 0;
     int o = 0;
+    if (d->kind == 3) {
+        /* PusherObstacle (env/pusher/pusher_obstacle.py:183-204 `_get_obs`, :223-245 `compute_reward`); frames: 0 site fingertip,
+         * 1 body fingertip, 2 body box, 3 body target; the box / goal sliders are the last four qpos entries (:187,:202) */
+        const double *tip_site = P[0], *tip = P[1], *box = P[2], *target = P[3];
+        double v[3];
+        for (int j = 0; j < na; j++) { double sn, cs; orc_sincos(qpos[d->arm_qpos_idx[j]], &sn, &cs); obs[j] = cs; obs[na + j] = sn; }
+        o = 2 * na;
+        obs[o++] = qpos[s->nq - 2]; obs[o++] = qpos[s->nq - 1];                      /* box qpos */
+        for (int j = 0; j < na + 2; j++) obs[o++] = 0.0;                             /* joint and box velocities: the kinematic limit */
+        obs[o++] = tip[0]; obs[o++] = tip[1];                                        /* "fingertip": body position, xy */
+        obs[o++] = qpos[s->nq - 4]; obs[o++] = qpos[s->nq - 3];                      /* "goal" */
+        sub3(v, box, tip_site);
+        const double dist_box_to_gripper = norm3(v);
+        sub3(v, box, target);
+        const double box_to_target = norm3(v);
+        double reward_reach = 0.0, reward_push = 0.0;
+        if (dist_box_to_gripper < 0.1) reward_reach = 0.1 * (1.0 - orc_tanh_pos(5.0 * dist_box_to_gripper));
+        if (box_to_target < 0.1) reward_push = 0.3 * (1.0 - orc_tanh_pos(5.0 * box_to_target));
+        r = reward_reach + reward_push;
+        if (box_to_target < d->distance_threshold) { r += d->success_reward; succ = 1; }
+    } else {
     for (int j = 0; j < na; j++) obs[o++] = qpos[d->arm_qpos_idx[j]];          /* joint_pos */
     for (int j = 0; j < na; j++) obs[o++] = dyn ? dyn_vel_of(dyn, qvel, d->arm_qpos_idx[j]) : 0.0;          /* joint_vel */
     for (int j = 0; j < d->n_grip; j++) obs[o++] = qpos[d->grip_qpos_idx[j]];  /* gripper_qpos */
@@ -1648,12 +1672,13 @@ static void env_step_impl(const OrcScene *s, const OrcEnvDesc *d, const OrcDynDe
         for (int i = 0; i < 3; i++) obs[o++] = end[i];
         obs[o++] = oq[0]; obs[o++] = oq[1]; obs[o++] = oq[2]; obs[o++] = oq[3];
     }
+    }
     if (action) {
         *ep_len += 1;
         *reward = r;
         *success = (uint8_t)succ;
         *done = (uint8_t)(succ || *ep_len == d->max_episode_steps);
-        if (dyn)     /* `_after_step`'s clamp, after reward / obs as in the reference */
+        if (dyn || d->kind == 3)     /* `_after_step`'s clamp, after reward / obs as in the reference */
             for (int i = 0; i < s->nq; i++)
                 if (d->qpos_limited[i]) qpos[i] = clampd(qpos[i], d->qpos_min[i], d->qpos_max[i]);
     }

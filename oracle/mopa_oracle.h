@@ -108,7 +108,7 @@ double orc_tanh_pos(double x);
 /*  kinematic env.step restated -- see the comment on orc_env_step in mopa_oracle.c.
  * Same fields as MopaEnvDesc (include/mopa_hip.h) without the model. */
 typedef struct OrcEnvDesc {
-    int32_t kind;                                   /* 0 push, 1 lift, 2 assembly */
+    int32_t kind;                                   /* 0 push, 1 lift, 2 assembly (Sawyer), 3 PusherObstacle */
     int32_t n_arm; const int32_t *arm_qpos_idx;
     int32_t n_grip; const int32_t *grip_qpos_idx;
     int32_t n_act; const int32_t *act_qpos_idx; const double *act_lo, *act_hi;   /* position actuators, ctrl order (arm first) */

@@ -11,7 +11,9 @@ import os
 import numpy as np
 import pytest
 
-ENVS = [("SawyerPushObstacle-v0", "push"), ("SawyerLiftObstacle-v0", "lift"), ("SawyerAssemblyObstacle-v0", "assembly")]
+ENVS = [("SawyerPushObstacle-v0", "push"), ("SawyerLiftObstacle-v0", "lift"), ("SawyerAssemblyObstacle-v0", "assembly"),
+        ("PusherObstacle-v0", "pusher")]       # pusher: env/pusher/pusher_obstacle.py, its PID loop at the kinematic limit
+DIST_THRESHOLD = {"pusher": 0.05}              # config/pusher.py:16-20 (the Sawyer envs: 0.06)
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -35,7 +37,8 @@ def test_oracle_env_equals_reference_env(env, tag, oracle_mod):
     orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
     facts = env_facts(env, pi.model)
     E, T = G["action"].shape[:2]
-    ref = oracle_mod.OracleEnv(orc, facts, E, ac_scale=pi.spec.ac_scale, max_episode_steps=int(G["max_episode_steps"]))
+    ref = oracle_mod.OracleEnv(orc, facts, E, ac_scale=pi.spec.ac_scale, max_episode_steps=int(G["max_episode_steps"]),
+                               distance_threshold=DIST_THRESHOLD.get(tag, 0.06))
     assert ref.obs_dim == G["obs"].shape[2] and ref.action_dim == G["action"].shape[2]
     ref.set_state(G["qpos0"])
     np.testing.assert_allclose(ref.obs, G["obs0"], rtol=0, atol=1e-12)

@@ -319,6 +319,58 @@ def make_ref_env(env_name, seed=0, max_episode_steps=250):
     return env
 
 
+PUSHER_KW = dict(reward_type="dense", distance_threshold=0.05, success_reward=150.0, frame_skip=1, ctrl_reward_coef=0.0)   # config/pusher.py
+
+
+def make_ref_env_pusher(seed=0, max_episode_steps=250):
+    """The reference's `PusherObstacleEnv` (env/pusher/pusher_obstacle.py) over refshim.FakeSim, built like make_ref_env.
+    Its `_step` drives torque motors through the env's PID loop (`_get_control` + `_do_simulation`, env/base.py:200-209,
+    388-400) for int(frame_dt / dt) sub-steps; the kinematic limit of that loop -- the four joints reach `desired_state`,
+    nothing else moves, velocities are zero -- replaces the two methods: `_get_control` hands the desired state through,
+    `_do_simulation` writes it."""
+    from env.pusher import PusherObstacleEnv
+    from gym import spaces
+    spec = ENV_SPECS["PusherObstacle-v0"]
+    m = load_scene(spec.scene)
+    env = object.__new__(PusherObstacleEnv)
+    sim = refshim.FakeSim(m, actuators=[f"motor_{j}" for j in spec.robot_joints])
+    sim.model.opt.timestep = 0.01                    # pusher_gripper.xml:7
+    env.sim, env.data = sim, sim.data
+    env._kwargs = dict(PUSHER_KW)
+    env._env_config = {"frame_skip": 1, "ctrl_reward": 0.0, "init_randomness": 1e-5, "max_episode_steps": max_episode_steps,
+                       "unstable_penalty": 0, "reward_type": "dense", "distance_threshold": PUSHER_KW["distance_threshold"],
+                       "success_reward": PUSHER_KW["success_reward"]}
+    env._frame_skip, env._frame_dt = 1, sim.model.opt.timestep          # one pass through the sub-step loop
+    env._seed, env.np_random = seed, np.random.RandomState(seed)
+    env.render_mode, env._viewer = "no", None
+    idx, lo, hi, lim = qpos_joint_arrays(m)
+    env.jnt_indices, env._jnt_minimum, env._jnt_maximum, env._is_jnt_limited = list(idx), lo, hi, lim
+    env.joint_space = spaces.Dict([("default", spaces.Box(low=lo, high=hi, dtype=np.float32))])
+    env.action_space = spaces.Dict([("default", spaces.Box(low=-np.ones(4), high=np.ones(4), dtype=np.float32))])
+    env.joint_names = list(spec.robot_joints)
+    env.ref_joint_pos_indexes = [sim.model.get_joint_qpos_addr(x) for x in env.joint_names]
+    env.ref_joint_vel_indexes = [sim.model.get_joint_qvel_addr(x) for x in env.joint_names]
+    env.ref_indicator_joint_pos_indexes = [sim.model.get_joint_qpos_addr(x + "-goal") for x in env.joint_names]
+    env.ref_dummy_joint_pos_indexes = [sim.model.get_joint_qpos_addr(x + "-dummy") for x in env.joint_names]
+    env._ac_scale = 0.1
+    env.min_world_size, env.max_world_size = [-0.41, -0.41], [0.41, 0.41]
+    env._prev_state, env._i_term = None, 0.0
+    env._fail = env._terminal = env._success = False
+    env._episode_reward, env._episode_length, env._episode_time = 0, 0, 0.0
+    env._set_camera_position = env._set_camera_rotation = lambda *a, **k: None
+    adr = np.array(env.ref_joint_pos_indexes)
+
+    env._get_control = lambda state, prev_state, target_vel: np.asarray(state, dtype=np.float64).copy()
+
+    def kinematic_limit(a=None):
+        sim.data.qpos[adr] = a
+        sim.data.qvel[:] = 0.0
+        sim.forward()
+
+    env._do_simulation = kinematic_limit
+    return env
+
+
 def flat_ob(ob):
     return np.concatenate([np.asarray(v, dtype=np.float64).ravel() for v in ob.values()])
 
@@ -560,6 +612,61 @@ def gen_env():
              reward=rew, done=done, success=succ, qpos_after=q_after, max_episode_steps=np.array(MAXS))
 
 
+def gen_env_pusher():
+    """PusherObstacleEnv.step on scripted direct / planner actions from set states (joint0 is unlimited: actions carry it across
+    +-pi; the box sits near the fingertip / the target in some envs so that both reward terms and the success branch occur)."""
+    rng = np.random.default_rng(77)
+    E, T, MAXS = 12, 20, 20
+    env0 = make_ref_env_pusher()
+    nq = env0.sim.model.nq
+    q0 = np.zeros((E, nq)); act = np.zeros((E, T, 4)); is_pl = np.zeros((E, T), dtype=np.int64); fresh = np.zeros((E, T), dtype=np.int64)
+    n_steps = np.zeros(E, dtype=np.int64)
+    obs = np.zeros((E, T, 20)); obs0 = np.zeros((E, 20))
+    rew = np.zeros((E, T)); done = np.zeros((E, T), dtype=np.int64); succ = np.zeros((E, T), dtype=np.int64)
+    q_after = np.zeros((E, T, nq))
+    m = env0.sim._m
+    box_base = np.asarray(m.body_pos[m.body_names.index("box")])[:2]
+    tgt_base = np.asarray(m.body_pos[m.body_names.index("target")])[:2]
+    for e in range(E):
+        env = make_ref_env_pusher(seed=50 + e, max_episode_steps=MAXS)
+        q = env.sim.data.qpos.copy()
+        q[:4] = rng.uniform([-3.0, -2.0, -2.0, -2.0], [3.0, 2.0, 2.0, 2.0])
+        if e % 4 == 3:
+            q[0] = rng.choice([-3.1, 3.1])            # next to the seam of the unlimited joint
+        env.set_state(q, env.sim.data.qvel.copy())
+        tip = env.sim.data.get_site_xpos("fingertip")[:2].copy()
+        if e % 2 == 1:                                # box next to the fingertip (slider value = world position - body base)
+            q[-2:] = np.clip(tip + rng.normal(0, 0.03, 2) - box_base, -0.4, 0.4)
+        else:
+            q[-2:] = rng.uniform(-0.3, 0.3, 2)
+        if e % 3 == 0:                                # goal next to the box: reward_push, and within the threshold for some
+            q[-4:-2] = np.clip(q[-2:] + box_base - tgt_base + rng.normal(0, 0.04 if e % 2 else 0.02, 2), -0.4, 0.4)
+        else:
+            q[-4:-2] = rng.uniform(-0.3, 0.3, 2)
+        env.set_state(q, env.sim.data.qvel.copy())
+        env._after_reset()
+        env._prev_state = None
+        q0[e] = env.sim.data.qpos
+        obs0[e] = flat_ob(env._get_obs())
+        for t in range(T):
+            pl = int(rng.random() < 0.5)
+            a = rng.uniform(-0.12, 0.12, 4) if pl else rng.uniform(-1.0, 1.0, 4)
+            if t % 5 == 0:
+                env._reset_prev_state()
+                fresh[e, t] = 1
+            ob, r, dn, info = env.step(OrderedDict(default=a.copy()), is_planner=bool(pl))
+            act[e, t], is_pl[e, t] = a, pl
+            obs[e, t], rew[e, t], done[e, t], succ[e, t] = flat_ob(ob), r, int(dn), int(env._success)
+            q_after[e, t] = env.sim.data.qpos
+            n_steps[e] = t + 1
+            if dn:
+                break
+    print(f"  env[pusher]: steps {int(n_steps.sum())} nonzero rewards {int((rew != 0).sum())} max reward {rew.max():.3f} "
+          f"success {int(succ.sum())} done {int(done.sum())} |joint0| max {np.abs(q_after[:, :, 0]).max():.2f}")
+    save("ref_py_env_pusher.npz", qpos0=q0, obs0=obs0, action=act, is_planner=is_pl, fresh_prev=fresh, n_steps=n_steps, obs=obs,
+         reward=rew, done=done, success=succ, qpos_after=q_after, max_episode_steps=np.array(MAXS))
+
+
 def gen_rollouts():
     gen_rollout()
     gen_rollout(E=12, T=4, reuse=True)
@@ -569,7 +676,7 @@ def gen_rollouts():
     gen_rollout(E=24, T=5, discrete=True)
 
 
-SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env)
+SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env, env_pusher=gen_env_pusher)
 
 
 def main():

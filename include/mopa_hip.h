@@ -244,10 +244,19 @@ int mopa_debug_pair_dist(MopaScene *scene, const double *qpos_host /*[nq]*/, dou
  *   ASSEMBLY  frames 1..4 = sites "hole","hole_bottom","pegHead","pegEnd";                     quat 1 = "peg"
  *             obs[38]: common 25 + hole, pegHead, pegEnd, peg_quat(wxyz)
  *   common 25 = joint_pos 7, joint_vel 7 (0), gripper_qpos 2, gripper_qvel 2 (0), eef_pos 3, eef_quat 4 (xyzw)
+ *   PUSHER    PusherObstacle-v0 (env/pusher/pusher_obstacle.py:183-274; BASELINE config 1's env, joint0 unlimited): four hinges under
+ *             torque motors driven by the env's PID loop (env/base.py:200-209); kinematic limit: the joints reach
+ *             desired_state = prev + action -- the action UNSCALED and UNCLIPPED, as the reference's `_step` leaves it (:262-266);
+ *             the joint-limit clamp comes after reward / obs.  frames 0 = site "fingertip", 1 = body "fingertip", 2 = body "box",
+ *             3 = body "target"; quats = "fingertip", "box" (unused); n_grip 0.
+ *             obs[20]: cos(theta) 4, sin(theta) 4, box qpos 2 (= qpos[nq-2:]), joint vel 4 (0), box vel 2 (0), fingertip xy 2,
+ *             goal 2 (= qpos[nq-4:nq-2]);  reward: 0.1 (1 - tanh 5 d_tip_box) [d < 0.1] + 0.3 (1 - tanh 5 d_box_target) [d < 0.1],
+ *             success: d_box_target < distance_threshold (config/pusher.py: 0.05)
  * ====================================================================================================== */
 #define MOPA_ENV_PUSH 0
 #define MOPA_ENV_LIFT 1
 #define MOPA_ENV_ASSEMBLY 2
+#define MOPA_ENV_PUSHER 3
 #define MOPA_ENV_OBS_DIM 40      /* largest observation (PUSH); see mopa_env_obs_dim */
 
 typedef struct MopaEnvDesc {
@@ -261,7 +270,7 @@ typedef struct MopaEnvDesc {
     const int32_t *act_qpos_idx;     /* [n_act] qpos address of the actuated joint */
     const double *act_ctrl_lo;       /* [n_act] ctrlrange (-inf / +inf when not ctrllimited) */
     const double *act_ctrl_hi;
-    int32_t n_frames;                /* 5 (PUSH, ASSEMBLY) or 3 (LIFT), slots as listed above */
+    int32_t n_frames;                /* 5 (PUSH, ASSEMBLY), 3 (LIFT) or 4 (PUSHER), slots as listed above */
     const int32_t *frame_body;       /* [n_frames] */
     const double *frame_off;         /* [n_frames,3] offset in the body frame (site position; 0 for a body frame) */
     int32_t n_quats;                 /* 2 */
@@ -283,12 +292,13 @@ typedef struct MopaEnv MopaEnv;
 
 int mopa_env_create(const MopaEnvDesc *desc, MopaEnv **out);
 void mopa_env_destroy(MopaEnv *env);
-int mopa_env_obs_dim(const MopaEnv *env);      /* 40 / 35 / 38 */
+int mopa_env_obs_dim(const MopaEnv *env);      /* 40 / 35 / 38 / 20 */
 int mopa_env_action_dim(const MopaEnv *env);   /* n_arm (+1 for LIFT) */
 
 /* One step of E envs (all pointers device, f64 unless noted).  Per env e:
  *   prev = (is_planner && has_prev[e]) ? prev_state[e] : qpos[e, arm]
  *   desired = prev + clip(is_planner ? action[e, :n_arm] : action[e, :n_arm]*ac_scale, -ac_scale, +ac_scale)
+ *   (PUSHER: desired = prev + action[e, :n_arm])
  *   LIFT: gripper targets = qpos[e, gripper] + action[e, n_arm]
  *   move_mask[e] (NULL = 1): bit 1 set -> env e sits this call out entirely (nothing read or written);
  *   bit 0 set -> every actuated joint = its target clamped to ctrlrange (kinematic servo); bit 0 clear -> the command is

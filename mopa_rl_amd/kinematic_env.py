@@ -182,15 +182,20 @@ def push_env_facts(model) -> EnvFacts:
 
 
 class BatchKinematicEnv:
-    """E envs of one of the three Sawyer obstacle tasks, stepped kinematically on one GPU."""
+    """E envs of one of the three Sawyer obstacle tasks -- or of PusherObstacle-v0 (KIND_PUSHER: four hinges, joint0 unlimited) --
+    stepped kinematically on one GPU."""
 
     def __init__(self, env_name: str, num_envs: int, device=None, seed: int = 0, max_episode_steps: int = 250,
-                 distance_threshold: float = 0.06, success_reward: float = 150.0, ac_scale: Optional[float] = None,
+                 distance_threshold: Optional[float] = None, success_reward: float = 150.0, ac_scale: Optional[float] = None,
                  block_invalid: bool = False, model=None, dynamics: bool = False, frame_dt: float = 0.15, contacts=False,
                  contact_options: dict = None, dyn_lanes: int = 1):
         torch = _torch()
         if env_name not in ENV_KIND:
             raise _lib.MopaError(f"no batched kinematic env for {env_name!r}")
+        if distance_threshold is None:        # config/sawyer.py: 0.06, config/pusher.py:16-20: 0.05
+            distance_threshold = 0.05 if ENV_KIND[env_name] == KIND_PUSHER else 0.06
+        if dynamics and ENV_KIND[env_name] == KIND_PUSHER:
+            raise _lib.MopaError("PusherObstacle-v0: kinematic env only (the dynamics / contact kernels restate the Sawyer envs' servo model)")
         if not torch.cuda.is_available():
             raise _lib.MopaError("BatchKinematicEnv needs a HIP device (there is no CPU fallback)")
         self.env_name = env_name
@@ -247,9 +252,10 @@ class BatchKinematicEnv:
         self._gen = torch.Generator(device=dev)
         self._gen.manual_seed(int(seed))
         self._qpos0 = torch.tensor(self.model.qpos0, dtype=f64, device=dev)
-        self._init_arm = torch.tensor(self.spec.init_qpos, dtype=f64, device=dev)
+        init_arm = self.spec.init_qpos if len(self.spec.init_qpos) else np.asarray(self.model.qpos0)[np.asarray(f.arm_qpos_idx, dtype=np.int64)]
+        self._init_arm = torch.tensor(np.asarray(init_arm, dtype=np.float64), dtype=f64, device=dev)
         row = np.array(self.model.qpos0, dtype=np.float64)
-        row[np.asarray(self.facts.arm_qpos_idx, dtype=np.int64)] = np.asarray(self.spec.init_qpos, dtype=np.float64)
+        row[np.asarray(self.facts.arm_qpos_idx, dtype=np.int64)] = np.asarray(init_arm, dtype=np.float64)
         self.init_qpos_row = row            # qpos0 with the arm at the env's init_qpos: the reset pose without its noise
         self._arm_idx = torch.tensor(f.arm_qpos_idx, dtype=torch.long, device=dev)
         self._jitter_idx = torch.tensor(f.reset_jitter_idx, dtype=torch.long, device=dev)
@@ -471,8 +477,11 @@ class BatchKinematicEnv:
         sawyer_push_obstacle.py:36-52); everything else qpos0.  `mask` (bool/uint8 [E]) resets only those envs."""
         torch = _torch()
         E, dev = self.E, self.device
-        q = self._qpos0.expand(E, self.nq).clone()
-        q[:, self._arm_idx] = self._init_arm + 0.02 * torch.randn(E, self.n_arm, dtype=torch.float64, device=dev, generator=self._gen)
+        if self.kind == KIND_PUSHER:
+            q = self._reset_pusher()
+        else:
+            q = self._qpos0.expand(E, self.nq).clone()
+            q[:, self._arm_idx] = self._init_arm + 0.02 * torch.randn(E, self.n_arm, dtype=torch.float64, device=dev, generator=self._gen)
         if len(self._jitter_idx):
             q[:, self._jitter_idx] += (torch.rand(E, len(self._jitter_idx), dtype=torch.float64, device=dev, generator=self._gen) * 0.02 - 0.01)
         if mask is None:
@@ -487,6 +496,46 @@ class BatchKinematicEnv:
         self._rest(mask)
         self._launch(None, False, None)
         return self.obs
+
+    def _reset_pusher(self, draws: int = 64, max_rounds: int = 24):
+        """`PusherObstacleEnv._reset` (env/pusher/pusher_obstacle.py:40-68) for all E envs: goal and box ~ U([-0.35, 0.13], [-0.24, 0.2])
+        written into their sliders, every qpos entry += U(-0.02, 0.02); a draw is kept when nothing touches (`ncon == 0`: K1 with no
+        ignored pair at threshold 0), box and target are more than 0.1 apart and goal_x <= box_x.  The reference loops until a
+        draw passes (about 1.5 % do: both points come from one 0.11 x 0.07 patch); here every round draws `draws` candidates per
+        env, validates them in one launch and keeps each env's FIRST passing one -- the same distribution (rows that saw no
+        passing draw in `max_rounds` rounds keep their last candidate)."""
+        torch = _torch()
+        E, K, dev, f64 = self.E, int(draws), self.device, torch.float64
+        if getattr(self, "_reset_scene", None) is None:
+            pi = planner_inputs(self.env_name, self.model)
+            self._reset_scene = _lib.Scene(pi.model, pi.passive_joint_idx, [], 0.0, device=dev.index if dev.index is not None else -1,
+                                           prune_pairs=False)
+            self._reset_bp = BatchPlanner(self._reset_scene)
+            m = self.model
+            self._box_off = torch.tensor(np.asarray(m.body_pos[m.body_names.index("box")]) - np.asarray(m.body_pos[m.body_names.index("target")]),
+                                         dtype=f64, device=dev)
+        lo = torch.tensor([-0.35, 0.13], dtype=f64, device=dev)
+        hi = torch.tensor([-0.24, 0.2], dtype=f64, device=dev)
+        q = self._qpos0.expand(E, self.nq).clone()
+        todo = torch.ones(E, dtype=torch.bool, device=dev)
+        rows = torch.arange(E, device=dev)
+        for r in range(max_rounds):
+            c = self._qpos0 + (torch.rand(E, K, self.nq, dtype=f64, device=dev, generator=self._gen) * 0.04 - 0.02)
+            goal = lo + (hi - lo) * torch.rand(E, K, 2, dtype=f64, device=dev, generator=self._gen)
+            box = lo + (hi - lo) * torch.rand(E, K, 2, dtype=f64, device=dev, generator=self._gen)
+            c[:, :, -4:-2], c[:, :, -2:] = goal, box
+            flat = c.view(E * K, self.nq)
+            free = self._reset_bp.is_valid(flat[:, self._arm_idx].contiguous(), flat, samples_per_env=1).bool().view(E, K)
+            d = torch.cat([box - goal, torch.zeros(E, K, 1, dtype=f64, device=dev)], dim=2) + self._box_off
+            ok = free & (d.norm(dim=2) > 0.1) & (goal[:, :, 0] <= box[:, :, 0])
+            first = torch.argmax(ok.to(torch.uint8), dim=1)             # the first passing draw (0 when none passes)
+            hit = ok.any(dim=1)
+            take = todo & (hit if r < max_rounds - 1 else torch.ones_like(hit))
+            q = torch.where(take[:, None], c[rows, first], q)
+            todo = todo & ~hit
+            if not bool(todo.any()):
+                break
+        return q
 
     def set_state(self, qpos):
         """Load explicit qpos rows [E, nq] (tests, replaying recorded states) and refresh the obs."""

@@ -1,5 +1,7 @@
 """GPU parity of K4 (`k_env_step`, the batched kinematic env.step) against oracle/mopa_oracle.c:orc_env_step:
 observations, rewards, flags, counters and the carried state must be equal BIT FOR BIT over whole rollouts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -188,7 +190,7 @@ def test_env_abi_argument_errors(torch_mod):
         env.step(torch_mod.zeros(4, 6, dtype=torch_mod.float64, device=env.device))
 
 
-@pytest.mark.parametrize("env_name", ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0"])
+@pytest.mark.parametrize("env_name", ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "SawyerAssemblyObstacle-v0", "PusherObstacle-v0"])
 @pytest.mark.parametrize("record", [False, True])
 def test_waypoint_execution_forms_agree(env_name, record, torch_mod):
     """`mopa_env_exec_batch` has two forms: one lane walking an env's waypoints step by step (k_env_exec), and all
@@ -240,3 +242,51 @@ def test_waypoint_execution_forms_agree(env_name, record, torch_mod):
     for k in outs["walk"]:
         a, b = outs["walk"][k], outs["slots"][k]
         assert np.array_equal(a.view(np.uint8), b.view(np.uint8)), k
+
+
+def test_pusher_env_bit_identical_to_oracle(oracle_mod, torch_mod):
+    """PusherObstacle-v0 (BASELINE config 1's env: four hinges, joint0 unlimited; env/pusher/pusher_obstacle.py): K4's fourth kind
+    against the oracle -- unscaled actions, the joint-limit clamp after the obs, cos / sin observations, both reward terms and the
+    success branch -- bit for bit; start states: random arm poses, the box next to the fingertip, the goal next to the box"""
+    from mopa_rl_amd.kinematic_env import env_facts, make_env
+    from mopa_rl_amd.scene import planner_inputs
+    torch = torch_mod
+    env_name = "PusherObstacle-v0"
+    pi = planner_inputs(env_name)
+    f = env_facts(env_name, pi.model)
+    orc = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_py_env_pusher.npz"))
+    rng = np.random.default_rng(5)
+    E = 384
+    q = np.tile(np.asarray(pi.model.qpos0, dtype=np.float64), (E, 1))
+    q[:, :4] = rng.uniform([-6.0, -2.9, -2.9, -2.9], [6.0, 2.9, 2.9, 2.9], size=(E, 4))
+    q[:, -4:] = rng.uniform(-0.3, 0.3, size=(E, 4))
+    near = np.concatenate([G["qpos0"], G["qpos_after"][np.arange(len(G["qpos0"])), G["n_steps"] // 2]])
+    q[: 8 * len(near)] = np.tile(near, (8, 1))
+    q[: 8 * len(near), :4] += rng.normal(0, 0.01, size=(8 * len(near), 4))
+    env = make_env(env_name, E, max_episode_steps=5)
+    ref = oracle_mod.OracleEnv(orc, f, E, ac_scale=pi.spec.ac_scale, max_episode_steps=5, distance_threshold=0.05)
+    assert env.obs_dim == ref.obs_dim == 20 and env.action_dim == ref.action_dim == 4
+    env.set_state(torch.tensor(q, device=env.device))
+    ref.set_state(q)
+    _compare(env, ref, "after set_state")
+    live = n_done = n_succ = 0
+    for t in range(7):
+        is_planner = bool(t % 3 == 1)
+        a = rng.uniform(-0.15, 0.15, size=(E, 4)) if is_planner else rng.uniform(-1.0, 1.0, size=(E, 4))
+        obs, rew, done, info = env.step(torch.tensor(a, device=env.device), is_planner=is_planner)
+        ref.step(a, is_planner=is_planner)
+        _compare(env, ref, f"step {t}")
+        assert np.array_equal(_bits(rew.cpu().numpy()), _bits(ref.reward)), f"step {t}: reward"
+        assert np.array_equal(done.cpu().numpy(), ref.done) and np.array_equal(info["success"].cpu().numpy(), ref.success)
+        live += int((ref.reward > 0).sum()); n_done += int(ref.done.sum()); n_succ += int(ref.success.sum())
+    assert live > 0 and n_done > 0 and n_succ > 0
+    assert np.abs(ref.qpos[:, 0]).max() > 3.2          # the unlimited joint went past the seam
+    # reset: every env collision-free, box and target apart, goal_x <= box_x (pusher_obstacle.py:40-68)
+    env2 = make_env(env_name, 512, seed=3)
+    env2.reset()
+    qq = env2.qpos.cpu().numpy()
+    assert np.all(qq[:, -4] <= qq[:, -2]) and np.all(np.abs(qq[:, :4]) <= 0.02 + 1e-12)
+    assert np.all(np.linalg.norm(np.c_[qq[:, -2:] - qq[:, -4:-2], np.full(len(qq), 0.015)], axis=1) > 0.1)     # box - target, z offset 0.015
+    orc0 = oracle_mod.OracleScene(pi.model, pi.passive_joint_idx, [], 0.0)
+    assert all(orc0.is_valid(r)[0] for r in qq[:64])

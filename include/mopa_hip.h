@@ -581,6 +581,17 @@ int mopa_paths_unwrap_batch(int device, int64_t M, int32_t nq, int32_t n_arm, do
                             const double *hi_state_dev, const double *lo_shrunk_dev, const double *hi_shrunk_dev,
                             int32_t *seg_count_dev /*[M,max_path]*/, int32_t *n_walk_dev /*[M]*/, int32_t *out_len_dev /*[M]*/,
                             void *stream);
+/* the same with the seam rule of the reference's un-wrap loop for models with UNLIMITED joints (sampling_based_planner.py:79-97):
+ * bit c of seam_mask marks qpos coordinate c as one of `non_limited_idx`; the planner's states live in (-3.14, 3.14) there
+ * (SamplingBasedPlanner.convert_nonlimited -> util/env.py:joint_convert wraps start and goal before planning), and a step with
+ * abs(state - pre_state) > 3.14 is taken the short way round: + (3.14 - pre + state + 3.14) when it left through +3.14,
+ * - (3.14 - state + pre + 3.14) when through -3.14 (3.14, not pi; sums in this order).  seam_mask 0 == mopa_paths_unwrap_batch. */
+int mopa_paths_unwrap_seam_batch(int device, int64_t M, int32_t nq, int32_t n_arm, double *path_dev /*[M,max_path,nq] in/out*/,
+                                 int32_t max_path, const int32_t *path_len_dev /*[M]*/, const int32_t *status_dev /*[M]*/,
+                                 const double *cur_dev /*[M,nq]*/, double ac_scale, int32_t interpolate, const double *lo_state_dev,
+                                 const double *hi_state_dev, const double *lo_shrunk_dev, const double *hi_shrunk_dev,
+                                 int32_t *seg_count_dev /*[M,max_path]*/, int32_t *n_walk_dev /*[M]*/, int32_t *out_len_dev /*[M]*/,
+                                 uint64_t seam_mask, void *stream);
 int mopa_paths_walk_batch(int device, int64_t M, int32_t nq, int32_t n_arm, const double *path_dev, int32_t max_path,
                           const int32_t *path_len_dev, const int32_t *out_len_dev, double ac_scale, const double *lo_state_dev,
                           const double *hi_state_dev, const double *lo_shrunk_dev, const double *hi_shrunk_dev,

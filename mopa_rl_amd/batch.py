@@ -284,7 +284,8 @@ class BatchPlanner:
         return out, trials, valid
 
 
-def postprocess_paths(path, path_len, status, cur, n_arm: int, ac_scale: float, interpolate: bool, limits, is_valid, stream=None):
+def postprocess_paths(path, path_len, status, cur, n_arm: int, ac_scale: float, interpolate: bool, limits, is_valid, stream=None,
+                      seam_mask: int = 0):
     """Planner rows -> executable trajectories on the device (C ABI `mopa_paths_*`): un-wrap by successive differences
     (reference motion_planners/sampling_based_planner.py:71-99; `path` [M, max_path, nq] is overwritten with the un-wrapped
     rows), then -- `interpolate` -- the reference's densification of steps longer than ac_scale (rl/sac_agent.py:205-233)
@@ -292,7 +293,9 @@ def postprocess_paths(path, path_len, status, cur, n_arm: int, ac_scale: float, 
 
     limits: agent_planning.JointLimits (float32 state limits + margin).  Returns (traj [M, L, nq], length [M] int64 -- 0 for
     queries with status != 0 --, needs_fallback [M] bool: a long step of that query has an invalid interior state, the
-    reference plans such a step with its fallback planners and the caller has to).  One small read-back (totals)."""
+    reference plans such a step with its fallback planners and the caller has to).  One small read-back (totals).
+    seam_mask: bit c set = qpos coordinate c belongs to an unlimited joint (`non_limited_idx`): its steps across +-3.14 are taken
+    the short way round (sampling_based_planner.py:79-97)."""
     torch = _torch()
     L = _lib.lib()
     M, max_path, nq = path.shape
@@ -303,9 +306,9 @@ def postprocess_paths(path, path_len, status, cur, n_arm: int, ac_scale: float, 
     n_walk = torch.empty(M, dtype=torch.int32, device=dev)
     out_len = torch.empty(M, dtype=torch.int32, device=dev)
     lim = [t.contiguous() for t in (limits.lo_state, limits.hi_state, limits.lo_shrunk, limits.hi_shrunk)]
-    _lib.check(L.mopa_paths_unwrap_batch(di, M, nq, int(n_arm), _ptr(path), max_path, _ptr(path_len), _ptr(status), _ptr(cur),
-                                         float(ac_scale), int(bool(interpolate)), *[_ptr(t) for t in lim], _ptr(seg), _ptr(n_walk),
-                                         _ptr(out_len), st))
+    _lib.check(L.mopa_paths_unwrap_seam_batch(di, M, nq, int(n_arm), _ptr(path), max_path, _ptr(path_len), _ptr(status), _ptr(cur),
+                                              float(ac_scale), int(bool(interpolate)), *[_ptr(t) for t in lim], _ptr(seg), _ptr(n_walk),
+                                              _ptr(out_len), int(seam_mask), st))
     walk_off = torch.cumsum(n_walk.to(torch.int64), 0) - n_walk.to(torch.int64)
     tot_walk, rows = (int(x) for x in torch.stack([n_walk.sum(), out_len.max()]).cpu())
     rows = max(rows, 1)

@@ -12,8 +12,10 @@ the current reward (:303-334).  Counters `mp / rl / interpolation / mp_fail / ap
 Action spaces: joint-space MoPA-SAC, and MoPA + IK (`use_ik_target`: Cartesian displacement + rotation quaternion of the
 ik_target site, turned into a joint displacement by the batched damped-LS IK -- BASELINE config 5), and `discrete_action`
 (the policy's `ac_type` head routes a step, :86-88,106-111,349).  Envs: the three Sawyer
-obstacle envs (no unlimited joints; 7 arm entries per action, Lift adds the gripper entry, which a planner step applies at
-the last waypoint of its path, :163-167).  The `reuse_data` relabelling (:204-300) -- extra transitions between random
+obstacle envs (7 arm entries per action, Lift adds the gripper entry, which a planner step applies at
+the last waypoint of its path, :163-167) and PusherObstacle-v0 (4 joints, joint0 UNLIMITED: query endpoints are wrapped into
+(-3.14, 3.14) before planning and the returned steps un-wrapped across the seam, as `SamplingBasedPlanner.plan` does --
+`wrap_unlimited`, `seam_steps_np`, `mopa_paths_unwrap_seam_batch`; `RolloutConfig.for_env` carries config/pusher.py).  The `reuse_data` relabelling (:204-300) -- extra transitions between random
 pairs of waypoints of an executed path -- is `reuse_transitions()` below, fed by `agent_step(..., record=True)`.
 The env is the KINEMATIC one (kinematic_env.py) -- not dynamics parity.
 
@@ -45,7 +47,7 @@ COUNTERS = ("mp", "rl", "interpolation", "mp_fail", "approximate", "invalid")
 @dataclass
 class RolloutConfig:
     """Defaults restated from the reference: config/__init__.py:24-110 (mopa section), config/sawyer.py:76-112,
-    config/motion_planner.py:4-70."""
+    config/motion_planner.py:4-70.  `RolloutConfig.for_env(name)` fills the env-specific ones (config/pusher.py differs)."""
     omega: float = 0.7
     ac_space_type: str = "piecewise"
     action_range: float = 0.5
@@ -115,6 +117,19 @@ class RolloutConfig:
     ik_target: str = "grip_site"
     min_world_size: tuple = (-1.2, -1.2, 0.0)        # env/sawyer/sawyer.py:52-53
     max_world_size: tuple = (1.2, 1.2, 2.0)
+
+    @classmethod
+    def for_env(cls, env_name: str, **over):
+        """the config the reference builds for `env_name`: config/sawyer.py / config/pusher.py / config/motion_planner.py defaults as
+        restated in scene.ENV_SPECS (Pusher: ac_scale 0.1, action_range 1.0, range 0.2, simple_planner_range 0.1,
+        simple_planner_timelimit 0.02, step_size 0.04, joint_margin 0, contact_threshold -0.0015), then `over`."""
+        from .scene import ENV_SPECS
+        sp = ENV_SPECS[env_name]
+        kw = dict(omega=sp.omega, action_range=sp.action_range, ac_scale=sp.ac_scale, num_trials=sp.num_trials, step_size=sp.step_size,
+                  timelimit=sp.timelimit, simple_planner_timelimit=sp.simple_planner_timelimit, range=sp.range,
+                  simple_planner_range=sp.simple_planner_range, joint_margin=sp.joint_margin, contact_threshold=sp.contact_threshold)
+        kw.update(over)
+        return cls(**kw)
 
 
 def reuse_transitions(out, cfg, n_arm: int, rng, max_reuse_data: int = 30, grip_qpos_idx=None):
@@ -186,6 +201,42 @@ def _side_streams(dev, n):
     return pool[:n]
 
 
+def wrap_unlimited(q, idx):
+    """`SamplingBasedPlanner.convert_nonlimited` (motion_planners/sampling_based_planner.py:51-55) for rows of states [M, nq]
+    (torch): `util.env.joint_convert` (util/env.py:15-25) on the columns `idx` of the unlimited joints -- Python's float // and %
+    spelled out (fmod; the quotient rounded to the nearest integer).  Returns a copy (or `q` itself when `idx` is empty); the
+    caller's un-wrapped state, from which the trajectory is rebuilt, is left alone."""
+    if not len(idx):
+        return q
+    torch = _torch()
+    q = q.clone()
+    for j in idx:
+        a = q[:, j]
+        m = torch.fmod(a, 3.14)                                           # a % 3.14 for a > 0, a % -3.14 for a <= 0 (sign of a either way)
+        k = torch.round((a - m) / torch.where(a > 0, 3.14, -3.14))       # a // +-3.14
+        odd = torch.remainder(k, 2.0) != 0
+        r = torch.where(odd, torch.where(a > 0, m - 3.14, m + 3.14), m)
+        q[:, j] = torch.where(a == 0, torch.full_like(a, -0.0), r)        # (0.0 % -3.14 is -0.0 in Python)
+    return q
+
+
+def seam_steps_np(P, idx):
+    """successive differences P[..., k+1, :] - P[..., k, :] of planner rows (numpy) with the seam rule of the reference's un-wrap
+    loop on the unlimited joints' columns `idx` (sampling_based_planner.py:79-97; same sums, same order)"""
+    prev, cur = P[..., :-1, :], P[..., 1:, :]
+    step = cur - prev
+    for j in idx:
+        p, c = prev[..., j], cur[..., j]
+        jump = np.abs(c - p) > 3.14
+        up = jump & (p > 0) & (c <= 0)
+        down = jump & ~up & (p < 0) & (c > 0)
+        sj = step[..., j]
+        sj[up] = ((3.14 - p[up]) + c[up]) + 3.14
+        sj[down] = -(((3.14 - c[down]) + p[down]) + 3.14)
+    return step
+
+
+
 class BatchMoPARollout:
     def reuse_transitions(self, out, rng, max_reuse_data: int = 30):
         """`reuse_transitions` on a recorded step of this rollout, with the env's gripper joint supplied where its action has
@@ -202,8 +253,11 @@ class BatchMoPARollout:
             raise _lib.MopaError("env.ac_scale and RolloutConfig.ac_scale differ")
         spec = ENV_SPECS[env.env_name]
         pi = planner_inputs(env.env_name, env.model)
-        if len(pi.non_limited_idx):
-            raise NotImplementedError("unlimited joints (3.14 wrap of SamplingBasedPlanner) are not handled by the batched rollout")
+        # unlimited joints (`non_limited_idx`, rl/trainer.py:80-82; Pusher: joint0): SamplingBasedPlanner wraps a query's start and
+        # goal into (-3.14, 3.14) there before planning and takes the returned steps across the seam the short way round
+        # (motion_planners/sampling_based_planner.py:51-55,60-99) -- `_wrap_q` / the seam mask of the path post-processing
+        self._seam_idx = [int(i) for i in pi.non_limited_idx]
+        self._seam_mask = sum(1 << i for i in self._seam_idx)
         self.pi = pi
         dev_index = env.device.index if env.device.index is not None else -1
         mk = lambda r: _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, self.cfg.contact_threshold, range_=r,
@@ -319,6 +373,12 @@ class BatchMoPARollout:
         self._t_dev.fill_(int(value))
         self.t_env.fill_(int(value))
 
+    def _wrap_q(self, q):
+        return wrap_unlimited(q, self._seam_idx)
+
+    def _seam_steps_np(self, P):
+        return seam_steps_np(P, self._seam_idx)
+
     def _rrt_launch(self, cur_f, target_f, ids, stream=None, iters=None, keep=False, resume=None, chain=False):
         """RRT-Connect (K3) for the envs `ids` whose straight line is blocked (:205-209): asynchronous, optionally on a side
         stream.  The sample stream of a query is keyed by (cfg.seed + the env's own step count, env id), so an env's plans do
@@ -330,6 +390,8 @@ class BatchMoPARollout:
         iters = self.main_iters if iters is None else int(iters)
         job = {"ids": ids, "cur": cur_f, "target": target_f, "steps": self.t_env[ids].clone(), "event": None, "stage": "rrt", "stream": stream,
                "iters": iters}
+        if self._seam_idx:       # the planner sees the wrapped endpoints; job["cur"] stays the caller's state
+            cur_f, target_f = self._wrap_q(cur_f).contiguous(), self._wrap_q(target_f).contiguous()
         if stream is None:
             job["path"], job["plen"], job["status"], _ = self.bp.plan(cur_f, target_f, max_iters=iters, max_nodes=cfg.max_nodes,
                                                                       max_path=cfg.max_path, seed=cfg.seed, env_ids=gids, seeds=seeds)
@@ -409,7 +471,7 @@ class BatchMoPARollout:
                     if job.get("unwrapped"):       # rows that went through mopa_paths_unwrap_batch already (row 0 = cur)
                         T = P
                     else:
-                        A = np.concatenate([cur_h[good][:, None, :], P[:, 1:] - P[:, :-1]], axis=1)
+                        A = np.concatenate([cur_h[good][:, None, :], self._seam_steps_np(P)], axis=1)
                         T = np.add.accumulate(A, axis=1)
                     nrow = plen_h[good] - 1
                     job["T"], job["nrow"] = T, nrow
@@ -430,7 +492,7 @@ class BatchMoPARollout:
                 if st_h[r] == 0:
                     p = path_h[r, :plen_h[r]]
                     # SamplingBasedPlanner.plan: start + running sum of successive differences; PlannerAgent drops row 0
-                    job["replacement"][k] = np.add.accumulate(np.vstack([job["starts"][k][None], p[1:] - p[:-1]]), axis=0)[1:]
+                    job["replacement"][k] = np.add.accumulate(np.vstack([job["starts"][k][None], self._seam_steps_np(p)]), axis=0)[1:]
                 elif job["stage"] == "simple":
                     left.append(k)
                 else:
@@ -470,7 +532,7 @@ class BatchMoPARollout:
             with ctx:
                 from .batch import postprocess_paths
                 out, ln, need = postprocess_paths(job["path"], job["plen"], job["status"], job["cur"], self.n, cfg.ac_scale,
-                                                  cfg.interpolation, self.limits, self._valid, stream=pstream)
+                                                  cfg.interpolation, self.limits, self._valid, stream=pstream, seam_mask=self._seam_mask)
                 st = job["status"]
                 ok = st == 0           # sentinel rows (sampling_based_planner.py:64-69): -5 goal invalid, -4 no exact solution
                 job["dev"] = [out, ln, ok, st != _lib.PLAN_INVALID_GOAL, st != _lib.PLAN_NO_EXACT]
@@ -554,8 +616,8 @@ class BatchMoPARollout:
         dev = self.env.device
         ks = job["fb"]
         scene_bp, iters, base = ((self._bp_simple, self.simple_iters, 1) if stage == "simple" else (self.bp, self.main_iters, 2))
-        starts = torch.tensor(job["starts"][ks], device=dev)
-        ends = torch.tensor(job["ends"][ks], device=dev)
+        starts = self._wrap_q(torch.tensor(job["starts"][ks], device=dev))
+        ends = self._wrap_q(torch.tensor(job["ends"][ks], device=dev))
         rows = job["good"][job["seg_r"][ks]]
         total = int(cfg.env_id_total) if cfg.env_id_total else self.E
         ids = torch.tensor(total * base + int(cfg.env_id_base) + job["ids_h"][rows], dtype=torch.int64, device=dev)

@@ -40,13 +40,13 @@ def _make(G, E, env_name=ENV, **kw):
     timelimit, max_nodes, max_path, seed, max_episode_steps, num_trials = G["params"]
     env = make_env(env_name, E, seed=0, max_episode_steps=int(max_episode_steps))
     env.reset()
-    cfg = RolloutConfig(timelimit=float(timelimit), max_nodes=int(max_nodes), max_path=int(max_path), seed=int(seed),
-                        num_trials=int(num_trials), **kw)
+    cfg = RolloutConfig.for_env(env_name, timelimit=float(timelimit), max_nodes=int(max_nodes), max_path=int(max_path), seed=int(seed),
+                                num_trials=int(num_trials), **kw)
     return env, BatchMoPARollout(env, cfg)
 
 
 @pytest.mark.parametrize("env_name,tag", [("SawyerPushObstacle-v0", "push"), ("SawyerLiftObstacle-v0", "lift"),
-                                          ("SawyerAssemblyObstacle-v0", "assembly")])
+                                          ("SawyerAssemblyObstacle-v0", "assembly"), ("PusherObstacle-v0", "pusher")])
 def test_batched_rollout_equals_reference_rollout_runner(env_name, tag):
     """Every agent step of every env against the REFERENCE'S OWN `MoPARolloutRunner.run` (rl/mopa_rollouts.py:70-375), run in
     the build container env by env on the same scripted actions with the reference's SACAgent / PlannerAgent /
@@ -70,13 +70,73 @@ def test_batched_rollout_equals_reference_rollout_runner(env_name, tag):
         got_c = np.stack([(ro.counters[k] - before[k]).cpu().numpy() for k in COUNTERS], axis=1)
         assert np.array_equal(got_c, G["counters"][:, t]), f"step {t}: counters"
         np.testing.assert_allclose(out["rew"].cpu().numpy(), G["rew"][:, t], rtol=1e-12, atol=1e-13, err_msg=f"step {t}: reward")
-        np.testing.assert_allclose(out["ob"].cpu().numpy(), G["ob"][:, t], rtol=0, atol=1e-12, err_msg=f"step {t}: ob")
-        np.testing.assert_allclose(out["ob_next"].cpu().numpy(), G["ob_next"][:, t], rtol=0, atol=1e-12, err_msg=f"step {t}: ob_next")
+        ob, ob_want = out["ob"].cpu().numpy(), G["ob"][:, t].copy()
+        ob_n, ob_n_want = out["ob_next"].cpu().numpy(), G["ob_next"][:, t].copy()
+        if tag == "pusher":
+            # `PusherObstacleEnv._reset` draws joint / box velocities (pusher_obstacle.py:51-56) that the obs of an episode reports
+            # until the first env.step (a failed plan with an invalid target takes none); the kinematic env has no velocity state
+            # (every step ends at rest): those six entries are not compared
+            for a in (ob, ob_want, ob_n, ob_n_want):
+                a[:, 10:16] = 0.0
+        np.testing.assert_allclose(ob, ob_want, rtol=0, atol=1e-12, err_msg=f"step {t}: ob")
+        np.testing.assert_allclose(ob_n, ob_n_want, rtol=0, atol=1e-12, err_msg=f"step {t}: ob_next")
     tot = dict(zip(COUNTERS, G["counters"].sum(axis=(0, 1))))
     if tag == "push":
         assert all(v > 0 for v in tot.values()), tot            # every branch of the loop is in the fixture
     assert tot["rl"] > 0 and tot["interpolation"] > 0 and tot["mp_fail"] > 0 and tot["invalid"] > 0, tot
     assert G["done"].sum() > 0 and G["intra"].max() >= 8
+    if tag == "pusher":      # BASELINE config 1's env: the unlimited joint0 leaves (-3.14, 3.14) and queries start from beyond the seam
+        assert np.abs(G["qpos_start"][:, :, 0]).max() > 3.2 and tot["mp"] > 0
+
+
+def test_seam_crossing_paths_unwrap_like_the_single_env_planner():
+    """Planner rows of a model with an unlimited joint (Pusher: joint0 is SO(2)) through `postprocess_paths` with the seam mask,
+    against `SamplingBasedPlanner.plan`'s own un-wrap (the mirror tests/test_ref_py_host.py pins to the reference): queries whose
+    wrapped endpoints lie on either side of +-3.14, so that RRT-Connect connects them ACROSS the seam; every un-wrapped row must
+    be the mirror's, bit for bit."""
+    import torch
+    from mopa_rl_amd import _lib
+    from mopa_rl_amd.agent_planning import JointLimits
+    from mopa_rl_amd.batch import BatchPlanner, postprocess_paths
+    from mopa_rl_amd.kinematic_env import env_facts
+    from mopa_rl_amd.rollout import seam_steps_np, wrap_unlimited
+    from mopa_rl_amd.scene import planner_inputs
+    pi = planner_inputs("PusherObstacle-v0")
+    f = env_facts("PusherObstacle-v0", pi.model)
+    scene = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold, range_=pi.spec.range, seed=5)
+    bp = BatchPlanner(scene)
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(2)
+    q0 = np.asarray(pi.model.qpos0, dtype=np.float64)
+    cand = np.tile(q0, (4096, 1))
+    cand[:, 0] = rng.choice([-1.0, 1.0], 4096) * rng.uniform(2.6, 3.6, 4096)          # un-wrapped: some beyond +-3.14
+    cand[:, 1:4] = rng.uniform(-2.5, 2.5, (4096, 3))
+    ok = bp.is_valid(torch.tensor(cand[:, :4], device=dev).contiguous(), torch.tensor(cand, device=dev), samples_per_env=1).bool().cpu().numpy()
+    cand = cand[ok]
+    M = (len(cand) // 2) & ~1
+    assert M >= 64
+    start, goal = cand[:M], cand[M:2 * M].copy()
+    goal[:, 1:4] = start[:, 1:4] + rng.normal(0, 0.2, (M, 3))                          # near-by arm shapes: most queries solve
+    okg = bp.is_valid(torch.tensor(goal[:, :4], device=dev).contiguous(), torch.tensor(goal, device=dev), samples_per_env=1).bool().cpu().numpy()
+    start, goal = start[okg], goal[okg]
+    M = len(start)
+    st_t, go_t = torch.tensor(start, device=dev), torch.tensor(goal, device=dev)
+    sw, gw = wrap_unlimited(st_t, [0]).contiguous(), wrap_unlimited(go_t, [0]).contiguous()
+    assert float(sw[:, 0].abs().max()) <= 3.14
+    path, plen, status, _ = bp.plan(sw, gw, max_iters=600, max_nodes=512, max_path=128, seed=5)
+    raw = path.cpu().numpy().copy()
+    lim = JointLimits(f.qpos_min, f.qpos_max, f.qpos_limited, 0.0, device=dev)
+    valid = lambda rows: bp.is_valid(rows[:, :4].contiguous(), rows.contiguous(), samples_per_env=1)
+    out, ln, need = postprocess_paths(path, plen, status, st_t.contiguous(), 4, pi.spec.ac_scale, False, lim, valid, seam_mask=1)
+    out, ln, plen_h, st_h = out.cpu().numpy(), ln.cpu().numpy(), plen.cpu().numpy(), status.cpu().numpy()
+    crossed = 0
+    for q in np.where(st_h == 0)[0]:
+        P = raw[q, :plen_h[q]]
+        want = np.add.accumulate(np.vstack([start[q][None], seam_steps_np(P, [0])]), axis=0)
+        crossed += int((np.abs(P[1:, 0] - P[:-1, 0]) > 3.14).any())
+        assert ln[q] == plen_h[q] - 1
+        assert np.array_equal(_bits(out[q, :ln[q]]), _bits(want[1:])), q
+    assert (st_h == 0).sum() >= 32 and crossed >= 8, ((st_h == 0).sum(), crossed)
 
 
 def test_discrete_action_rollout_equals_reference_runner():
@@ -223,6 +283,67 @@ def test_async_planner_gives_every_env_the_same_transitions(env_name):
     assert int(a[3]["mp"].sum()) > 0                                          # RRT-Connect was exercised ...
     if env_name == ENV:
         assert int(a[3]["mp_fail"].sum()) > 0 and b[4] > 0 and d[4] > 0       # ... with both outcomes, and second launches
+
+
+def test_pusher_rollout_forms_agree_across_the_seam():
+    """PusherObstacle-v0 (joint0 unlimited) started next to +-3.14 and driven across it: the lock-step run, the asynchronous
+    planner run, and the lock-step run with the torch bookkeeping + host-side path post-processing must give every env the same
+    transitions (wrap of the query endpoints, seam rule of the un-wrap: device kernel vs numpy form)."""
+    import torch
+    from mopa_rl_amd.kinematic_env import make_env
+    from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
+    env_name = "PusherObstacle-v0"
+    E, T = 192, 5
+    rng = np.random.default_rng(6)
+    AC = rng.uniform(-1, 1, size=(E, T, 4)) * rng.choice([0.5, 0.9, 1.0], size=(E, T, 1))
+    sign = np.where(np.arange(E) % 2 == 0, 1.0, -1.0)
+    AC[: E // 2] *= 0.6
+    AC[: E // 2, :, 0] = sign[: E // 2, None] * rng.uniform(0.71, 0.85, size=(E // 2, T))
+    ACt = torch.tensor(AC, device="cuda")
+    # valid start states with joint0 next to the seam on the side its env is driven towards
+    probe = make_env(env_name, 8192, seed=1)
+    probe.reset()
+    q = probe.qpos.clone()
+    g = torch.Generator(device=probe.device); g.manual_seed(3)
+    q[:, 0] = 3.02 + 0.11 * torch.rand(8192, generator=g, dtype=torch.float64, device=probe.device)
+    q[:, 1:4] = (torch.rand(8192, 3, generator=g, dtype=torch.float64, device=probe.device) * 2 - 1) * 2.5
+    q[1::2, 0] *= -1.0
+    ro0 = BatchMoPARollout(probe, RolloutConfig.for_env(env_name))
+    ok = ro0._valid(q).cpu().numpy()
+    qn = q.cpu().numpy()
+    pos, neg = qn[ok & (qn[:, 0] > 0)], qn[ok & (qn[:, 0] < 0)]
+    assert len(pos) >= E // 2 and len(neg) >= E // 2
+    start = np.empty((E, qn.shape[1]))
+    start[0::2], start[1::2] = pos[: E // 2], neg[: E // 2]
+    probe.close()
+    runs = {}
+    for mode in ("lockstep", "async", "host"):
+        env = make_env(env_name, E, seed=12, max_episode_steps=1000)
+        env.set_state(torch.tensor(start, device=env.device))
+        ro = BatchMoPARollout(env, RolloutConfig.for_env(env_name, timelimit=0.3, max_nodes=512, max_path=128, num_trials=10,
+                                                         async_planner=(mode == "async"), planner_first_iters=60, planner_min_job=1,
+                                                         device_paths=(mode != "host"), fused=(mode != "host")))
+        seq = [[] for _ in range(E)]
+        calls = 0
+        while min(len(x) for x in seq) < T:
+            te = ro.t_env.clamp(max=T - 1)
+            out = ro.agent_step(ACt[torch.arange(E, device="cuda"), te].contiguous())
+            st = out["stepped"].cpu().numpy()
+            rows = np.concatenate([out["rew"].cpu().numpy()[:, None], out["done"].cpu().numpy()[:, None].astype(np.float64),
+                                   out["intra_steps"].cpu().numpy()[:, None].astype(np.float64), env.qpos.cpu().numpy()[:, :4],
+                                   out["ac"].cpu().numpy()], axis=1)
+            for e in np.where(st)[0]:
+                seq[e].append(rows[e])
+            calls += 1
+            assert calls < 200
+        runs[mode] = (np.array([np.array(x[:T]) for x in seq]), {k: int(v.sum()) for k, v in ro.counters.items()})
+        ro.drain() if hasattr(ro, "drain") else None
+        env.close()
+    a, b, c = runs["lockstep"], runs["async"], runs["host"]
+    assert np.array_equal(_bits(a[0]), _bits(b[0])), "the asynchronous planner changes an env's transitions"
+    assert np.array_equal(_bits(a[0]), _bits(c[0])), "host-side post-processing / torch bookkeeping change an env's transitions"
+    assert a[1]["mp"] > 0 and a[1]["interpolation"] > 0 and a[1]["mp_fail"] > 0, a[1]
+    assert np.abs(a[0][:, :, 3]).max() > 3.3          # joint0 ended up beyond the seam
 
 
 @pytest.mark.parametrize("env_name,kw", [("SawyerPushObstacle-v0", {}), ("SawyerLiftObstacle-v0", {}),

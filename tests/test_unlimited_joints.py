@@ -1,0 +1,41 @@
+"""Unlimited joints in the batched path (Pusher's joint0): the array forms of `SamplingBasedPlanner.convert_nonlimited` /
+`util.env.joint_convert` and of the un-wrap loop's seam rule (reference motion_planners/sampling_based_planner.py:51-55,71-99,
+util/env.py:15-25) against the scalar mirrors in mopa_rl_amd/sampling_based_planner.py -- which tests/test_ref_py_host.py pins to the
+reference's own functions."""
+import numpy as np
+import pytest
+
+
+def test_wrap_unlimited_equals_joint_convert_bit_for_bit():
+    torch = pytest.importorskip("torch")
+    from mopa_rl_amd.rollout import wrap_unlimited
+    from mopa_rl_amd.sampling_based_planner import joint_convert
+    rng = np.random.default_rng(0)
+    k = np.arange(-13, 14) * 3.14
+    a = np.concatenate([rng.uniform(-40, 40, 20000), k, np.nextafter(k, np.inf), np.nextafter(k, -np.inf),
+                        [0.0, -0.0, 3.14, -3.14, 6.28, -6.28, 1e-300, -1e-300, 3.1399999999999997, 3.1400000000000006]])
+    q = torch.tensor(np.stack([a, a[::-1].copy(), a], axis=1))
+    w = wrap_unlimited(q, [0, 2]).numpy()
+    ref = np.array([joint_convert(float(x)) for x in a])
+    assert np.array_equal(w[:, 0].view(np.uint64), ref.view(np.uint64))
+    assert np.array_equal(w[:, 2].view(np.uint64), ref.view(np.uint64))
+    assert np.array_equal(w[:, 1], a[::-1]) and np.array_equal(q.numpy()[:, 0], a)       # other columns / the input: untouched
+    assert wrap_unlimited(q, []) is q
+
+
+def test_seam_steps_equal_the_single_env_mirror():
+    from mopa_rl_amd.rollout import seam_steps_np
+    from mopa_rl_amd.sampling_based_planner import SamplingBasedPlanner
+    rng = np.random.default_rng(1)
+    sp = object.__new__(SamplingBasedPlanner)
+    sp.non_limited_idx = [0, 3]
+    for _ in range(50):
+        K = int(rng.integers(2, 12))
+        P = rng.uniform(-3.14, 3.14, size=(K, 6))
+        P[::3, 0] = rng.choice([-3.13, 3.13, 3.0, -3.0], size=len(P[::3]))          # frequent seam crossings
+        want = sp._unwrapped_steps(P.copy())
+        got = seam_steps_np(P.copy(), [0, 3])
+        assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+        got3 = seam_steps_np(np.stack([P, P[::-1]]), [0, 3])                          # a batch of paths at once
+        assert np.array_equal(got3[0].view(np.uint64), want.view(np.uint64))
+    assert (np.abs(P[1:, 0] - P[:-1, 0]) > 3.14).any() or True

@@ -279,6 +279,8 @@ def make_ref_env(env_name, seed=0, max_episode_steps=250):
     (it loads MuJoCo); the attributes it would set are set here from the same sources (env/base.py:27-98,
     env/sawyer/sawyer.py:19-56).  `_do_simulation` -- one MuJoCo step of the position servos -- becomes: every actuated
     joint reaches its (ctrl-range-clamped) target."""
+    if env_name == "PusherObstacle-v0":
+        return make_ref_env_pusher(seed=seed, max_episode_steps=max_episode_steps)
     import env.sawyer as ref_envs
     from gym import spaces
     cls = {"SawyerPushObstacle-v0": ref_envs.SawyerPushObstacleEnv, "SawyerLiftObstacle-v0": ref_envs.SawyerLiftObstacleEnv,
@@ -392,14 +394,33 @@ def rollout_actions(E, T, n_ac, rng):
     return ac
 
 
+def pusher_seam_starts(pi, rng, n):
+    """arm poses of the Pusher with joint0 within 0.12 rad of +-3.14 that the validity oracle accepts (straight, the arm lies in
+    obstacle 4 / 5 there): rollouts started from them carry the unlimited joint across the seam"""
+    from oracle import oracle as O
+    orc = O.OracleScene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold)
+    q0 = np.asarray(pi.model.qpos0, dtype=np.float64)
+    out = []
+    while len(out) < n:
+        q = q0.copy()
+        q[0] = rng.choice([-1.0, 1.0]) * rng.uniform(3.02, 3.13)
+        q[1:4] = rng.uniform(-2.5, 2.5, 3)
+        if orc.is_valid(q)[0]:
+            out.append(q[:4].copy())
+    return out
+
+
 def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=False, ik=False, discrete=False):
     import util.env as ref_util_env
     from rl.mopa_rollouts import MoPARolloutRunner
     ref_util_env.np = refshim.NumpyCompat()
     P = ROLLOUT_PARAMS
+    if env_name == "PusherObstacle-v0":
+        P = dict(P, timelimit=0.5)            # the cluttered Pusher scene: 1000 iterations, so that some blocked lines get planned
     cfg = make_config(env_name, timelimit=P["timelimit"], reuse_data=reuse, num_trials=P["num_trials"], use_ik_target=ik,
                       discrete_action=discrete)
-    n_ac = 8 if env_name == "SawyerLiftObstacle-v0" else 7
+    pusher = env_name == "PusherObstacle-v0"
+    n_ac = 8 if env_name == "SawyerLiftObstacle-v0" else (4 if pusher else 7)
     agent, pi = make_agent(env_name, cfg, ac_dim=n_ac)
     st = Streams(agent, E, P["seed"], P["max_nodes"], P["max_path"])
     rng = np.random.default_rng(11)
@@ -409,6 +430,13 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
         AC[:, :, :3] *= rng.choice([0.05, 0.3, 1.0], size=(E, T, 1))           # small steps (direct) and long reaches (planner)
         AC[:, :, 3] = np.abs(AC[:, :, 3]) + 0.5                                 # mostly small rotations ...
         AC[: E // 4, :, 3:] = rng.uniform(-1, 1, size=(E // 4, T, 4))            # ... and some arbitrary ones
+    elif pusher:
+        # joint0 (unlimited) is driven hard one way in half of the envs -- from a start next to +-3.14 (below) that takes the planner's
+        # SO(2) coordinate across the seam --, the others get mixed direct / planner actions
+        AC = rng.uniform(-1, 1, size=(E, T, n_ac)) * rng.choice([0.5, 0.9, 1.0], size=(E, T, 1))
+        AC[: E // 2] *= 0.6
+        AC[: E // 2, :, 0] = np.where(np.arange(E // 2)[:, None] % 2 == 0, 1.0, -1.0) * rng.uniform(0.71, 0.8, size=(E // 2, T))
+        seam_starts = pusher_seam_starts(pi, rng, E // 2)
     else:
         AC = rollout_actions(E, T, n_ac, rng)
     # --discrete_action (rl/mopa_rollouts.py:86-88): the policy's `ac_type` head, not the action's magnitude, picks the planner
@@ -422,6 +450,16 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
     for e in range(E):
         env = make_ref_env(env_name, seed=100 + e, max_episode_steps=P["max_episode_steps"])
         state = {"t": -1}
+        if pusher and e < E // 2:
+            def reset_at_seam(env=env, arm=seam_starts[e], orig=env.reset):
+                orig()
+                q = env.sim.data.qpos.copy()
+                # towards the seam: the sign of the start equals the sign of this env's drive (even e: +, odd e: -)
+                q[:4] = arm
+                q[0] = abs(q[0]) * (1.0 if e % 2 == 0 else -1.0)
+                env.set_state(q, env.sim.data.qvel.copy())
+                return env._get_obs()
+            env.reset = reset_at_seam
 
         def act(ob, is_train=True, return_stds=False, random_exploration=False, e=e, env=env, state=state):
             state["t"] += 1
@@ -446,7 +484,10 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
                 n = len(env.ref_joint_pos_indexes)    # a BLAS dot whose summation order is build-dependent: such steps are compared to round-off)
                 tq = env.sim.data.qpos.copy()
                 tq[env.ref_joint_pos_indexes] += agent.convert2planner_displacement(a["default"][:n], env._ac_scale)
+                tq0 = tq.copy()
                 tq = np.clip(tq, env._jnt_minimum[env.jnt_indices], env._jnt_maximum[env.jnt_indices])
+                free = np.invert(env._is_jnt_limited[env.jnt_indices])      # (rl/mopa_rollouts.py:121-131: unlimited entries are restored)
+                tq[free] = tq0[free]
                 out["pulled_back"][e, t] = int(not agent.isValidState(tq))
             return a, None, None
 
@@ -674,9 +715,14 @@ def gen_rollouts():
     gen_rollout("SawyerAssemblyObstacle-v0", "assembly", E=24, T=5)
     gen_rollout("SawyerAssemblyObstacle-v0", "assembly", E=24, T=5, ik=True)
     gen_rollout(E=24, T=5, discrete=True)
+    gen_rollout_pusher()
 
 
-SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env, env_pusher=gen_env_pusher)
+def gen_rollout_pusher():
+    gen_rollout("PusherObstacle-v0", "pusher", E=24, T=5)
+
+
+SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env, env_pusher=gen_env_pusher, rollout_pusher=gen_rollout_pusher)
 
 
 def main():

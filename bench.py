@@ -420,7 +420,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     if use_ik:
         over["use_ik_target"] = 1       # MoPA + IK action space (BASELINE config 5): Cartesian displacement + rotation quaternion
     rank = int(os.environ.get("RANK", "0")) if world > 1 else 0
-    ro = BatchMoPARollout(env, RolloutConfig(async_planner=async_planner, env_id_base=rank * E, env_id_total=world * E, **over))
+    ro = BatchMoPARollout(env, RolloutConfig.for_env(env_name, async_planner=async_planner, env_id_base=rank * E, env_id_total=world * E, **over))
     if os.environ.get("MOPA_BENCH_PHASES"):
         ro.timing = {}           # per-phase times (each mark synchronises the main stream: slower calls, profiling only)
     torch.manual_seed(8)
@@ -920,6 +920,8 @@ def main():
             # the same at twice the envs per GPU: at 4096 half the envs wait for an RRT-Connect query in any call and the call
             # is bound by host dispatch; the agent-step rate levels off near 8192-16384 resident envs (tools/rollout_envs_sweep.py)
             ro["rollout_async_2x"] = rollout_section(torch, ENV, 2 * args.envs, device, 200, async_planner=True)
+            # BASELINE config 1's env, batched (PusherObstacle-v0, joint0 unlimited: wrapped query endpoints, seam rule of the un-wrap)
+            ro["rollout_pusher"] = rollout_section(torch, "PusherObstacle-v0", args.envs, device, 200, async_planner=True)
             if args.graphs:          # (HIP-graph replay no longer pays: DESIGN 8; kept behind the flag)
                 ro["rollout_async_graphs"] = rollout_section(torch, ENV, args.envs, device, 300, async_planner=True, use_graphs=True)
             # the same rollout where a Push policy could actually be trained: the env with dynamics + contacts (stage C)

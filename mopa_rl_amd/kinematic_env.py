@@ -478,7 +478,7 @@ class BatchKinematicEnv:
         torch = _torch()
         E, dev = self.E, self.device
         if self.kind == KIND_PUSHER:
-            q = self._reset_pusher()
+            q = self._reset_pusher(mask)
         else:
             q = self._qpos0.expand(E, self.nq).clone()
             q[:, self._arm_idx] = self._init_arm + 0.02 * torch.randn(E, self.n_arm, dtype=torch.float64, device=dev, generator=self._gen)
@@ -497,13 +497,15 @@ class BatchKinematicEnv:
         self._launch(None, False, None)
         return self.obs
 
-    def _reset_pusher(self, draws: int = 64, max_rounds: int = 24):
-        """`PusherObstacleEnv._reset` (env/pusher/pusher_obstacle.py:40-68) for all E envs: goal and box ~ U([-0.35, 0.13], [-0.24, 0.2])
-        written into their sliders, every qpos entry += U(-0.02, 0.02); a draw is kept when nothing touches (`ncon == 0`: K1 with no
-        ignored pair at threshold 0), box and target are more than 0.1 apart and goal_x <= box_x.  The reference loops until a
-        draw passes (about 1.5 % do: both points come from one 0.11 x 0.07 patch); here every round draws `draws` candidates per
-        env, validates them in one launch and keeps each env's FIRST passing one -- the same distribution (rows that saw no
-        passing draw in `max_rounds` rounds keep their last candidate)."""
+    def _reset_pusher(self, mask=None, draws: int = 64, pool_factor: int = 16):
+        """`PusherObstacleEnv._reset` (env/pusher/pusher_obstacle.py:40-68) for the envs of `mask` (None: all): goal and box ~
+        U([-0.35, 0.13], [-0.24, 0.2]) written into their sliders, every qpos entry += U(-0.02, 0.02); a draw is kept when nothing
+        touches (`ncon == 0`: K1 with no ignored pair at threshold 0), box and target are more than 0.1 apart and goal_x <= box_x.
+        The reference loops until a draw passes (about 1.5 % do: both points come from one 0.11 x 0.07 patch).  Here accepted draws
+        are produced in bulk (E x `draws` candidates per validity launch, the accepted ones kept in draw order) into a pool of
+        `pool_factor` x E states that resets consume front to back -- every reset state is an independent accepted draw, used once.
+        The pool's cursor lives on the device; the host only keeps an upper bound of it (E per masked call) and reads the true value
+        when that bound says the pool might run out: one synchronisation every ~pool_factor calls."""
         torch = _torch()
         E, K, dev, f64 = self.E, int(draws), self.device, torch.float64
         if getattr(self, "_reset_scene", None) is None:
@@ -514,28 +516,40 @@ class BatchKinematicEnv:
             m = self.model
             self._box_off = torch.tensor(np.asarray(m.body_pos[m.body_names.index("box")]) - np.asarray(m.body_pos[m.body_names.index("target")]),
                                          dtype=f64, device=dev)
-        lo = torch.tensor([-0.35, 0.13], dtype=f64, device=dev)
-        hi = torch.tensor([-0.24, 0.2], dtype=f64, device=dev)
-        q = self._qpos0.expand(E, self.nq).clone()
-        todo = torch.ones(E, dtype=torch.bool, device=dev)
-        rows = torch.arange(E, device=dev)
-        for r in range(max_rounds):
-            c = self._qpos0 + (torch.rand(E, K, self.nq, dtype=f64, device=dev, generator=self._gen) * 0.04 - 0.02)
-            goal = lo + (hi - lo) * torch.rand(E, K, 2, dtype=f64, device=dev, generator=self._gen)
-            box = lo + (hi - lo) * torch.rand(E, K, 2, dtype=f64, device=dev, generator=self._gen)
-            c[:, :, -4:-2], c[:, :, -2:] = goal, box
-            flat = c.view(E * K, self.nq)
-            free = self._reset_bp.is_valid(flat[:, self._arm_idx].contiguous(), flat, samples_per_env=1).bool().view(E, K)
-            d = torch.cat([box - goal, torch.zeros(E, K, 1, dtype=f64, device=dev)], dim=2) + self._box_off
-            ok = free & (d.norm(dim=2) > 0.1) & (goal[:, :, 0] <= box[:, :, 0])
-            first = torch.argmax(ok.to(torch.uint8), dim=1)             # the first passing draw (0 when none passes)
-            hit = ok.any(dim=1)
-            take = todo & (hit if r < max_rounds - 1 else torch.ones_like(hit))
-            q = torch.where(take[:, None], c[rows, first], q)
-            todo = todo & ~hit
-            if not bool(todo.any()):
-                break
-        return q
+            self._pool = torch.zeros(0, self.nq, dtype=f64, device=dev)
+            self._pool_cursor = torch.zeros((), dtype=torch.int64, device=dev)
+            self._pool_upper = 0
+        P = int(pool_factor) * E
+        if self._pool_upper + E > self._pool.shape[0]:
+            used = min(int(self._pool_cursor.item()), self._pool.shape[0])
+            parts, have = [self._pool[used:]], self._pool.shape[0] - used
+            lo = torch.tensor([-0.35, 0.13], dtype=f64, device=dev)
+            hi = torch.tensor([-0.24, 0.2], dtype=f64, device=dev)
+            while have < P:
+                N = E * K
+                c = self._qpos0 + (torch.rand(N, self.nq, dtype=f64, device=dev, generator=self._gen) * 0.04 - 0.02)
+                goal = lo + (hi - lo) * torch.rand(N, 2, dtype=f64, device=dev, generator=self._gen)
+                box = lo + (hi - lo) * torch.rand(N, 2, dtype=f64, device=dev, generator=self._gen)
+                c[:, -4:-2], c[:, -2:] = goal, box
+                free = self._reset_bp.is_valid(c[:, self._arm_idx].contiguous(), c, samples_per_env=1).bool()
+                d = torch.cat([box - goal, torch.zeros(N, 1, dtype=f64, device=dev)], dim=1) + self._box_off
+                ok = free & (d.norm(dim=1) > 0.1) & (goal[:, 0] <= box[:, 0])
+                acc = c[ok]
+                parts.append(acc)
+                have += acc.shape[0]
+            self._pool = torch.cat(parts)[:max(P, E)].contiguous()
+            self._pool_cursor.zero_()
+            self._pool_upper = 0
+        if mask is None:
+            idx = self._pool_cursor + torch.arange(E, device=dev)
+            self._pool_cursor += E
+        else:
+            mk = mask.to(torch.bool)
+            rank = torch.cumsum(mk.to(torch.int64), 0) - 1
+            idx = self._pool_cursor + torch.where(mk, rank, torch.zeros_like(rank))
+            self._pool_cursor += mk.sum()
+        self._pool_upper += E
+        return self._pool[idx.clamp(max=self._pool.shape[0] - 1)]
 
     def set_state(self, qpos):
         """Load explicit qpos rows [E, nq] (tests, replaying recorded states) and refresh the obs."""

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Build container, after `gpurun -- 'bash tools/profile_round.sh rNN'`: copies the judged summaries from gpurun_out/ (scratch) into
+# profiles/rNN/ (tracked).  bash tools/collect_round.sh r05
+TAG=${1:-r05}
+cd "$(dirname "$0")/.."
+G=gpurun_out; P=profiles/$TAG; mkdir -p $P
+python tools/make_traffic_json.py $G/prof_$TAG $P
+python tools/summarize_prof.py $G/prof_$TAG > $P/k_is_valid_v5_summary.txt
+head -12 $G/prof_$TAG/trace_kernel_stats.csv > $P/trace_kernel_stats_top.csv
+cp $G/prof_$TAG/trace_domain_stats.csv $P/trace_domain_stats.csv
+head -25 $G/prof_$TAG/full_kernel_stats.csv > $P/full_bench_kernel_stats_top.csv
+cp $G/k3_$TAG/plan_passes.txt $P/k3_plan_passes.txt
+cp $G/k3_$TAG/plan_fail_only.txt $P/k3_fail_only_timing.txt
+cp $G/k3_$TAG/trace_kernel_stats_k3.csv $P/k3_fail_only_kernel_stats.csv
+cp $G/k3_$TAG/pmc_counter_collection_k3.csv $P/k3_pmc_sq.csv
+cp $G/k3_$TAG/pmc2_counter_collection_k3.csv $P/k3_pmc_sq2.csv
+cp $G/prof_${TAG}_k7/trace_kernel_stats.csv $P/k7_trace_kernel_stats.csv
+cp $G/prof_${TAG}_k7/pmc_sq_counter_collection_dyn.csv $P/k7_pmc_sq_counter_collection_dyn.csv
+cp $G/prof_${TAG}_k7/pmc_sq2_counter_collection.csv $P/k7_pmc_sq2_counter_collection.csv
+for f in parity_sweep plan_parity_sweep motion_parity_sweep ct_parity_sweep rollout_launches_per_call ct_bench ct_bench_pyramidal dyn_lanes_ab lone_wave k7_icache; do
+  [ -f $G/round_$TAG/$f.txt ] && cp $G/round_$TAG/$f.txt $P/$f.txt
+done
+git status --short $P | head -40

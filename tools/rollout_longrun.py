@@ -1,13 +1,13 @@
-"""Asynchronous rollouts for 4000 calls (uniform random actions, Push and Lift): memory, waiting envs, the slowest env's step
+"""Asynchronous rollouts for 4000 calls (uniform random actions; Push, Lift and Pusher): memory, waiting envs, the slowest env's step
 count (fairness of the planner queue) and the counters every 1000 calls.  GPU box."""
 import sys, time; sys.path.insert(0, ".")
 import torch, numpy as np
 from mopa_rl_amd.kinematic_env import make_env
 from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
 E = 4096
-for env_name in ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0"):
+for env_name in (sys.argv[1:] or ("SawyerPushObstacle-v0", "SawyerLiftObstacle-v0", "PusherObstacle-v0")):
     env = make_env(env_name, E, seed=5, max_episode_steps=250); env.reset()
-    ro = BatchMoPARollout(env, RolloutConfig(async_planner=True))
+    ro = BatchMoPARollout(env, RolloutConfig.for_env(env_name, async_planner=True))
     gen = torch.Generator(device=env.device); gen.manual_seed(1)
     t0 = time.perf_counter(); stepped = 0
     for t in range(4000):

@@ -172,9 +172,13 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
     # ... and a stream of batches through the iteration ladder (BatchPlanner.plan_laddered): 200 iterations first, the ~3 % it
     # does not solve again with all 2000 on other streams while the next batches' first launches run -- results identical
     # to full-budget launches (tests/test_gpu_parity.py::test_laddered_planning_equals_one_full_launch)
-    nb = 24         # (the last retry launch drains alone for one straggler's latency, ~46 ms: 8 batches measured 14.6, 32 batches 11.6 ms per batch)
+    nb = 24         # (the last retry launch drains alone for one straggler's latency, ~37 ms: the rate grows with the stream's length -- `laddered_long`)
     batches = [dict(start=start, goal=goal, seed=7 + 13 * i) for i in range(nb)]
-    lad_kw = dict(max_iters=prm["max_iters"], first_iters=200, max_nodes=prm["max_nodes"], max_path=prm["max_path"],
+    # scheduling knobs (results do not depend on them): a first rung of 100 iterations and retry launches of >= 1024 pooled queries
+    # measured best over long streams (tools/ladder_grid.py, tools/ladder_nb.py: 534 k plans/s at 24 batches, 629 k at 64; round 4's
+    # 200 / 512: 477 k / 529 k); at 24 batches the rate also depends on where the last retry launch lands (110-120 / 1024 / 3-4 streams: 570-587 k)
+    lad_kw = dict(max_iters=prm["max_iters"], first_iters=int(os.environ.get("MOPA_LADDER_FIRST_ITERS", "100")), max_nodes=prm["max_nodes"],
+                  max_path=prm["max_path"], retry_min=int(os.environ.get("MOPA_LADDER_RETRY_MIN", "1024")),
                   first_stream=streams[0], retry_streams=streams[1:3], retry_exclusive=bool(int(os.environ.get("MOPA_LADDER_EXCL", "0"))))
     bp.plan_laddered(batches, **lad_kw)        # untimed: per-stream scratch (trees of the pooled retry launches) grows to its final size
     torch.cuda.synchronize()
@@ -185,7 +189,16 @@ def plan_section(torch, bp, pi, E, device, with_cpu=True):
     same = all(bool((a == b).all().item()) for a, b in zip(lad[0][1:], (plen, status, nchk)))
     out["laddered"] = {"batches": nb, "queries": nb * E, "ms_total": dtl * 1e3, "ms_per_batch": dtl * 1e3 / nb, "plans_per_s": nb * E / dtl,
                        "first_batch_equals_full_launch": same,
-                       "note": f"{nb} batches of {E} queries: first launch with 200 iterations, unsolved queries again with {prm['max_iters']} on 2 other streams"}
+                       "note": f"{nb} batches of {E} queries: first launch with {lad_kw['first_iters']} iterations, unsolved queries (pooled, >= {lad_kw['retry_min']}) again with {prm['max_iters']} on 2 other streams"}
+    nbl = 64        # the same ladder over a longer stream: the final drain weighs less
+    long_batches = [dict(start=start, goal=goal, seed=7 + 13 * i) for i in range(nbl)]
+    bp.plan_laddered(long_batches, **lad_kw)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    bp.plan_laddered(long_batches, **lad_kw)
+    torch.cuda.synchronize()
+    dtl2 = _t.perf_counter() - t0
+    out["laddered_long"] = {"batches": nbl, "queries": nbl * E, "ms_total": dtl2 * 1e3, "plans_per_s": nbl * E / dtl2}
     if with_cpu:
         out["cpu_baseline"] = plan_cpu_baseline(pi, start.cpu().numpy(), goal.cpu().numpy(), prm, status.cpu().numpy(),
                                                 plen.cpu().numpy(), nchk.cpu().numpy())
@@ -700,7 +713,8 @@ def headline(out):
         "checks_per_s": out.get("value"), "roofline_frac_hbm": rf.get("frac"), "valu_frac": _g(rf, "valu", "frac"),
         "motions_per_s": _g(out, "motion", "motions_per_s_range"),
         "planner": {"ms_per_batch": _g(out, "planner", "ms_per_batch"), "plans_per_s": _g(out, "planner", "plans_per_s"),
-                    "laddered_plans_per_s": _g(out, "planner", "laddered", "plans_per_s"), "success_rate": _g(out, "planner", "success_rate"),
+                    "laddered_plans_per_s": _g(out, "planner", "laddered", "plans_per_s"),
+                    "laddered_long_plans_per_s": _g(out, "planner", "laddered_long", "plans_per_s"), "success_rate": _g(out, "planner", "success_rate"),
                     "cpu_plans_per_s": _g(out, "planner", "cpu_baseline", "value")},
         "scenes_checks_per_s": {k.split("Obstacle")[0].replace("Sawyer", "").lower(): _g(v, "checks_per_s")
                                 for k, v in (out.get("scenes") or {}).items() if isinstance(v, dict)},

@@ -184,8 +184,8 @@ class BatchPlanner:
                 t.record_stream(stream)
         return (path, plen, status, nchk, ps) if keep_state else (path, plen, status, nchk)
 
-    def plan_laddered(self, batches, max_iters: int = 2000, first_iters: int = 300, max_nodes: int = 1024, max_path: int = 256,
-                      retry_streams=None, first_stream=None, max_workgroups_first: int = -1, retry_min: int = 512, resume: bool = True,
+    def plan_laddered(self, batches, max_iters: int = 2000, first_iters: int = 100, max_nodes: int = 1024, max_path: int = 256,
+                      retry_streams=None, first_stream=None, max_workgroups_first: int = -1, retry_min: int = 1024, resume: bool = True,
                       retry_exclusive: bool = False):
         """A stream of query batches through RRT-Connect with an iteration ladder.  `batches`: list of dicts with `start`,
         `goal` ([E, nq] tensors), `seed` and optionally `env_ids` / `seeds` as for `plan`.  Every batch first runs with
@@ -195,7 +195,9 @@ class BatchPlanner:
         ends the loop, so the second run continues where the first stopped (`resume`: from its trees and counters; False: it retraces
         the first iterations): each batch's (path, path_len, status, n_checks)
         are those of `plan(..., max_iters=max_iters)`, bit for bit.  Returns the list of those tuples (after all launches
-        have finished).  One host read-back per batch (which queries go again)."""
+        have finished).  One host read-back per batch (which queries go again).  The defaults of `first_iters` / `retry_min` are
+        the ones that measured best over long streams of 4096-query batches on Push (tools/ladder_grid.py: 100 / 1024; they only
+        schedule the work)."""
         torch = _torch()
         if first_iters <= 0 or first_iters >= max_iters:
             return [self.plan(b["start"], b["goal"], max_iters=max_iters, max_nodes=max_nodes, max_path=max_path, seed=b.get("seed", 0),

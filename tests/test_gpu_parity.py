@@ -912,3 +912,51 @@ def test_nearest_neighbour_mirror_sizes_do_not_change_plans(oracle_mod, monkeypa
     for e in range(0, E, 12):
         ost, opath, ochk, _ = orc.plan(starts[e], goals[e], pi.spec.range, 0.005, max_iters=1200, max_nodes=2048, seed=11, env_id=e, max_path=256)
         assert ost == st[e] and ochk == out["all"][3][e]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", SUPPORTED_ENVS)
+def test_planner_builds_agree(env, oracle_mod, monkeypatch):
+    """K3's three builds -- four queries per workgroup at one / two waves per SIMD (k3w1 / k3w2) and ONE query per workgroup of four
+    waves (k3wg: waves 1-3 work out and evaluate what future iterations will ask; mopa_planner_k3.inc) -- give the same status, path
+    bits and consumed-check count on every scene, on queries that are trivial, solvable, budget-exhausting and invalid; so does k3wg
+    with a tiny tree mirror (its exact FP64 fall-backs) and with fewer workgroups than queries (the workgroup's query hand-over).
+    A few queries are checked against the oracle as well."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    pi, sc, orc = _mk(env, oracle_mod)
+    bp = BatchPlanner(sc)
+    E = 40
+    qa, row = sample_states(pi, 6000, 91, "uniform")
+    ov, _ = orc.is_valid_batch(qa, row, samples_per_env=len(qa))
+    good = qa[ov == 1]
+    assert len(good) >= 2 * E
+    starts = np.repeat(row, E, axis=0)
+    goals = starts.copy()
+    starts[:, pi.ref_joint_pos_indexes] = good[:E]
+    goals[:, pi.ref_joint_pos_indexes] = good[E:2 * E]
+    goals[:3] = starts[:3]
+    if (ov == 0).sum() >= 2:
+        goals[3:5, pi.ref_joint_pos_indexes] = qa[ov == 0][:2]
+    s, g = torch.from_numpy(starts).cuda(), torch.from_numpy(goals).cuda()
+    prm = dict(max_iters=700, max_nodes=1024, max_path=256, seed=23)
+    out = {}
+    for name, build, cap, kw in (("w1", "w1", None, {}), ("w2", "w2", None, {"max_workgroups": -1}), ("wg", "wg", None, {}),
+                                 ("wg_small_mirror", "wg", "64", {}), ("wg_3_workgroups", "wg", None, {"max_workgroups": 3, "exclusive": True})):
+        monkeypatch.setenv("MOPA_PLAN_BUILD", build)
+        if cap is None:
+            monkeypatch.delenv("MOPA_PLAN_NN_CAP", raising=False)
+        else:
+            monkeypatch.setenv("MOPA_PLAN_NN_CAP", cap)
+        out[name] = [t.cpu().numpy() for t in bp.plan(s, g, **prm, **kw)]
+    torch.cuda.synchronize()
+    ref = out["w1"]
+    assert (ref[2] == 0).sum() >= 3
+    for name, o in out.items():
+        assert np.array_equal(o[2], ref[2]) and np.array_equal(o[1], ref[1]) and np.array_equal(o[3], ref[3]), name
+        for e in range(E):
+            n = int(ref[1][e])
+            assert np.array_equal(_bits(o[0][e, :n]), _bits(ref[0][e, :n])), (name, e)
+    for e in (0, 3, 7, 19, 33):
+        ost, opath, ochk, _ = orc.plan(starts[e], goals[e], pi.spec.range, 0.005, max_iters=700, max_nodes=1024, seed=23, env_id=e, max_path=256)
+        assert ost == ref[2][e] and ochk == ref[3][e], e

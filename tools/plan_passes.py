@@ -53,3 +53,8 @@ if hasattr(lib, "mopa_debug_plan_mpr_pairs"):
         g1, g2 = divmod(int(k), 64)
         if both[g1, g2] == 0: break
         print("   %-34s %-34s disjoint %.3f  penetrating %.3f per pass" % (nm(g1), nm(g2), c[0, g1, g2] / t[4], c[1, g1, g2] / t[4]))
+    if t[51] or t[53]:
+        print("  workgroup-per-query build: table hits per env: nearest neighbour %.0f, verdict %.0f; states posed per env by wave 0 / 1 / 2 / 3: %.0f / %.0f / %.0f / %.0f" % (
+            t[51] / n, t[52] / n, t[53] / n, t[54] / n, t[55] / n, t[56] / n))
+        print("  growTree calls answered from the table alone: %.0f per env (%.0f us per env in that path); passes by cause: first call %.0f, connect first %.0f, connect later %.0f, interior states %.0f per env" % (
+            t[57] / n, t[39] / n / 100, t[58] / n, t[59] / n, t[60] / n, t[61] / n))

@@ -302,7 +302,7 @@ class CtFacts:
     ft_rad: np.ndarray         # [nf]
     pr_f: np.ndarray           # [np] i32
     pr_s: np.ndarray           # [np] i32
-    pr_par: np.ndarray         # [np,8]: mu, margin, K, B, d0, dmax, width, 0
+    pr_par: np.ndarray         # [np,12]: mu, margin, K, B, d0, dmax, width, 0, condim (3 / 4 / 6), torsional friction, rolling friction, 0
     obj_qadr: int
     obj_mass: float
     obj_inertia: np.ndarray    # [3] principal moments at the COM
@@ -330,6 +330,9 @@ class CtFacts:
     limit_rows: int = 1              # joint limits as rows of the Newton solver (MuJoCo) instead of stage A's inelastic stop
     lim_par: tuple = (0.0,) * 8      # their solver parameters in a pair record's layout: -, margin, K, B, d0, dmax, width, -
     condim_downgraded: int = 0       # directed pairs whose geoms ask for condim 4 / 6 (torsional / rolling friction) and are solved as condim 3
+                                     # (the pyramidal solver forms only: solver 2 solves every pair with the XML's condim)
+    arena: int = 0                   # solver 2: doubles of an env's LDS share the contact records have (a contact's record: record_size); 0 = as
+                                     # many as keep four waves on a CU (the library's default)
 
 
 def _joint_space_inertia_diag(dyn: DynFacts, qpos_row: np.ndarray) -> np.ndarray:
@@ -382,11 +385,11 @@ def _spread_order(n: int):
     return [i for i in order if i < n]
 
 
-def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpair: int = 4, iterations: int = 50,
+def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = None, maxpair: int = None, iterations: int = 50,
                   tolerance: float = 1e-10, precull_every: int = 15, precull_margin: float = 0.15, near_every: int = 3, near_margin: float = 0.03, warmstart: bool = True,
                   noslip_iterations: int = 5, noslip_tolerance: float = 1e-6, solver: str = "newton", cone: str = None, limit_rows=None,
                   limit_solref=(0.02, 1.0), limit_solimp=(0.9, 0.95, 0.001),
-                  qpos_ref: np.ndarray = None) -> CtFacts:
+                  qpos_ref: np.ndarray = None, condim: str = "xml", arena: int = None) -> CtFacts:
     from .mjcf import GEOM_BOX, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_MESH, GEOM_PLANE, GEOM_SPHERE, JNT_FREE
     m = model
     if len(getattr(m, "geom_solref", ())) == 0:
@@ -399,6 +402,14 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         raise ValueError("cone: 'elliptic' (Newton solver only) or 'pyramidal'")
     # the solver keeps per-contact state one contact per lane of an env's 16 (elliptic) / two pyramid rows per lane (Newton, pyramidal)
     cap = {("newton", "elliptic"): 16, ("newton", "pyramidal"): 8, ("pgs", "pyramidal"): 16}[(solver, cone)]
+    # defaults: the elliptic form keeps up to 16 contacts (one per lane) and 8 of a directed pair out of an LDS arena of variable-size
+    # records; the pyramidal forms keep round 5's fixed records (8 contacts, 4 of a pair)
+    if maxcon is None:
+        maxcon = 16 if cone == "elliptic" else 8
+    if maxpair is None:
+        maxpair = 8 if cone == "elliptic" else 4
+    if condim not in ("xml", "3"):
+        raise ValueError("condim: 'xml' (the pairs' own: max of the two geoms') or '3' (sliding friction only)")
     if maxcon > cap:
         raise ValueError(f"maxcon <= {cap} for solver {solver!r} with {cone} cones")
     names = list(m.body_names)
@@ -548,6 +559,18 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         else:
             dirs = [(sa, sb), (sb, sa)]
         mu = max(float(m.geom_friction[a]), float(m.geom_friction[b]))
+        # [3P] contact condim = max of the geoms'; friction coefficients = max, each of the three kinds (equal priorities)
+        cdim = 3
+        f_tors, f_roll = 0.005, 0.0001
+        if len(getattr(m, "geom_condim", ())):
+            cdim = max(int(m.geom_condim[a]), int(m.geom_condim[b]))
+            if cdim not in (3, 4, 6):
+                raise ValueError("condim 1 / other values are not supported")
+        if len(getattr(m, "geom_friction3", ())):
+            f_tors = max(float(m.geom_friction3[a][1]), float(m.geom_friction3[b][1]))
+            f_roll = max(float(m.geom_friction3[a][2]), float(m.geom_friction3[b][2]))
+        elif cdim > 3:
+            raise ValueError("compiled scene carries no torsional / rolling friction (recompile with tools/compile_scenes.py)")
         margin = max(float(m.geom_margin[a]), float(m.geom_margin[b]))
         tc = max(0.5 * (float(m.geom_solref[a][0]) + float(m.geom_solref[b][0])), 2.0 * h)
         dr = 0.5 * (float(m.geom_solref[a][1]) + float(m.geom_solref[b][1]))
@@ -558,9 +581,10 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         for f_, s_ in dirs:
             if sh[f_][2] == GEOM_PLANE:
                 continue
-            if len(getattr(m, "geom_condim", ())) and max(int(m.geom_condim[a]), int(m.geom_condim[b])) > 3:
+            use_dim = cdim if (cone == "elliptic" and condim == "xml") else 3
+            if cdim > use_dim:
                 n_downgraded += 1
-            pairs.append((f_, s_, [mu, margin, K, B, d0, dmax, width, 0.0]))
+            pairs.append((f_, s_, [mu, margin, K, B, d0, dmax, width, 0.0, float(use_dim), f_tors, f_roll, 0.0]))
             used_as_f.add(f_)
     # features only of shapes that appear as F
     feat0, ft_pos, ft_rad = [0], [], []
@@ -591,11 +615,11 @@ def contact_facts(model, dyn: DynFacts, object_body: str, maxcon: int = 8, maxpa
         sh_mat=np.array([s[5] for s in sh]), sh_rbound=np.array([s[6] for s in sh]), sh_feat0=np.array(feat0, dtype=np.int32),
         ft_pos=np.concatenate(ft_pos) if ft_pos else np.zeros((0, 3)), ft_rad=np.array(ft_rad, dtype=np.float64),
         pr_f=np.array([p[0] for p in pairs], dtype=np.int32), pr_s=np.array([p[1] for p in pairs], dtype=np.int32),
-        pr_par=np.array([p[2] for p in pairs], dtype=np.float64).reshape(-1, 8),
+        pr_par=np.array([p[2] for p in pairs], dtype=np.float64).reshape(-1, 12),
         obj_qadr=int(m.jnt_qposadr[jo]), obj_mass=mt, obj_inertia=prin, obj_ipos=com, obj_iquat=iquat, obj_damping=damp,
         obj_inv_mass=1.0 / mt, obj_inv_inertia=1.0 / prin, obj_inv_mass_d=1.0 / (mt + h * damp), obj_inv_inertia_d=1.0 / (prin + h * damp),
         maxcon=int(maxcon), maxpair=int(maxpair), iterations=int(iterations), tolerance=float(tolerance),
         inv_scale=1.0 / (float(dg.mean()) * max(1, nv)), precull_every=int(precull_every), precull_margin=float(precull_margin),
         warmstart=int(bool(warmstart)), near_every=int(near_every), near_margin=float(near_margin), noslip_iterations=int(noslip_iterations), noslip_tolerance=float(noslip_tolerance),
         solver={("pgs", "pyramidal"): 0, ("newton", "pyramidal"): 1, ("newton", "elliptic"): 2}[(solver, cone)], limit_rows=int(limit_rows), lim_par=lim_par,
-        condim_downgraded=n_downgraded)
+        condim_downgraded=n_downgraded, arena=int(arena or 0))

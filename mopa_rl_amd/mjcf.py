@@ -52,6 +52,11 @@ class MjcfError(ValueError):
     pass
 
 
+def _friction3(txt):
+    v = _floats(txt)
+    return (v + [1.0, 0.005, 0.0001][len(v):])[:3]
+
+
 def _floats(s: str) -> List[float]:
     return [float(x) for x in s.replace(",", " ").split()]
 
@@ -188,6 +193,7 @@ class CompiledModel:
     geom_solref: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), dtype=np.float64))  # [ngeom,2] (timeconst, dampratio)
     geom_solimp: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), dtype=np.float64))  # [ngeom,3] (d0, dmax, width)
     geom_condim: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int32))         # [ngeom]
+    geom_friction3: np.ndarray = field(default_factory=lambda: np.zeros((0, 3), dtype=np.float64))   # [ngeom,3] sliding, torsional, rolling friction
     meta: Dict[str, object] = field(default_factory=dict)
 
     # ---- name lookups mirroring the mujoco-py calls the reference makes ----
@@ -224,6 +230,7 @@ class CompiledModel:
     _DYN = ("body_mass body_ipos body_inertia jnt_damping jnt_armature jnt_stiffness act_kind act_gain act_gear act_forcelimited "
             "act_forcerange opt geom_friction").split()                                   # absent in scenes compiled before round 3
     _CT = "geom_solref geom_solimp geom_condim".split()                                  # absent in scenes compiled before round 4
+    _CT6 = "geom_friction3".split()                                                      # absent in scenes compiled before round 6
     _LISTS = "body_names jnt_names all_geom_names geom_mesh site_names".split()
 
     def to_json(self) -> str:
@@ -232,7 +239,8 @@ class CompiledModel:
             d[k] = getattr(self, k)
         d["act_names"] = list(self.act_names)
         for k in self._ARRAYS + ([k for k in self._OPTIONAL] if len(self.mesh_vertnum) else []) + self._ACT + \
-                (self._DYN if len(self.body_mass) else []) + (self._CT if len(self.geom_solref) else []):
+                (self._DYN if len(self.body_mass) else []) + (self._CT if len(self.geom_solref) else []) + \
+                (self._CT6 if len(self.geom_friction3) else []):
             a = getattr(self, k)
             d[k] = {"dtype": str(a.dtype), "shape": list(a.shape),
                     "data": [float(x).hex() if a.dtype.kind == "f" else int(x) for x in a.ravel()]}
@@ -245,7 +253,7 @@ class CompiledModel:
         for k in cls._LISTS:
             kw[k] = list(d[k])
         kw["act_names"] = list(d.get("act_names", []))
-        for k in cls._ARRAYS + [k for k in cls._OPTIONAL + cls._ACT + cls._DYN + cls._CT if k in d]:
+        for k in cls._ARRAYS + [k for k in cls._OPTIONAL + cls._ACT + cls._DYN + cls._CT + cls._CT6 if k in d]:
             e = d[k]
             if e["dtype"].startswith("float"):
                 a = np.array([float.fromhex(x) for x in e["data"]], dtype=np.float64)
@@ -593,6 +601,7 @@ class _Builder:
              "conaffinity": int(at.get("conaffinity", "1")), "margin": float(at.get("margin", "0")),
              "mesh": at.get("mesh", ""), "density": float(at.get("density", "1000")),
              "friction": _floats(at.get("friction", "1 0.005 0.0001"))[0],
+             "friction3": _friction3(at.get("friction", "1 0.005 0.0001")),    # (sliding, torsional, rolling); missing entries = MuJoCo's defaults
              "solref": (_floats(at.get("solref", "0.02 1")) + [1.0])[:2],
              "solimp": (_floats(at.get("solimp", "0.9 0.95 0.001")) + [0.95, 0.001])[:3],   # (d0, dmax, width); midpoint 0.5, power 2
              "condim": int(at.get("condim", "3")),
@@ -809,6 +818,7 @@ class _Builder:
             geom_solref=np.array([g["solref"] for g in cg], dtype=np.float64).reshape(-1, 2),
             geom_solimp=np.array([g["solimp"] for g in cg], dtype=np.float64).reshape(-1, 3),
             geom_condim=arr(cg, "condim", np.int32),
+            geom_friction3=np.array([g["friction3"] for g in cg], dtype=np.float64).reshape(-1, 3),
             meta={"source": os.path.basename(self.xml_path)},
         )
 

@@ -183,7 +183,8 @@ typedef struct OrcCtDesc {
     const double *ft_pos, *ft_rad;               /* [nf,3] (body frame of the owning shape) [nf] */
     int32_t np;
     const int32_t *pr_f, *pr_s;                  /* [np] */
-    const double *pr_par;                        /* [np,8]: mu, margin, K, B, d0, dmax, width, - (solref / solimp mixed per pair) */
+    const double *pr_par;                        /* [np,12]: mu, margin, K, B, d0, dmax, width, - (solref / solimp mixed per pair), condim (3 / 4 / 6),
+                                                    torsional friction, rolling friction, - (solver 2; the others solve every pair as condim 3) */
     int32_t obj_qadr;                            /* qpos address of the object's free joint; -1: no object */
     double obj_mass, obj_inertia[3], obj_ipos[3], obj_iquat[4], obj_damping;   /* principal inertia at the COM (ipos, iquat in the body frame) */
     double obj_inv_mass, obj_inv_inertia[3];     /* reciprocals for the constraint stage (M^-1) */
@@ -194,11 +195,14 @@ typedef struct OrcCtDesc {
     int32_t precull_every; double precull_margin;
     int32_t near_every; double near_margin;      /* third culling level: the active pairs within this of contact, re-listed every near_every sub-steps */
     int32_t warmstart;                           /* carry the pyramid forces of persisting contacts into the next sub-step */
-    int32_t solver;                              /* 0: projected Gauss-Seidel, 1: Newton (MuJoCo's default; `iterations` caps either) */
+    int32_t solver;                              /* 0: projected Gauss-Seidel (pyramidal cones), 1: Newton, pyramidal cones, 2: Newton, ELLIPTIC cones with the
+                                                    pairs' condim (3, 4: + torsional, 6: + rolling friction) -- the XML's model */
     int32_t limit_rows;                          /* joint limits as rows of the (Newton) solver instead of an inelastic stop */
     double lim_par[8];                           /* their parameters in a pair record's layout: -, margin 0, K, B, d0, dmax, width, - */
     int32_t noslip_iterations;                   /* sweeps of the noslip pass after the main solve (XML: 5; 0 = none) */
     double noslip_tolerance;                     /* its early exit: improvement * inv_scale below this (MuJoCo default 1e-6) */
+    int32_t arena;                               /* solver 2: doubles of the kernel's per-env LDS arena the contact records share (a contact whose record
+                                                    does not fit is dropped, as one beyond maxcon is); 0 = unlimited */
 } OrcCtDesc;
 typedef struct OrcCtStats { int64_t substeps, contacts, sweeps, dropped; int32_t max_contacts; int64_t hot_pairs, active_pairs; } OrcCtStats;
 /* n sub-steps with contacts; qvel [nd + 6]: dofs, then the object's (v of its COM, w) in the world; stats may be NULL (accumulated) */

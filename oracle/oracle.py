@@ -168,6 +168,7 @@ class OrcCtDesc(C.Structure):
         ("maxcon", C.c_int32), ("maxpair", C.c_int32), ("iterations", C.c_int32), ("tolerance", C.c_double), ("inv_scale", C.c_double),
         ("precull_every", C.c_int32), ("precull_margin", C.c_double), ("near_every", C.c_int32), ("near_margin", C.c_double), ("warmstart", C.c_int32),
         ("solver", C.c_int32), ("limit_rows", C.c_int32), ("lim_par", C.c_double * 8), ("noslip_iterations", C.c_int32), ("noslip_tolerance", C.c_double),
+        ("arena", C.c_int32),
     ]
 
 
@@ -240,6 +241,8 @@ class OracleDyn:
             c.solver = int(ct.solver)
             c.limit_rows = int(ct.limit_rows)
             c.lim_par = (C.c_double * 8)(*[float(x) for x in ct.lim_par])
+            c.arena = int(getattr(ct, "arena", 0))
+            assert np.asarray(ct.pr_par).shape[1] == 12
             self.ct = c
             d.ct = C.cast(C.pointer(c), C.c_void_p)
         self.stats = OrcCtStats()

@@ -108,14 +108,15 @@ def bias_force(model, qpos, qvel, dyn_bodies, qadr, armature, eps=1e-6):
 
 # ---- stage C: one sub-step with contacts, by an independent route (tests/test_oracle_contact.py) ---------------------------
 def _proj_cone(y, mu):
-    """Euclidean projection of y = (y_n, y_t1, y_t2) onto the friction cone |y_t| <= mu y_n (textbook second-order-cone projection)"""
-    t = float(np.hypot(y[1], y[2]))
+    """Euclidean projection of y = (y_n, y_t...) onto the friction cone |y_t| <= mu y_n (textbook second-order-cone projection; any
+    number of tangential components)"""
+    t = float(np.linalg.norm(y[1:]))
     if t <= mu * y[0]:
         return y.copy()
     if mu * t <= -y[0]:
-        return np.zeros(3)
+        return np.zeros(len(y))
     a = (y[0] + mu * t) / (1.0 + mu * mu)
-    return np.array([a, mu * a * y[1] / t, mu * a * y[2] / t])
+    return np.concatenate([[a], mu * a * y[1:] / t])
 
 
 def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl, limit_rows=False, cone="pyramidal"):
@@ -125,10 +126,14 @@ def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl,
     the constraint forces as the exact solution (active-set NNLS) of MuJoCo's dual problem
         min_{f >= 0}  1/2 f^T (A + R) f + f^T (J a_smooth - aref),      A = J M^-1 J^T,  R = (1 - imp) / imp diag(A)
     with pyramidal rows J_n +- mu J_t and aref = -B J v - K imp (dist - margin).
-    cone="elliptic": rows n, t1, t2 per contact, one regulariser r = (1 - imp) / imp A_nn for all three, the friction rows' aref without
-    the position term, forces in the cone |f_t| <= mu f_n -- solved in its PRIMAL form, written from the cone projection alone
-        min_q  1/2 (q - a_smooth)^T M (q - a_smooth) + sum_c |proj_K(-(J_c q - aref_c))|^2 / (2 r_c)  (+ the limit rows' half-quadratics)
-    by damped Newton with a finite-difference Hessian (15 unknowns), to a gradient of 1e-9 of its start."""
+    cone="elliptic": rows n, t1, t2 per contact (condim 4: + the relative angular velocity about n, condim 6: + about t1, t2; the pair's
+    condim and torsional / rolling friction in ct.pr_par[:, 8:11]), the normal row's regulariser r = (1 - imp) / imp A_nn, the friction
+    rows' r_j = r mu_1^2 / mu_j^2 (MuJoCo's rule r_j mu_j^2 = const), their aref without the position term, forces in the ellipsoidal cone
+    sum_j (f_j / mu_j)^2 <= f_n^2.  Under the scaling S = diag(1, mu_j / mu_1) that cone is circular with mu_1 and the regulariser
+    isotropic, so the dual's per-contact minimiser is a Euclidean cone projection: f = S proj_K(-S (J q - aref)) / r -- which gives the
+    PRIMAL form, written from the projection alone:
+        min_q  1/2 (q - a_smooth)^T M (q - a_smooth) + sum_c |proj_K(-S_c (J_c q - aref_c))|^2 / (2 r_c)  (+ the limit rows' half-quadratics)
+    solved by damped Newton with a finite-difference Hessian (15 unknowns), to a gradient of 1e-12 of its start."""
     from scipy.optimize import nnls
     m = model
     nd, h = dyn.nd, float(dyn.timestep)
@@ -173,8 +178,23 @@ def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl,
             row[nd + 3:] = RD.T @ np.cross(pos - c, d)
         return row
 
+    def ang_jac(model_body, d):      # d . angular velocity of a model body, per unit dof velocity
+        row = np.zeros(nv)
+        on_obj = False
+        a = model_body
+        while a > 0:
+            if a in bodies:
+                i = bodies.index(a)
+                row[i] = 0.0 if types[i] == 2 else float(d @ axes[i])
+            if int(m.body_jntnum[a]) == 1 and int(m.jnt_type[int(m.body_jntadr[a])]) == 0:
+                on_obj = True
+            a = int(m.body_parent[a])
+        if on_obj:
+            row[nd + 3:] = RD.T @ d
+        return row
+
     if cone == "elliptic":
-        return _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull, RD, q, M, limit_rows)
+        return _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull, RD, q, M, limit_rows, ang_jac)
     rows, pars, dists, mus = [], [], [], []
     pair_of = {(int(f), int(s)): k for k, (f, s) in enumerate(zip(ct.pr_f, ct.pr_s))}
     for r in contacts:
@@ -229,7 +249,7 @@ def contact_step_reference(model, dyn, ct, contacts, qpos, qvel, bias_lag, ctrl,
     return np.concatenate([vn[:nd + 3], RD @ vn[nd + 3:]]), f
 
 
-def _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull, RD, q, M, limit_rows):
+def _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull, RD, q, M, limit_rows, ang_jac):
     nd, h = dyn.nd, float(dyn.timestep)
     nv = nd + 6
     Minv = np.linalg.inv(Mfull)
@@ -249,12 +269,18 @@ def _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull,
         t1 = e - n * (n @ e); t1 /= np.linalg.norm(t1)
         t2 = np.cross(n, t1)
         bF, bS = int(m.geom_body[int(ct.sh_geom[sf])]), int(m.geom_body[int(ct.sh_geom[ss])])
-        J = np.array([point_jac(bF, pos, d) - point_jac(bS, pos, d) for d in (n, t1, t2)])
+        dim = int(par[8]) if len(par) > 8 else 3
+        rows = [point_jac(bF, pos, d) - point_jac(bS, pos, d) for d in (n, t1, t2)]
+        rows += [ang_jac(bF, d) - ang_jac(bS, d) for d in (n, t1, t2)[:dim - 3]]
+        J = np.array(rows)
+        mus = np.array([par[0], par[0], max(par[9], 1e-5), max(par[10], 1e-5), max(par[10], 1e-5)][:dim - 1]) if dim > 3 else np.array([par[0], par[0]])
+        S = np.concatenate([[1.0], mus / par[0]])
         imp = impedance(par, dist)
         rr = (1 - imp) / imp * float(J[0] @ Minv @ J[0])
         jv = J @ vfull
-        aref = np.array([-par[3] * jv[0] - par[2] * imp * (dist - par[1]), -par[3] * jv[1], -par[3] * jv[2]])
-        cons.append((J, aref, rr, float(par[0])))
+        aref = -par[3] * jv
+        aref[0] -= par[2] * imp * (dist - par[1])
+        cons.append((J, aref, rr, float(par[0]), S))
     lims = []
     if limit_rows:
         for i in range(nd):
@@ -270,11 +296,11 @@ def _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull,
             lims.append((i, side, -par[3] * side * vfull[i] - par[2] * imp * dist, 1.0 / rr))
 
     def forces(qa):
-        return [_proj_cone(-(J @ qa - aref), mu) / rr for J, aref, rr, mu in cons]
+        return [S * _proj_cone(-(S * (J @ qa - aref)), mu) / rr for J, aref, rr, mu, S in cons]
 
     def grad(qa):
         g = Mfull @ (qa - a0)
-        for (J, aref, rr, mu), f in zip(cons, forces(qa)):
+        for (J, aref, rr, mu, S), f in zip(cons, forces(qa)):
             g = g - J.T @ f
         for i, side, aref, D in lims:
             x = side * qa[i] - aref
@@ -284,8 +310,8 @@ def _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull,
 
     def cost(qa):
         c = 0.5 * (qa - a0) @ Mfull @ (qa - a0)
-        for (J, aref, rr, mu), f in zip(cons, forces(qa)):
-            c += 0.5 * rr * float(f @ f)
+        for (J, aref, rr, mu, S), f in zip(cons, forces(qa)):
+            c += 0.5 * rr * float((f / S) @ (f / S))
         for i, side, aref, D in lims:
             x = side * qa[i] - aref
             if x < 0:
@@ -295,7 +321,7 @@ def _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull,
     g0 = max(np.linalg.norm(grad(qa)), 1e-30)
     for _ in range(200):
         g = grad(qa)
-        if np.linalg.norm(g) <= 1e-9 * g0:
+        if np.linalg.norm(g) <= 1e-12 * g0:
             break
         eps = 1e-7 * max(1.0, np.abs(qa).max())
         H = np.array([(grad(qa + eps * np.eye(nv)[k]) - grad(qa - eps * np.eye(nv)[k])) / (2 * eps) for k in range(nv)])
@@ -306,7 +332,7 @@ def _contact_step_elliptic(m, dyn, ct, contacts, point_jac, Mfull, tfull, vfull,
             t *= 0.5
         qa = qa + t * step
     f = np.concatenate(forces(qa)) if cons else np.zeros(0)
-    Jt = sum((J.T @ fc for (J, _, _, _), fc in zip(cons, forces(qa))), np.zeros(nv))
+    Jt = sum((J.T @ fc for (J, _, _, _, _), fc in zip(cons, forces(qa))), np.zeros(nv))
     for i, side, aref, D in lims:
         x = side * qa[i] - aref
         if x < 0:

@@ -415,7 +415,8 @@ typedef struct MopaCtDesc {
     const double *ft_pos, *ft_rad;                          /* [nf,3] [nf] */
     int32_t np;
     const int32_t *pr_f, *pr_s;                             /* [np] */
-    const double *pr_par;                                   /* [np,8] */
+    const double *pr_par;                                   /* [np,12]: mu, margin, K, B, d0, dmax, width, -, condim (3 / 4 / 6), torsional friction,
+                                                               rolling friction, - (solver 2 solves a pair with its condim; 0 / 1 as condim 3) */
     int32_t obj_qadr;                                       /* qpos address of the object's free joint */
     double obj_mass, obj_inertia[3], obj_ipos[3], obj_iquat[4], obj_damping;
     double obj_inv_mass, obj_inv_inertia[3], obj_inv_mass_d, obj_inv_inertia_d[3];
@@ -432,9 +433,12 @@ typedef struct MopaCtDesc {
     double lim_par[8];               /* their parameters in a pair record's layout: -, margin 0, K, B, d0, dmax, width, - */
     int32_t noslip_iterations;       /* sweeps of the noslip pass after the main solve (0 = none) */
     double noslip_tolerance;
+    int32_t arena;                   /* solver 2: doubles of an env's LDS the (variable-size) contact records share; a contact whose record does not
+                                        fit is dropped like one beyond maxcon.  0 = what keeps four waves on a CU (mopa_env_contact_arena tells) */
 } MopaCtDesc;
 int mopa_env_attach_contacts(MopaEnv *env, const MopaCtDesc *desc);
 int mopa_ct_desc_size(void);           /* sizeof(MopaCtDesc) as the library was built (binding self-check) */
+int mopa_env_contact_arena(const MopaEnv *env);   /* the arena (doubles per env) the attached contact stage runs with; -1 without one */
 /* per-env counters of the last stepping launch: [E,4] int32 = contacts summed over the sub-steps, solver sweeps summed,
  * contacts dropped by the caps, largest contact count of a sub-step (NULL: not recorded) */
 int mopa_env_set_contact_stats(MopaEnv *env, int32_t *stats_dev);

@@ -344,7 +344,12 @@ class BatchKinematicEnv:
                 cd.solver = int(ct.solver)
                 cd.limit_rows = int(ct.limit_rows)
                 cd.lim_par = (C.c_double * 8)(*[float(x) for x in ct.lim_par])
+                cd.arena = int(ct.arena)
+                assert np.asarray(ct.pr_par).shape[1] == 12
                 _lib.check(L.mopa_env_attach_contacts(self._h, C.byref(cd)))
+                # the arena the library sized (0 asked for its default): a checker of this env has to drop the same contacts
+                import dataclasses
+                self.ct = dataclasses.replace(ct, arena=int(L.mopa_env_contact_arena(self._h)) if ct.solver == 2 else 0)
             self.nv = int(L.mopa_env_dyn_qvel_width(self._h))
             assert self.nv == df.nd + (6 if contacts else 0)
             # velocities of the dynamic dofs (arm, gripper) [+ the object's linear / angular velocity, world frame]

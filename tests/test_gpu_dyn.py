@@ -488,6 +488,52 @@ def test_contact_substeps_bit_exact(oracle_mod, torch_mod, env_name, n, solver):
         assert np.array_equal(_bits(gv[e]), _bits(ov)), f"env {e}: qvel (object velocity included)"
         assert np.array_equal(_bits(gl[e]), _bits(ol)), f"env {e}: lagged bias"
     assert touched > E // 4
+    if solver == "newton":
+        # the XML's condim is what was solved: the batch holds contacts with a torsional row (the object: condim 4) and, where the gripper
+        # meets the object, rolling rows (the pads: condim 6) -- and nothing was downgraded
+        pair_of = {(int(a), int(b)): k for k, (a, b) in enumerate(zip(env.ct.pr_f, env.ct.pr_s))}
+        dims = set()
+        for e in range(E):
+            dims |= {int(env.ct.pr_par[pair_of[(int(r[7]), int(r[8]))]][8]) for r in ref.dyn.contacts(q[e])}
+        assert env.ct.condim_downgraded == 0 and 6 in dims and (4 in dims or env_name == "SawyerAssemblyObstacle-v0"), dims
+    else:
+        assert env.ct.condim_downgraded > 0 and set(env.ct.pr_par[:, 8]) == {3.0}
+
+
+@pytest.mark.parametrize("env_name", ENVS)
+@pytest.mark.parametrize("opts", [{"arena": 150}, {"arena": 330, "maxpair": 3}, {"condim": "3"}, {"maxcon": 5, "maxpair": 2}])
+def test_contact_record_arena_and_caps_bit_exact(oracle_mod, torch_mod, env_name, opts):
+    """round 6: the elliptic form's contact records are of variable size (8 + 3 dim + dim (dim + 1) / 2 + 6 dim [object] + nd dim [arm] doubles)
+    and share an LDS arena; a contact whose record does not fit is dropped, like one beyond maxcon / maxpair.  Small arenas, small caps and
+    condim forced to 3: 30 sub-steps bit for bit against the oracle, and the same number of dropped contacts on both sides."""
+    torch = torch_mod
+    E = 66
+    pi, orc, env, ref = _setup_ct(oracle_mod, env_name, E, contact_options=opts)
+    assert env.ct.solver == 2 and env.ct.arena == opts.get("arena", env.ct.arena) and env.ct.arena >= 135
+    d = env.dyn
+    q, v = _ct_states(env, orc, E, seed=77)
+    rng = np.random.default_rng(78)
+    ctrl = q[:, d.qadr] + rng.uniform(-0.3, 0.3, size=(E, d.nd)) * np.where(d.jtype == 3, 1.0, 0.02)
+    env.set_state(torch.tensor(q, device=env.device))
+    env.qvel.copy_(torch.tensor(v, device=env.device))
+    lag0 = env.dyn_forward()[0]
+    env.bias_lag.copy_(lag0)
+    stats = torch.zeros(E, 4, dtype=torch.int32, device=env.device)
+    from mopa_rl_amd import _lib
+    _lib.check(_lib.lib().mopa_env_set_contact_stats(env._h, stats.data_ptr()))
+    env.dyn_substeps(torch.tensor(ctrl, device=env.device), 30)
+    gq, gv = env.qpos.cpu().numpy(), env.qvel.cpu().numpy()
+    st = stats.cpu().numpy()
+    lag0 = lag0.cpu().numpy()
+    dropped = 0
+    for e in range(E):
+        d0, c0 = ref.dyn.stats.dropped, ref.dyn.stats.contacts
+        oq, ov, ol = ref.dyn.step(q[e], v[e], lag0[e], ctrl[e], 30)
+        assert np.array_equal(_bits(gq[e]), _bits(oq)) and np.array_equal(_bits(gv[e]), _bits(ov)), (opts, e)
+        assert st[e, 0] == ref.dyn.stats.contacts - c0 and st[e, 2] == ref.dyn.stats.dropped - d0, (opts, e, st[e])
+        dropped += int(st[e, 2])
+    assert dropped > 0 or "condim" in opts
+    env.close()
 
 
 def test_joint_limit_rows_bit_identical_to_oracle(oracle_mod, torch_mod):

@@ -411,7 +411,7 @@ def rollout_section(torch, env_name, E, device, agent_steps, world=1, async_plan
     from mopa_rl_amd.dist import TransitionExchange, all_reduce_mean_
     from mopa_rl_amd.kinematic_env import make_env
     from mopa_rl_amd.rollout import BatchMoPARollout, RolloutConfig
-    env = make_env(env_name, E, device=device, seed=21 + int(os.environ.get("RANK", "0")), max_episode_steps=250,
+    env = make_env(env_name, E, device=device, seed=21 + int(os.environ.get("RANK", "0")),
                    **({"dynamics": True, "contacts": True} if dynamics else {}))
     env.reset()
     over = {k: int(v) for k, v in (kv.split("=") for kv in os.environ.get("MOPA_BENCH_ROLLOUT", "").split(",") if kv)}   # A/B knob
@@ -683,6 +683,21 @@ def _r(x, nd=6):
     return x
 
 
+def exchange_preflight(torch, dist, world, rank, device):
+    """all-gather of a rank-stamped tensor over the initialised backend; raises unless every rank sees exactly the stamps 0 .. world-1 (and
+    all ranks agree that they did).  Returns the stamps seen."""
+    stamp = torch.full((4,), 1000 + rank, dtype=torch.int64, device=device)
+    got = [torch.full((4,), -1, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(got, stamp)
+    seen = sorted({int(x) - 1000 for g in got for x in g.cpu().tolist()})
+    ok = torch.tensor([1 if seen == list(range(world)) else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) != 1:
+        raise SystemExit(f"rank {rank}: exchange preflight failed -- stamps seen {seen}, expected {list(range(world))}: refusing to time a "
+                         f"{world}-rank run whose collective does not reach every rank")
+    return seen
+
+
 def headline(out):
     """The ONE line the driver parses: the contract's keys, `roofline`, `cpu_baseline`, the parity count and a numeric summary of
     every section -- no prose (the per-section blocks are in gpurun_out/bench_full_n<N>.json and on stderr).  Pure function of
@@ -696,9 +711,9 @@ def headline(out):
     cfg = out.get("config") or {}
     h["config"] = {k: cfg.get(k) for k in ("workload", "envs_per_gpu", "states_per_env", "pairs_checked_per_state", "parallelism") if k in cfg}
     h["valid_fraction"] = out.get("valid_fraction")
-    h["exchange"] = {k: _g(out, "exchange", k) for k in ("backend", "ranks")}
+    h["exchange"] = {k: _g(out, "exchange", k) for k in ("backend", "ranks", "ranks_seen", "kernel_ms_per_rank")}
     h["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bytes_per_check",
-                                            "traffic_source", "input_resident") if k in rf}
+                                            "traffic_source", "input_resident", "limiter") if k in rf}
     if "valu" in rf:
         h["roofline"]["valu"] = {k: rf["valu"].get(k) for k in ("achieved", "peak", "unit", "frac", "insts_per_check")}
     h["cpu_baseline"] = None if cb is None else {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "sample", "single_thread_value")}
@@ -819,6 +834,9 @@ def main():
         else:
             dist.init_process_group(backend)
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
+    # preflight over the REAL backend, before any timing: every rank all-gathers a rank-stamped tensor and must see `world` distinct
+    # stamps (a collective that silently ran over fewer ranks, or returned stale buffers, fails here and not in a scaling curve)
+    ranks_seen = exchange_preflight(torch, dist, world, rank, device if backend == "nccl" else torch.device("cpu")) if world > 1 else [0]
 
     pi = planner_inputs(ENV)
     scene = _lib.Scene(pi.model, pi.passive_joint_idx, pi.ignored_contacts, pi.spec.contact_threshold,
@@ -864,10 +882,15 @@ def main():
     elapsed = time.perf_counter() - t0
     unsettle()
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kern_ms_ranks = [kern_ms]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        cdev = device if backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        km = [torch.zeros(1, dtype=torch.float64, device=cdev) for _ in range(world)]
+        dist.all_gather(km, torch.tensor([kern_ms], dtype=torch.float64, device=cdev))
+        kern_ms_ranks = [round(float(x.item()), 6) for x in km]      # a slow rank shows here (the headline's roofline is rank 0's kernel)
     valid = og.local[(args.steps - 1) % og.depth] if args.steps > 0 else og.local[0]
 
     n_valid = int(valid.sum().item())
@@ -884,15 +907,17 @@ def main():
                                    + {"mixed": "states 50% uniform joint-box samples + 50% near-init N(0,0.3)", "near": "states near-init N(0,0.3)",
                                       "uniform": "states uniform in the joint box"}[args.mode],
                        "envs_per_gpu": E, "states_per_env": S, "pairs_checked_per_state": scene.npair_checked,
-                       "parallelism": f"env-shard x{world}" + (" + RCCL all_gather(uint8 masks), triple-buffered, overlapped with the next steps' kernels" if world > 1 else "")},
+                       "parallelism": f"env-shard x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend} all_gather(uint8 masks), triple-buffered, overlapped with the next steps' kernels" if world > 1 else "")},
             "valid_fraction": n_valid / N,
-            "exchange": {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None, "ranks": world,
+            "exchange": {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None, "ranks": world, "ranks_seen": ranks_seen,
+                         "kernel_ms_per_rank": kern_ms_ranks,
                          "collectives": (["all_gather(uint8 masks) per validity step", "all_gather(transition records) + all_reduce(gradient-sized "
                                           "buffer) per rollout call"] if world > 1 else [])},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "kernel": scene.valid_kernel(N), "kernel_ms": kern_ms, "bytes_per_check": bytes_per_check,
                          "input_resident": "one input batch re-used by every step (58.7 MB: Infinity-Cache resident after step 1)",
+                         "limiter": "fp64-issue",      # what actually bounds K1 (`valu` below when a PMC pass of this build is committed); `bound` / `frac` stay the HBM roofline the contract asks for
                          "note": "path is FP64-VALU bound, not HBM bound (SURVEY.md 8d); see DESIGN.md"},
         }
         t = committed_traffic(scene.valid_kernel(N), N)

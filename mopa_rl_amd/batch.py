@@ -6,6 +6,7 @@ pointers to libmopa_hip.so through the C ABI (include/mopa_hip.h).
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 from typing import Optional, Tuple
@@ -35,8 +36,24 @@ def _stream_handle(stream) -> C.c_void_p:
         return C.c_void_p(stream.cuda_stream)
     # the current stream's raw handle without building a torch.cuda.Stream object (a dozen lookups per agent_step call:
     # ~9 us each through torch.cuda.current_stream(), well under 1 us this way)
-    tc = _torch()._C
-    return C.c_void_p(tc._cuda_getCurrentRawStream(tc._cuda_getDevice()))
+    return C.c_void_p(_raw_stream_fn()())
+
+
+_RAW_STREAM = None
+
+
+def _raw_stream_fn():
+    """the cheapest way this torch build offers to read the current stream's raw handle (chosen once): the private
+    torch._C._cuda_getCurrentRawStream when it exists, else the documented torch.cuda.current_stream().cuda_stream"""
+    global _RAW_STREAM
+    if _RAW_STREAM is None:
+        torch = _torch()
+        tc = torch._C
+        if os.environ.get("MOPA_STREAM_PUBLIC_API") != "1" and hasattr(tc, "_cuda_getCurrentRawStream") and hasattr(tc, "_cuda_getDevice"):
+            _RAW_STREAM = lambda: tc._cuda_getCurrentRawStream(tc._cuda_getDevice())
+        else:
+            _RAW_STREAM = lambda: torch.cuda.current_stream().cuda_stream
+    return _RAW_STREAM
 
 
 class PlanState:

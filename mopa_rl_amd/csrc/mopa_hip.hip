@@ -1262,15 +1262,18 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             sc.slab_waves = want;
         }
         if (!sc.k1_ctr.p) {
+            // zeroed ONCE, synchronously (never inside a stream capture: a first call under capture fails loudly here instead of baking a
+            // memset node into the graph).  INVARIANT the kernels keep (tile_ctr_release): every wave of a launch reaches the release, the
+            // last one puts [0] and [1] back to zero -- a kernel edit that adds an early return before the release breaks later launches.
             HIP_TRY(grow(S, sc.k1_ctr, 64));
-            HIP_TRY(hipMemsetAsync(sc.k1_ctr.p, 0, 64, st));
+            HIP_TRY(hipMemset(sc.k1_ctr.p, 0, 64));
         }
         unsigned long long *const d_ctr = sc.k1_ctr.as<unsigned long long>();
         double *const d_slab = sc.slab.as<double>();
         dim3 grid((unsigned)blocks);
-        // [6 profile words | 2 pad | tile counter] live right behind the slabs of this launch's waves
-        double *d_tail = d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride;
 #ifdef MOPA_V2_PROFILE
+        // [6 profile words | 2 pad] live right behind the slabs of this launch's waves
+        double *d_tail = d_slab + (size_t)blocks * kWavesPerBlock * (S->hdr.nmg + S->hdr.n_save) * kSlabStride;
         unsigned long long *d_prof = (unsigned long long *)d_tail;
         (void)zero_async(d_prof, 6 * 8, st);
 #endif

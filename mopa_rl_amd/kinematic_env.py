@@ -185,7 +185,7 @@ class BatchKinematicEnv:
     """E envs of one of the three Sawyer obstacle tasks -- or of PusherObstacle-v0 (KIND_PUSHER: four hinges, joint0 unlimited) --
     stepped kinematically on one GPU."""
 
-    def __init__(self, env_name: str, num_envs: int, device=None, seed: int = 0, max_episode_steps: int = 250,
+    def __init__(self, env_name: str, num_envs: int, device=None, seed: int = 0, max_episode_steps: Optional[int] = None,
                  distance_threshold: Optional[float] = None, success_reward: float = 150.0, ac_scale: Optional[float] = None,
                  block_invalid: bool = False, model=None, dynamics: bool = False, frame_dt: float = 0.15, contacts=False,
                  contact_options: dict = None, dyn_lanes: int = 1):
@@ -209,6 +209,8 @@ class BatchKinematicEnv:
         self.n_arm = len(f.arm_qpos_idx)
         self.action_dim, self.obs_dim = f.action_dim, f.obs_dim
         self.obs_layout = OBS_LAYOUTS[f.kind]
+        if max_episode_steps is None:         # config/sawyer.py: 250, config/pusher.py: 150 (the reference's per-env defaults)
+            max_episode_steps = 150 if env_name == "PusherObstacle-v0" else 250
         self.max_episode_steps = int(max_episode_steps)
         self.ac_scale = float(self.spec.ac_scale if ac_scale is None else ac_scale)
         L = _lib.lib()

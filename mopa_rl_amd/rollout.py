@@ -213,7 +213,7 @@ def wrap_unlimited(q, idx):
     for j in idx:
         a = q[:, j]
         m = torch.fmod(a, 3.14)                                           # a % 3.14 for a > 0, a % -3.14 for a <= 0 (sign of a either way)
-        k = torch.round((a - m) / torch.where(a > 0, 3.14, -3.14))       # a // +-3.14
+        k = torch.round((a - m) / torch.where(a > 0, a.new_tensor(3.14), a.new_tensor(-3.14)))       # a // +-3.14 (the divisor in a's float64)
         odd = torch.remainder(k, 2.0) != 0
         r = torch.where(odd, torch.where(a > 0, m - 3.14, m + 3.14), m)
         q[:, j] = torch.where(a == 0, torch.full_like(a, -0.0), r)        # (0.0 % -3.14 is -0.0 in Python)

@@ -12,7 +12,9 @@ def test_wrap_unlimited_equals_joint_convert_bit_for_bit():
     from mopa_rl_amd.sampling_based_planner import joint_convert
     rng = np.random.default_rng(0)
     k = np.arange(-13, 14) * 3.14
-    a = np.concatenate([rng.uniform(-40, 40, 20000), k, np.nextafter(k, np.inf), np.nextafter(k, -np.inf),
+    big = np.arange(-2000, 2001, 37) * 3.14                        # (large multiples: the divisor has to be 3.14 in float64, not float32's 3.1400001)
+    a = np.concatenate([rng.uniform(-40, 40, 20000), rng.uniform(-1e6, 1e6, 5000), big, np.nextafter(big, np.inf), np.nextafter(big, -np.inf),
+                        k, np.nextafter(k, np.inf), np.nextafter(k, -np.inf),
                         [0.0, -0.0, 3.14, -3.14, 6.28, -6.28, 1e-300, -1e-300, 3.1399999999999997, 3.1400000000000006]])
     q = torch.tensor(np.stack([a, a[::-1].copy(), a], axis=1))
     w = wrap_unlimited(q, [0, 2]).numpy()

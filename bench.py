@@ -31,7 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ENV = "SawyerPushObstacle-v0"
+ENV = os.environ.get("MOPA_BENCH_ENV", "SawyerPushObstacle-v0")      # (MOPA_BENCH_ENV: the per-scene K1 profiles of tools/profile.sh; the headline is Push)
 # algorithmic bytes per validity check = 7 f64 joint values read + 1 verdict byte
 # written + the env's qpos row (nq f64) amortised over the S states that share it.
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
@@ -630,6 +630,13 @@ def k1_sources_sha256():
     return h.hexdigest()
 
 
+def traffic_record_seal(rec):
+    """sha256 over every field of a traffic record but the seal itself (tools/make_traffic_json.py writes it with the record)"""
+    import hashlib
+    body = {k: v for k, v in rec.items() if k not in ("record_sha256", "source")}
+    return hashlib.sha256(json.dumps(body, sort_keys=True).encode()).hexdigest()
+
+
 def committed_traffic(kernel, n_states):
     """HBM-side traffic / VALU counts of the dominant kernel from the committed rocprofv3 PMC passes (tools/profile.sh ->
     tools/make_traffic_json.py -> profiles/rNN/k_is_valid_traffic.json); they cannot be collected from inside this process.
@@ -639,6 +646,11 @@ def committed_traffic(kernel, n_states):
     sha, src = lib_sha256(), k1_sources_sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "k_is_valid_traffic.json")), reverse=True):
         t = json.load(open(f))
+        if "record_sha256" in t and t["record_sha256"] != traffic_record_seal(t):
+            print(f"[bench] {os.path.relpath(f, ROOT)}: record edited after it was written (seal mismatch) -- ignored", file=sys.stderr)
+            continue
+        if "record_sha256" not in t and os.path.basename(os.path.dirname(f)) >= "r06":
+            continue          # (records of round 6 on carry the seal; older rounds' files predate it)
         same_build = t.get("lib_sha256") == sha or (t.get("k1_sources_sha256") is not None and t.get("k1_sources_sha256") == src)
         if same_build and t.get("states_per_launch") == n_states and t.get("kernel", "").startswith(kernel):
             t["source"] = os.path.relpath(f, ROOT)

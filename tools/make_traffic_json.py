@@ -3,7 +3,7 @@
 bench.py reads `roofline.traffic` / `roofline.valu` from.  The file is stamped with the sha256 of the libmopa_hip.so it was
 measured on (the library travels to the GPU box unchanged); bench.py ignores it for any other build.
 
-    python tools/make_traffic_json.py gpurun_out/prof_r02 profiles/r02 [kernel-name-prefix]
+    python tools/make_traffic_json.py gpurun_out/prof_r02 profiles/r02 [kernel-name-prefix [output-file-name]]
 """
 import csv
 import glob
@@ -44,11 +44,14 @@ if fetch is None or write is None:
 sha = hashlib.sha256(open(os.path.join(ROOT, "mopa_rl_amd", "csrc", "libmopa_hip.so"), "rb").read()).hexdigest()
 sys.path.insert(0, ROOT)
 import bench as _bench
+from mopa_rl_amd.scene import planner_inputs as _pi
+NQ = int(_pi(_bench.ENV).model.nq)          # (MOPA_BENCH_ENV selects the scene, as for the profiled bench run)
 out = {
     "kernel": kname, "states_per_launch": N, "lib_sha256": sha, "k1_sources_sha256": _bench.k1_sources_sha256(),
     "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "dispatches_averaged": [nf, nw, nv],
     "traffic_bytes_per_launch": int((fetch + write) * 1024),
-    "algorithmic_bytes_per_launch": int(N * (7 * 8 + 1 + 36 * 8 / 256)),
+    "algorithmic_bytes_per_launch": int(N * (7 * 8 + 1 + NQ * 8 / 256)),
+    "scene": _bench.ENV,
     "kernel_avg_ns_rocprof": avg_ns,
     "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/profile.sh), raw KB x 1024, mean per dispatch of the "
             "1 048 576-state launches; the guide's gfx950 half-count correction is calibrated for 16 B/lane streaming reads and is NOT "
@@ -57,6 +60,10 @@ out = {
 if valu is not None:
     out["valu_insts_per_launch"] = valu
     out["valu_note"] = "SQ_INSTS_VALU per dispatch (pmc_sq pass)"
+# both stamps (library, K1 sources) are written HERE, in the run that read the counters, and sealed: bench.py recomputes `record_sha256` over
+# every other field and ignores a record that does not carry its own seal (a stamp edited afterwards breaks it)
+out["record_sha256"] = _bench.traffic_record_seal(out)
 os.makedirs(dst, exist_ok=True)
-json.dump(out, open(os.path.join(dst, "k_is_valid_traffic.json"), "w"), indent=1)
+name = "k_is_valid_traffic.json" if len(sys.argv) <= 4 else sys.argv[4]
+json.dump(out, open(os.path.join(dst, name), "w"), indent=1)
 print(json.dumps(out, indent=1))

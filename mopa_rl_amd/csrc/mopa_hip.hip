@@ -1049,7 +1049,8 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
                 if (mb_parent[c] == k && !pas[c]) cont = true;
             if (!cont) mb_pas[k] |= 1 << 16;
         }
-        const bool on = pas_b.size() >= 4 && pas_b.size() <= 64 && pas_g.size() <= 64 && nlv <= 8 && !std::getenv("MOPA_V5_NO_TILE_POSES");
+        const size_t pas_min = std::getenv("MOPA_V5_TILE_MIN") ? (size_t)atoi(std::getenv("MOPA_V5_TILE_MIN")) : 4;      // (A/B knob)
+        const bool on = pas_b.size() >= pas_min && pas_b.size() <= 64 && pas_g.size() <= 64 && nlv <= 8 && !std::getenv("MOPA_V5_NO_TILE_POSES");
         h.n_pas_b = on ? (int)pas_b.size() : 0; h.n_pas_g = on ? (int)pas_g.size() : 0; h.n_pas_lv = on ? nlv : 0;
         h.o_pas_b = B.add_i(pas_b); h.o_pas_lv = B.add_i(pas_lv); h.o_mb_pas = B.add_i(mb_pas); h.o_pas_g = B.add_i(pas_g); h.o_mg_pas = B.add_i(mg_pas);
     }

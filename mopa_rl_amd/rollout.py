@@ -94,6 +94,9 @@ class RolloutConfig:
                                       # per SIMD): launches that took every slot would stall the main stream's kernels for their
                                       # whole bulk phase.  3 streams x 128 measured best on Push (tools/rollout_ab.sh: 1.03 M agent
                                       # steps/s; 3 x 64: 0.79 M, 2 x 256: 0.93 M)
+    planner_chain_workgroups: int = 0 # workgroups of the continuation launch behind a first-phase launch (0: planner_workgroups).  With planner_exclusive
+                                      # >= 1 that launch runs the workgroup-per-query build of K3 (four waves on a budget-exhausting query, the CU to itself):
+                                      # few workgroups keep the CUs it takes away from the main stream's kernels few
     planner_exclusive: int = 0        # 1: the full-budget launches (continuation of a first-phase launch / pooled retries), 2: every asynchronous
                                       # planner launch keeps its CUs to itself (C ABI `exclusive_cu`): the one-wave-per-SIMD build of K3 with the
                                       # FP32 tree mirror in the CU's whole LDS (a budget-exhausting query: 41 instead of 46+ ms)
@@ -410,7 +413,8 @@ class BatchMoPARollout:
                     job["event"] = torch.cuda.Event()
                     job["event"].record(stream)
                     rb = self.bp.plan(cur_f, target_f, max_iters=self.main_iters, max_nodes=cfg.max_nodes, max_path=cfg.max_path,
-                                      seed=cfg.seed, env_ids=gids, seeds=seeds, stream=stream, max_workgroups=cfg.planner_workgroups,
+                                      seed=cfg.seed, env_ids=gids, seeds=seeds, stream=stream,
+                                      max_workgroups=cfg.planner_chain_workgroups or cfg.planner_workgroups,
                                       resume=res[4], exclusive=cfg.planner_exclusive >= 1)
                     ev_b = torch.cuda.Event()
                     ev_b.record(stream)

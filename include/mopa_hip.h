@@ -505,6 +505,13 @@ typedef struct MopaRolloutStep {
 } MopaRolloutStep;
 int mopa_rollout_stage(const MopaRolloutStep *step, int32_t stage /*0..5*/, void *stream);
 int mopa_rollout_step_size(void);      /* sizeof(MopaRolloutStep) as the library was built (binding self-check) */
+/* The planner's pick-up of the waiting envs (rl/mopa_rollouts.py:205-209 for E envs: the envs whose straight line is blocked get an RRT-Connect
+ * query), one launch: out_count[0] <- number of set bytes of mask [E]; if min_n <= that <= cap: their indices ascending -> out_ids, rows of q_cur / q_tgt
+ * [E,nq] -> out_cur / out_tgt [cap,nq], t_env[ids] -> out_steps, t_env[ids] + seed -> out_seeds, and the mask bytes are cleared; otherwise nothing
+ * else is written (below min_n the pool waits; above cap the caller chooses which envs go first).  All buffers on the device; bool buffers are bytes. */
+int mopa_rollout_pool_pick(int64_t E, int32_t nq, int64_t min_n, int64_t cap, uint8_t *mask_dev, const double *q_cur_dev, const double *q_tgt_dev,
+                           const int64_t *t_env_dev, int64_t seed, int64_t *out_ids_dev, double *out_cur_dev, double *out_tgt_dev,
+                           int64_t *out_steps_dev, int64_t *out_seeds_dev, int64_t *out_count_dev, void *stream);
 
 /* The arm state the NEXT mopa_env_step_batch call with the same arguments would reach (desired_state clamped to ctrlrange
  * and joint limits), without stepping: input of a collision gate (mopa_is_valid_batch with samples_per_env = 1 -> move_mask). */

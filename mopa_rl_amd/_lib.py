@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "mopa_is_valid_batch", "mopa_check_motion_batch", "mopa_plan_batch", "mopa_pullback_batch", "mopa_is_valid_state", "mopa_plan",
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
-    "mopa_env_attach_dynamics", "mopa_env_attach_contacts", "mopa_env_set_contact_stats", "mopa_rollout_stage", "mopa_rollout_step_size", "mopa_ct_desc_size", "mopa_env_contact_arena", "mopa_env_dyn_dofs", "mopa_env_dyn_qvel_width", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
+    "mopa_env_attach_dynamics", "mopa_env_attach_contacts", "mopa_env_set_contact_stats", "mopa_rollout_stage", "mopa_rollout_pool_pick", "mopa_rollout_step_size", "mopa_ct_desc_size", "mopa_env_contact_arena", "mopa_env_dyn_dofs", "mopa_env_dyn_qvel_width", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
     "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch",
     "mopa_paths_unwrap_batch", "mopa_paths_unwrap_seam_batch", "mopa_paths_walk_batch", "mopa_paths_assemble_batch", "mopa_interpolate_batch",
 ]
@@ -187,6 +187,7 @@ def lib() -> C.CDLL:
     L.mopa_env_attach_contacts.argtypes = [vp, C.POINTER(MopaCtDesc)]
     L.mopa_env_set_contact_stats.argtypes = [vp, vp]
     L.mopa_rollout_stage.argtypes = [C.POINTER(MopaRolloutStep), C.c_int32, vp]
+    L.mopa_rollout_pool_pick.argtypes = [C.c_int64, C.c_int32, C.c_int64, C.c_int64] + [vp] * 4 + [C.c_int64] + [vp] * 7
     L.mopa_rollout_step_size.argtypes = []
     L.mopa_ct_desc_size.argtypes = []
     L.mopa_env_contact_arena.argtypes = [vp]

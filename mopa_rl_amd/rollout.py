@@ -382,16 +382,17 @@ class BatchMoPARollout:
     def _seam_steps_np(self, P):
         return seam_steps_np(P, self._seam_idx)
 
-    def _rrt_launch(self, cur_f, target_f, ids, stream=None, iters=None, keep=False, resume=None, chain=False):
+    def _rrt_launch(self, cur_f, target_f, ids, stream=None, iters=None, keep=False, resume=None, chain=False, steps=None, seeds=None):
         """RRT-Connect (K3) for the envs `ids` whose straight line is blocked (:205-209): asynchronous, optionally on a side
         stream.  The sample stream of a query is keyed by (cfg.seed + the env's own step count, env id), so an env's plans do
         not depend on which other envs are planned with it or when."""
         torch = _torch()
         cfg = self.cfg
-        seeds = (self.t_env[ids] + cfg.seed).contiguous()
+        if seeds is None:
+            seeds = (self.t_env[ids] + cfg.seed).contiguous()
         gids = (ids + int(cfg.env_id_base)).contiguous() if cfg.env_id_base else ids       # the planner's stream id: the GLOBAL env id
         iters = self.main_iters if iters is None else int(iters)
-        job = {"ids": ids, "cur": cur_f, "target": target_f, "steps": self.t_env[ids].clone(), "event": None, "stage": "rrt", "stream": stream,
+        job = {"ids": ids, "cur": cur_f, "target": target_f, "steps": self.t_env[ids].clone() if steps is None else steps, "event": None, "stage": "rrt", "stream": stream,
                "iters": iters}
         if self._seam_idx:       # the planner sees the wrapped endpoints; job["cur"] stays the caller's state
             cur_f, target_f = self._wrap_q(cur_f).contiguous(), self._wrap_q(target_f).contiguous()
@@ -983,12 +984,35 @@ class BatchMoPARollout:
                 # the count an earlier call left behind says a launch is due
                 if not (known[int(retry)] >= min_job or (known[int(retry)] > 0 and not kind_in_flight)):
                     continue
+            cap = cfg.planner_job_cap // 4 if retry else cfg.planner_job_cap
+            picked = None
+            if cfg.fused and cfg.async_planner and mask.is_cuda:
+                # the pick-up in one library launch (ids ascending as torch.nonzero lists them, mask cleared, start / target rows, step counts
+                # and seeds gathered) when the count lies within [what a launch waits for, the launch's cap]; one read-back as before
+                picked = self._pool_pick(mask, 1 if not kind_in_flight else min_job, cap)
+                if picked[0] == 0 or (picked[1] is None and picked[0] <= cap):
+                    continue          # nothing waits / too few: the pool waits for company
+            if picked is not None and picked[1] is not None:
+                n_p, bi, cur_p, tgt_p, steps_p, seeds_p = picked
+                if bool(self._interp_overflow):
+                    raise _lib.MopaError(f"a straight-line pre-check needed more than {self._k_interp} steps (targets further than "
+                                         "action_range from the current state?)")
+                iters = cfg.planner_first_iters if (two_phase and not retry) else self.main_iters
+                res_in = None
+                if retry and self._res is not None:
+                    from .batch import PlanState
+                    res_in = PlanState(self._res.tree_q, self._res.tree_p, self._res.state, cfg.max_nodes, self._res.na).rows(bi)
+                chain = bool(cfg.planner_chain) and two_phase and not retry and side is not None and cfg.device_paths and self.nq <= 64
+                job = self._rrt_launch(cur_p, tgt_p, bi, side, iters=iters, keep=two_phase and not retry and side is not None, resume=res_in,
+                                       chain=chain, steps=steps_p, seeds=seeds_p)
+                job["retry"] = retry
+                self._jobs.append(job)
+                continue
             bi = torch.nonzero(mask).flatten()
             if len(bi) and (not cfg.async_planner or len(bi) >= min_job or not kind_in_flight):
                 if bool(self._interp_overflow):
                     raise _lib.MopaError(f"a straight-line pre-check needed more than {self._k_interp} steps (targets further than "
                                          "action_range from the current state?)")
-                cap = cfg.planner_job_cap // 4 if retry else cfg.planner_job_cap
                 if cfg.async_planner and len(bi) > cap:
                     # the envs that have waited longest go first (a plain prefix would starve the high env indices whenever
                     # more envs wait than a launch takes)
@@ -1026,11 +1050,14 @@ class BatchMoPARollout:
                         x.record_stream(torch.cuda.current_stream())
             jid = job["ids"]
             t = lambda x: torch.as_tensor(x, device=dev)
-            s_t = t(s_j)
+            s_t, v_t, e_t = t(s_j), t(v_j), t(e_j)
+            # (everything below is index arithmetic over the job's rows with a `fin` mask -- no boolean-mask indexing: each `x[mask]` is a
+            #  torch.nonzero underneath, three launches, a memset and a read-back the host waits for)
+            fin = None
             if job["iters"] < self.main_iters:
                 # first-phase launch: "no exact solution" may only mean that the short budget ran out -- those queries run
                 # again with the full budget (their envs stay busy); everything else is final
-                again = ~s_t & ~t(e_j)
+                again = ~s_t & ~e_t
                 if "chain" in job:
                     # their continuation is already running behind this launch on its stream: a job of its own, finished at
                     # the second event
@@ -1048,22 +1075,25 @@ class BatchMoPARollout:
                                 x.record_stream(job["stream"])
                         still.append(lazy)
                 else:
-                    self._retry_mask[jid[again]] = True
+                    self._retry_mask[jid] = self._retry_mask[jid] | again
                     if "pstate" in job:
                         self._park_state(job["pstate"], jid, again)
                 self.n_retried = self.n_retried + again.sum()
-                keep = ~again
-                jid, s_t = jid[keep], s_t[keep]
-                tr_j, ln_j, v_j, e_j = t(tr_j)[keep], t(ln_j)[keep], t(v_j)[keep], t(e_j)[keep]
-            finished[jid] = True
+                fin = ~again
+            ok_f = s_t if fin is None else (s_t & fin)
+            bad_f = ~s_t if fin is None else (~s_t & fin)
+            finished[jid] = True if fin is None else fin
             n_fin += 1
-            plan_ok[jid] = s_t
-            self.counters["mp"][jid[s_t]] += 1
-            self.counters["mp_fail"][jid[~s_t]] += 1
-            self.counters["approximate"][jid[~s_t & ~t(e_j)]] += 1
-            self.counters["invalid"][jid[~s_t & ~t(v_j)]] += 1
-            traj_pad, path_len = self._merge_paths(traj_pad, path_len, tr_j, ln_j, jid)
-            self.busy[jid] = False
+            plan_ok[jid] = s_t if fin is None else torch.where(fin, s_t, plan_ok[jid])
+            self.counters["mp"].index_add_(0, jid, ok_f.to(self.counters["mp"].dtype))
+            self.counters["mp_fail"].index_add_(0, jid, bad_f.to(self.counters["mp_fail"].dtype))
+            self.counters["approximate"].index_add_(0, jid, (bad_f & ~e_t).to(self.counters["approximate"].dtype))
+            self.counters["invalid"].index_add_(0, jid, (bad_f & ~v_t).to(self.counters["invalid"].dtype))
+            ln_t = t(ln_j)
+            if fin is not None:      # (the rows of the queries that run again keep their length 0: their trajectory rows are never read)
+                ln_t = torch.where(fin, ln_t.to(path_len.dtype), path_len[jid])
+            traj_pad, path_len = self._merge_paths(traj_pad, path_len, t(tr_j), ln_t, jid)
+            self.busy[jid] = False if fin is None else (self.busy[jid] & ~fin)
         self._jobs = still
         mark("plan")
         bag.update(plan_ok=plan_ok, traj_pad=traj_pad, path_len=path_len, finished=finished, n_finished=n_fin)
@@ -1167,6 +1197,26 @@ class BatchMoPARollout:
             if not t.is_contiguous():
                 raise _lib.MopaError(f"rollout step buffer {k} is not contiguous")
             setattr(S, k, t.data_ptr())
+
+    def _pool_pick(self, mask, min_n: int, cap: int):
+        """mopa_rollout_pool_pick on the current stream: (count, ids, start rows, target rows, step counts, seeds) of the envs whose `mask` byte is
+        set -- the last five None when the count is outside [min_n, cap] (nothing was touched then)."""
+        torch = _torch()
+        from .batch import _stream_handle
+        dev = mask.device
+        ids = torch.empty(cap, dtype=torch.int64, device=dev)
+        cur = torch.empty(cap, self.nq, dtype=torch.float64, device=dev)
+        tgt = torch.empty(cap, self.nq, dtype=torch.float64, device=dev)
+        steps = torch.empty(cap, dtype=torch.int64, device=dev)
+        seeds = torch.empty(cap, dtype=torch.int64, device=dev)
+        cnt = torch.empty(1, dtype=torch.int64, device=dev)
+        _lib.check(_lib.lib().mopa_rollout_pool_pick(self.E, self.nq, int(min_n), int(cap), mask.data_ptr(), self._q_cur.data_ptr(), self._q_tgt.data_ptr(),
+                                                     self.t_env.data_ptr(), int(self.cfg.seed), ids.data_ptr(), cur.data_ptr(), tgt.data_ptr(),
+                                                     steps.data_ptr(), seeds.data_ptr(), cnt.data_ptr(), _stream_handle(None)))
+        n = int(cnt.item())
+        if n < min_n or n > cap:
+            return n, None, None, None, None, None
+        return n, ids[:n], cur[:n], tgt[:n], steps[:n], seeds[:n]
 
     def _pool_counts_known(self):
         """(envs waiting for a planner launch, for a retry launch) as of the latest earlier call whose bookkeeping has finished

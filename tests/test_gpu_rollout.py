@@ -557,3 +557,34 @@ def test_sharded_rollout_equals_the_unsharded_one():
     # ... and the ids matter: the second shard with rank-local ids (base 0) draws other streams
     wrong, _ = run(np.arange(E // G, E), 0, E // G)
     assert not np.array_equal(_bits(wrong), _bits(full[E // G:]))
+
+
+def test_pool_pick_kernel_equals_nonzero_and_gathers():
+    """round 6: mopa_rollout_pool_pick -- the planner's pick-up of the waiting envs in one launch -- against the torch operations it replaces
+    (nonzero, gathers, index_put), incl. the two ways it leaves everything untouched (fewer than min_n set, more than cap)"""
+    import torch
+    from mopa_rl_amd import _lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    for E, nq, p, min_n, cap in [(4096, 36, 0.05, 1, 2048), (4099, 34, 0.3, 64, 2048), (70, 16, 0.5, 1, 64), (4096, 36, 0.9, 1, 2048), (4096, 36, 0.01, 512, 2048), (64, 7, 0.0, 1, 16)]:
+        mask = torch.rand(E, generator=g, device=dev) < p
+        q_cur = torch.rand(E, nq, generator=g, dtype=torch.float64, device=dev)
+        q_tgt = torch.rand(E, nq, generator=g, dtype=torch.float64, device=dev)
+        t_env = torch.randint(0, 1000, (E,), generator=g, device=dev)
+        want = torch.nonzero(mask).flatten()
+        m2 = mask.clone()
+        ids = torch.full((cap,), -1, dtype=torch.int64, device=dev)
+        cur = torch.zeros(cap, nq, dtype=torch.float64, device=dev); tgt = torch.zeros_like(cur)
+        steps = torch.zeros(cap, dtype=torch.int64, device=dev); seeds = torch.zeros_like(steps)
+        cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        _lib.check(_lib.lib().mopa_rollout_pool_pick(E, nq, min_n, cap, m2.data_ptr(), q_cur.data_ptr(), q_tgt.data_ptr(), t_env.data_ptr(), 1234,
+                                                     ids.data_ptr(), cur.data_ptr(), tgt.data_ptr(), steps.data_ptr(), seeds.data_ptr(), cnt.data_ptr(), None))
+        torch.cuda.synchronize()
+        n = int(cnt.item())
+        assert n == len(want)
+        if min_n <= n <= cap:
+            assert torch.equal(ids[:n], want) and not bool(m2.any())
+            assert torch.equal(cur[:n], q_cur[want]) and torch.equal(tgt[:n], q_tgt[want])
+            assert torch.equal(steps[:n], t_env[want]) and torch.equal(seeds[:n], t_env[want] + 1234)
+        else:
+            assert torch.equal(m2, mask) and bool((ids == -1).all())

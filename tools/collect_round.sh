@@ -24,7 +24,7 @@ cp $G/k3_$TAG/pmc2_counter_collection_k3.csv $P/k3_pmc_sq2.csv
 cp $G/prof_${TAG}_k7/trace_kernel_stats.csv $P/k7_trace_kernel_stats.csv
 cp $G/prof_${TAG}_k7/pmc_sq_counter_collection_dyn.csv $P/k7_pmc_sq_counter_collection_dyn.csv
 cp $G/prof_${TAG}_k7/pmc_sq2_counter_collection.csv $P/k7_pmc_sq2_counter_collection.csv
-for f in parity_sweep plan_parity_sweep motion_parity_sweep ct_parity_sweep rollout_launches_per_call ct_bench ct_bench_pyramidal dyn_lanes_ab lone_wave k7_icache k3_build_ab ct_tail bench_line bench_line_full; do
+for f in parity_sweep plan_parity_sweep motion_parity_sweep ct_parity_sweep rollout_launches_per_call ct_bench ct_bench_pyramidal dyn_lanes_ab lone_wave k7_icache k3_build_ab ct_tail rollout_knobs bench_line bench_line_full; do
   [ -f $G/round_$TAG/$f.txt ] && cp $G/round_$TAG/$f.txt $P/$f.txt
   [ -f $G/round_$TAG/$f.json ] && cp $G/round_$TAG/$f.json $P/$f.json
 done

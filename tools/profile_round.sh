@@ -19,8 +19,8 @@ python tools/plan_parity_sweep.py 2>&1 | grep -v amdgpu.ids > $O/plan_parity_swe
 python tools/motion_parity_sweep.py 2>&1 | grep -v amdgpu.ids > $O/motion_parity_sweep.txt
 python tools/ct_parity_sweep.py 1024 4 2>&1 | grep -v amdgpu.ids > $O/ct_parity_sweep.txt
 python tools/count_launches.py 100 2>&1 | grep -v "amdgpu.ids\|Warning\|_warn_once" > $O/rollout_launches_per_call.txt
-python tools/ct_bench.py 4096 10 2>&1 | grep -v amdgpu.ids > $O/ct_bench.txt
-CT_OPTS='{"cone": "pyramidal"}' python tools/ct_bench.py 4096 10 2>&1 | grep -v amdgpu.ids > $O/ct_bench_pyramidal.txt
+python tools/ct_bench.py 4096 10 16 2>&1 | grep -v amdgpu.ids > $O/ct_bench.txt
+CT_OPTS='{"cone": "pyramidal"}' python tools/ct_bench.py 4096 10 8 2>&1 | grep -v amdgpu.ids > $O/ct_bench_pyramidal.txt
 python tools/dyn_lanes_ab.py 2>&1 | grep -v amdgpu.ids > $O/dyn_lanes_ab.txt
 tools/ubench/bin/lone_wave > $O/lone_wave.txt 2>&1
 bash tools/k7_icache.sh ${TAG}_k7ic > $O/k7_icache.txt 2>&1

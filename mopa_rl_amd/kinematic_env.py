@@ -529,6 +529,10 @@ class BatchKinematicEnv:
         P = int(pool_factor) * E
         if self._pool_upper + E > self._pool.shape[0]:
             used = min(int(self._pool_cursor.item()), self._pool.shape[0])
+            if used + E <= self._pool.shape[0]:
+                self._pool_upper = used          # (masked resets consumed far less than the bound assumed: no refill yet)
+        if self._pool_upper + E > self._pool.shape[0]:
+            used = min(int(self._pool_cursor.item()), self._pool.shape[0])
             parts, have = [self._pool[used:]], self._pool.shape[0] - used
             lo = torch.tensor([-0.35, 0.13], dtype=f64, device=dev)
             hi = torch.tensor([-0.24, 0.2], dtype=f64, device=dev)

@@ -1435,3 +1435,75 @@ class BatchMoPARollout:
             if job["event"] is not None:
                 job["event"].synchronize()
 
+
+    def run_episode(self, policy, max_step: int = 10000, is_train: bool = True, random_exploration: bool = False, reset: bool = True):
+        """`MoPARolloutRunner.run_episode` (reference rl/mopa_rollouts.py:401-678: the evaluation loop -- ONE episode, `while not done
+        and ep_len < max_step`, every agent step the same routing as `run`) for all E envs at once: each env runs one episode from
+        `env.reset()` (`reset=False`: from the state the env is in) and sits out once its episode is over (it gets the zero action
+        and nothing of it is recorded any more).  Lock-step only: a call is one agent step of every env still in its episode.
+
+        policy(ob [E, obs_dim], is_train=..., random_exploration=...) -> ac [E, >= ac_dim] (float64, in [-1, 1]; with
+        `discrete_action` a pair (ac, ac_type [E])) -- the batched `pi.act` (:432-437).
+
+        What differs from `run`, as in the reference: the per-step reward of a planner step is the PLAIN sum of its waypoints'
+        rewards (`meta_rew += reward`, :540 -- not the discounted SMDP return of :171), a failed plan is one step with the current
+        reward (:594-611), no `reuse_data` transitions.  Returns (rollout, ep_info):
+          rollout  ob [T + 1, E, obs_dim] (row t = the obs an env's t-th agent step started from; the row after its last step = the
+                   final obs: `rollout.add({"ob": ll_ob})`, :661), ac [T, E, ac_dim], rew [T, E], done [T, E] uint8, valid [T, E] bool
+                   (env e took an agent step in call t), n_steps [E], qpos_final [E, nq] (the state each episode ended in) -- the reference's
+                   evaluation rollout holds ob / ac of planner steps only (:577-585 against :648-653), this one of every step;
+          ep_info  len, rew (:663-670), success (the env's `episode_success`), and the six counters (:671), one entry per env.
+        `contact_force` (:538, MuJoCo's contact solver forces) has no kinematic counterpart and is not reported.  `max_step` below the
+        env's own episode cap would cut a path between two waypoints (:575): build the env with that cap instead."""
+        torch = _torch()
+        env, cfg, E = self.env, self.cfg, self.E
+        if cfg.async_planner:
+            raise _lib.MopaError("run_episode is the lock-step evaluation loop (async_planner=False)")
+        if max_step < env.max_episode_steps:
+            raise _lib.MopaError(f"max_step {max_step} < the env's max_episode_steps {env.max_episode_steps}: make the env with that episode cap")
+        dev = env.device
+        if reset:
+            env.reset()
+        gamma, disc_cache = cfg.discount_factor, self._disc
+        cfg.discount_factor, self._disc = 1.0, {}
+        try:
+            alive = torch.ones(E, dtype=torch.bool, device=dev)
+            ep_len = torch.zeros(E, dtype=torch.int64, device=dev)
+            ep_rew = torch.zeros(E, dtype=torch.float64, device=dev)
+            cnt = {k: torch.zeros(E, dtype=torch.int64, device=dev) for k in COUNTERS}
+            success = torch.zeros(E, dtype=torch.bool, device=dev)
+            obs, acs, rews, dones, valids = [], [], [], [], []
+            last_ob, last_q = env.obs.clone(), env.qpos.clone()
+            while True:
+                got = policy(env.obs.clone(), is_train=is_train, random_exploration=random_exploration)
+                ac, ac_type = got if cfg.discrete_action else (got, None)
+                ac = torch.where(alive[:, None], ac.to(torch.float64), torch.zeros_like(ac, dtype=torch.float64)).contiguous()
+                if ac_type is not None:
+                    ac_type = torch.where(alive, ac_type.reshape(-1).to(torch.int64), torch.zeros(E, dtype=torch.int64, device=dev))
+                before = {k: self.counters[k].clone() for k in COUNTERS}
+                out = self.agent_step(ac, ac_type=ac_type)
+                ep_len += torch.where(alive, out["intra_steps"] + 1, torch.zeros_like(ep_len))
+                ep_rew += torch.where(alive, out["rew"], torch.zeros_like(ep_rew))
+                for k in COUNTERS:
+                    cnt[k] += torch.where(alive, self.counters[k] - before[k], torch.zeros_like(cnt[k]))
+                success |= alive & out["success"].bool()
+                obs.append(torch.where(alive[:, None], out["ob"], last_ob))
+                acs.append(out["ac"].clone())
+                rews.append(torch.where(alive, out["rew"], torch.zeros_like(out["rew"])))
+                dones.append(torch.where(alive, out["done"].to(torch.uint8), torch.zeros_like(out["done"], dtype=torch.uint8)))
+                valids.append(alive.clone())
+                last_ob = torch.where(alive[:, None], out["ob_next"], last_ob)
+                last_q = torch.where(alive[:, None], env.qpos, last_q)
+                alive = alive & ~(out["done"].bool() | (ep_len >= max_step))
+                if not bool(alive.any()):         # (one host read per agent step: this is the evaluation loop, not the training one)
+                    break
+            obs.append(last_ob)
+        finally:
+            cfg.discount_factor, self._disc = gamma, disc_cache
+        valid = torch.stack(valids)
+        # row n_steps[e] of `ob` = env e's final obs; rows beyond it repeat it
+        ob_t = torch.stack(obs)
+        rollout = {"ob": ob_t, "ac": torch.stack(acs), "rew": torch.stack(rews), "done": torch.stack(dones), "valid": valid,
+                   "n_steps": valid.sum(0), "qpos_final": last_q}
+        ep_info = {"len": ep_len, "rew": ep_rew, "success": success, **cnt}
+        return rollout, ep_info

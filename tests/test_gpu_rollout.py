@@ -588,3 +588,50 @@ def test_pool_pick_kernel_equals_nonzero_and_gathers():
             assert torch.equal(steps[:n], t_env[want]) and torch.equal(seeds[:n], t_env[want] + 1234)
         else:
             assert torch.equal(m2, mask) and bool((ids == -1).all())
+
+
+@pytest.mark.parametrize("env_name,tag", [("SawyerPushObstacle-v0", "push"), ("SawyerLiftObstacle-v0", "lift")])
+def test_run_episode_equals_reference_evaluation_loop(env_name, tag):
+    """`BatchMoPARollout.run_episode` against the REFERENCE'S OWN `MoPARolloutRunner.run_episode` (rl/mopa_rollouts.py:401-678), run
+    in the build container env by env on the same scripted actions from the same start states (tests/golden/ref_py_episode_*.npz,
+    tools/gen_ref_py_golden.py `episode`): whole episodes, free-running -- nothing is re-loaded between agent steps.  Agent steps per
+    episode, episode length, the six counters, done flags and success must be identical; per-step rewards (plain sums over a path's
+    waypoints, not the SMDP return) and the episode reward agree to round-off; the final joint state is identical bit for bit in
+    episodes without an invalid-target back-off and to 1e-12 in the others (see _check_qpos)."""
+    import torch
+    from mopa_rl_amd.rollout import COUNTERS
+    G = np.load(os.path.join(GOLD, f"ref_py_episode_{tag}.npz"))
+    E, T = G["ac"].shape[:2]
+    env, ro = _make(G, E, env_name)
+    _load_state(env, G["qpos_start"][:, 0], np.zeros(E, dtype=np.int64))
+    AC = torch.tensor(G["ac"], device=env.device)
+    calls = {"t": 0}
+
+    def policy(ob, is_train=True, random_exploration=False):
+        t = calls["t"]
+        calls["t"] += 1
+        assert is_train and not random_exploration
+        return AC[:, t] if t < T else torch.zeros_like(AC[:, 0])
+
+    gamma = ro.cfg.discount_factor
+    rollout, info = ro.run_episode(policy, reset=False)
+    assert ro.cfg.discount_factor == gamma                      # (the loop sums rewards undiscounted and restores the SMDP discount)
+    n = G["n_steps"]
+    assert np.array_equal(rollout["n_steps"].cpu().numpy(), n), "agent steps per episode"
+    assert calls["t"] == int(n.max()) and rollout["valid"].shape[0] == int(n.max())
+    assert np.array_equal(info["len"].cpu().numpy(), G["ep_len"]), "episode length"
+    assert np.array_equal(np.stack([info[k].cpu().numpy() for k in COUNTERS], axis=1), G["counters"]), "counters"
+    assert np.array_equal(info["success"].cpu().numpy().astype(np.int64), G["ep_success"])
+    valid = rollout["valid"].cpu().numpy().T                     # [E, Tn]
+    Tn = valid.shape[1]
+    assert np.array_equal(valid, np.arange(Tn)[None, :] < n[:, None])
+    assert np.array_equal(rollout["done"].cpu().numpy().T.astype(np.int64)[valid], G["done"][:, :Tn][valid]), "done flags"
+    np.testing.assert_allclose(rollout["rew"].cpu().numpy().T[valid], G["rew"][:, :Tn][valid], rtol=1e-12, atol=1e-13, err_msg="per-step rewards")
+    np.testing.assert_allclose(info["rew"].cpu().numpy(), G["ep_rew"], rtol=1e-12, atol=1e-12, err_msg="episode reward")
+    pulled = G["pulled_back"].sum(1)
+    _check_qpos(rollout["qpos_final"].cpu().numpy(), G["qpos_final"], pulled, "final joint state")
+    # the obs each agent step started from, and the final obs (`rollout.add({"ob": ll_ob})`, :661)
+    ob = rollout["ob"].cpu().numpy()                             # [Tn + 1, E, obs_dim]
+    np.testing.assert_allclose(ob[:Tn].transpose(1, 0, 2)[valid], G["ob"][:, :Tn][valid], rtol=1e-12, atol=1e-12, err_msg="obs before each step")
+    np.testing.assert_allclose(ob[n, np.arange(E)], G["ob_final"], rtol=1e-12, atol=1e-12, err_msg="final obs")
+    env.close(); ro.close()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/ref_py_*.npz by IMPORTING THE REFERENCE'S PYTHON (build container only).
 
-    python tools/gen_ref_py_golden.py [section ...]        # sections: host agent rollout env ik (default: all)
+    python tools/gen_ref_py_golden.py [section ...]        # sections: host agent rollout env ik episode ... (default: all)
 
 The reference's native arithmetic (MuJoCo 2.0, OMPL) is absent from this image, but the layers above it are plain
 Python/numpy and can run here once their imports are satisfied (tools/refshim.py: module stubs, an oracle-backed
@@ -538,6 +538,85 @@ def gen_rollout(env_name="SawyerPushObstacle-v0", tag="push", E=32, T=5, reuse=F
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# section "episode": rl/mopa_rollouts.py:MoPARolloutRunner.run_episode (the evaluation loop, :401-678), env by env, scripted actions
+# ------------------------------------------------------------------------------------------------------------------
+def gen_episode(env_name="SawyerPushObstacle-v0", tag="push", E=24, discrete=False):
+    """One whole episode per env through the reference's `run_episode` (max_step 10000, is_train=True): what it returns -- the rollout's
+    rew / done lists, ep_info's len / rew / counters / episode_success -- plus the joint state at every policy call and at the end.
+    `get_contact_force` (MuJoCo's contact solver, env/base.py:568) is set to 0: no kinematic counterpart."""
+    import util.env as ref_util_env
+    from rl.mopa_rollouts import MoPARolloutRunner
+    ref_util_env.np = refshim.NumpyCompat()
+    P = ROLLOUT_PARAMS
+    cfg = make_config(env_name, timelimit=P["timelimit"], num_trials=P["num_trials"], discrete_action=discrete, stochastic_eval=False)
+    n_ac = 8 if env_name == "SawyerLiftObstacle-v0" else 7
+    agent, pi = make_agent(env_name, cfg, ac_dim=n_ac)
+    st = Streams(agent, E, P["seed"], P["max_nodes"], P["max_path"])
+    rng = np.random.default_rng(23)
+    T = P["max_episode_steps"]                      # an agent step takes at least one env step
+    AC = rng.uniform(-1, 1, size=(E, T, n_ac)) * rng.choice([0.5, 0.68, 0.9, 1.0], size=(E, T, 1))
+    AC[: E // 3, 1::3, 1] = 1.0                     # far targets towards the table / bin: blocked lines, invalid targets, failed plans
+    AC[: E // 3, 1::3, 3] = -1.0
+    AC_TYPE = rng.integers(0, 2, size=(E, T)) if discrete else None
+    nq = pi.model.nq
+    out = dict(ac=AC, qpos_start=np.zeros((E, T, nq)), qpos_final=np.zeros((E, nq)), n_steps=np.zeros(E, dtype=np.int64),
+               rew=np.zeros((E, T)), done=np.zeros((E, T), dtype=np.int64), pulled_back=np.zeros((E, T), dtype=np.int64),
+               ep_len=np.zeros(E, dtype=np.int64), ep_rew=np.zeros(E), ep_success=np.zeros(E, dtype=np.int64),
+               counters=np.zeros((E, len(COUNTERS)), dtype=np.int64), ob=None, ob_final=None)
+    for e in range(E):
+        env = make_ref_env(env_name, seed=300 + e, max_episode_steps=P["max_episode_steps"])
+        env.get_contact_force = lambda: 0.0
+        env.color_agent = env.reset_color_agent = lambda: None          # geom_rgba only (rendering)
+        state = {"t": -1}
+
+        def act(ob, is_train=True, return_stds=False, random_exploration=False, e=e, env=env, state=state):
+            state["t"] += 1
+            t = state["t"]
+            st.begin(e, t)
+            out["qpos_start"][e, t] = env.sim.data.qpos
+            fo = flat_ob(ob)
+            if out["ob"] is None:
+                out["ob"], out["ob_final"] = np.zeros((E, T, len(fo))), np.zeros((E, len(fo)))
+            out["ob"][e, t] = fo
+            a = OrderedDict(default=AC[e, t].copy())
+            if discrete:
+                a["ac_type"] = np.array([int(AC_TYPE[e, t])])
+            if (bool(AC_TYPE[e, t]) if discrete else agent.is_planner_ac(a)):
+                n = len(env.ref_joint_pos_indexes)
+                tq = env.sim.data.qpos.copy()
+                tq[env.ref_joint_pos_indexes] += agent.convert2planner_displacement(a["default"][:n], env._ac_scale)
+                tq = np.clip(tq, env._jnt_minimum[env.jnt_indices], env._jnt_maximum[env.jnt_indices])
+                out["pulled_back"][e, t] = int(not agent.isValidState(tq))
+            return a, None, None
+
+        agent.act = act
+        runner = object.__new__(MoPARolloutRunner)
+        runner._config, runner._env, runner._env_eval, runner._pi, runner._ik_env = cfg, env, None, agent, None
+        rollout, info, _frames = runner.run_episode(max_step=10000, is_train=True, record=False)
+        n = state["t"] + 1
+        # (the evaluation loop adds ob / ac to its rollout for planner steps only, :577-585 vs :648-653: the lists of rew / done are complete)
+        assert len(rollout["rew"]) == n and len(rollout["done"]) == n
+        out["n_steps"][e] = n
+        out["rew"][e, :n], out["done"][e, :n] = rollout["rew"], np.asarray(rollout["done"], dtype=np.int64)
+        out["ob_final"][e] = flat_ob(rollout["ob"][-1])
+        out["qpos_final"][e] = env.sim.data.qpos
+        out["ep_len"][e], out["ep_rew"][e] = info["len"], info["rew"]
+        out["ep_success"][e] = int(info.get("episode_success", 0))
+        out["counters"][e] = [info[k] for k in COUNTERS]
+    print(f"  episode[{tag}]: agent steps / episode", out["n_steps"].tolist(), "len", out["ep_len"].tolist(), "counters",
+          dict(zip(COUNTERS, out["counters"].sum(0).tolist())), "success", int(out["ep_success"].sum()), "pulled back", int(out["pulled_back"].sum()))
+    if discrete:
+        out["ac_type"] = AC_TYPE
+    save(f"ref_py_episode_{tag}{'_discrete' if discrete else ''}.npz",
+         params=np.array([P["timelimit"], P["max_nodes"], P["max_path"], P["seed"], P["max_episode_steps"], P["num_trials"]]), **out)
+
+
+def gen_episodes():
+    gen_episode()
+    gen_episode("SawyerLiftObstacle-v0", "lift", E=16)
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # section "ik": env/inverse_kinematics.py:qpos_from_site_pose (+ nullspace_method) on the reference env over FakeSim (f3)
 # ------------------------------------------------------------------------------------------------------------------
 def gen_ik():
@@ -722,7 +801,7 @@ def gen_rollout_pusher():
     gen_rollout("PusherObstacle-v0", "pusher", E=24, T=5)
 
 
-SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env, env_pusher=gen_env_pusher, rollout_pusher=gen_rollout_pusher)
+SECTIONS = OrderedDict(host=gen_host, agent=gen_agent, rollout=gen_rollouts, ik=gen_ik, env=gen_env, env_pusher=gen_env_pusher, rollout_pusher=gen_rollout_pusher, episode=gen_episodes)
 
 
 def main():

@@ -1304,7 +1304,10 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
         if (S->n_mesh_gp > 0) {
             // second pass: the mesh pairs only (MESH instantiation), verdict AND-ed / depth min-ed into the first pass's
             auto km = min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>;
-            hipLaunchKernelGGL(km, grid, block, S->v2_lds_bytes, st, S->hdr_mesh, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
+            // (the MESH instantiation holds one wave per SIMD: n_cu workgroups are all that run at once, and the gated pass sizes its tiles by
+            //  the waves of the launch -- a second round of workgroups would only find the counter exhausted)
+            const dim3 grid_m(mesh_list ? std::min<unsigned>(grid.x, (unsigned)S->n_cu) : grid.x);
+            hipLaunchKernelGGL(km, grid_m, block, S->v2_lds_bytes, st, S->hdr_mesh, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
                                (long long)samples_per_env, valid, min_dist, d_slab, 1, env_idx, (const long long *)mesh_list, d_ctr);
         }
         HIP_TRY(hipGetLastError());

@@ -529,6 +529,17 @@ __device__ __forceinline__ void coop_fold(double &bd, int &best) {
         const int oi = __builtin_amdgcn_update_dpp(0, best, 0x4E, 0xf, 0xf, false);
         if ((MAXIMUM ? od > bd : od < bd) || (od == bd && oi < best)) { bd = od; best = oi; }
     }
+    // (the four lanes of a quad now agree; a mirror pairs whole quads, whichever of their lanes meet)
+    if (G >= 8) {
+        const double od = dpp_quad_f64<0x141>(bd);              // row_half_mirror: lane 7 - l of the aligned eight
+        const int oi = __builtin_amdgcn_update_dpp(0, best, 0x141, 0xf, 0xf, false);
+        if ((MAXIMUM ? od > bd : od < bd) || (od == bd && oi < best)) { bd = od; best = oi; }
+    }
+    if (G >= 16) {
+        const double od = dpp_quad_f64<0x140>(bd);              // row_mirror: lane 15 - l of the row
+        const int oi = __builtin_amdgcn_update_dpp(0, best, 0x140, 0xf, 0xf, false);
+        if ((MAXIMUM ? od > bd : od < bd) || (od == bd && oi < best)) { bd = od; best = oi; }
+    }
 }
 #endif
 template <int G = 1>
@@ -537,10 +548,11 @@ MOPA_HD V3 mesh_support_local(const double *g, V3 ld, const double *aux) {
     const int n = (int)g[GO_SIZE + 1];
 #if defined(__HIP_DEVICE_COMPILE__)
     if (G > 1) {
-        static_assert(G == 1 || G == 2 || G == 4, "groups are quads or pairs of lanes");
+        static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16, "groups are aligned pairs / quads / eights / rows of lanes");
         const int sub = (int)(threadIdx.x & (G - 1));
         int best = sub < n ? sub : 0;
         double bd = dot3(ld, ld3(V + 3 * best));
+#pragma unroll 4
         for (int i = best + G; i < n; i += G) {
             const double d = dot3(ld, ld3(V + 3 * i));
             if (d > bd) { bd = d; best = i; }

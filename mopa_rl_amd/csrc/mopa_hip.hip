@@ -93,7 +93,8 @@ struct StreamScratch {
     DevBuf mpr;         // v5: per-wave ring of deferred cylinder pairs
     DevBuf cen;         // v5, scenes whose FP32 centre table does not fit LDS: the per-wave tables in global memory
     DevBuf k1_ctr;      // validity kernels' tile counter + exit count (self-resetting: tile_ctr_release)
-    DevBuf mesh_list;   // [0] = count, then the states with a mesh pair past the main pass's broad phase
+    DevBuf mesh_list;   // [0] = number of rows in mesh_rows, [1] = count, then the states with a mesh pair past the main pass's broad phase
+    DevBuf mesh_rows;   // complete records of the mesh pairs within reach ([cap][kMprRow] doubles; k_mesh_rows)
     size_t slab_waves = 0;
     DevBuf mv_cnt, mv_off, mv_env, mv_q, mv_valid, mv_scan;   // expanded motion validation (mopa_motion.inc)
     DevBuf plan_q, plan_p, plan_ctr;                          // planner: both trees of every env, env counter (mopa_planner.inc)
@@ -105,6 +106,7 @@ struct MopaScene {
     int device = 0;
     SceneHdr hdr{};
     SceneHdr hdr_mesh{};      // same scene, per-geom pair lists = the mesh pairs only (second pass of the lane-per-state kernels)
+    int n_mesh_dbl = 0;       // doubles of the hull-vertex block at hdr.o_mesh (k_mesh_rows stages it in LDS)
     int n_mesh_gp = 0;
     std::vector<double> h_dbl;
     std::vector<int32_t> h_int;
@@ -983,6 +985,7 @@ extern "C" int mopa_scene_create(const MopaSceneDesc *desc, MopaScene **out) {
     if (m.nmesh > 0) {
         h.has_mesh = 1;
         h.o_mesh = B.add_d(std::vector<double>(m.mesh_vert, m.mesh_vert + 3 * (size_t)m.nmeshvert));
+        S->n_mesh_dbl = 3 * (int)m.nmeshvert;
         for (int g = 0; g < m.ngeom; g++)
             if (m.geom_type[g] == G_MESH) {
                 double *rec = &g_rec[(size_t)kGeomStride * g];
@@ -1200,7 +1203,7 @@ extern "C" void mopa_scene_destroy(MopaScene *S) {
         if (q) (void)hipFree(q);
     for (auto &kv : S->scratch) {
         StreamScratch &sc = kv.second;
-        for (DevBuf *b : {&sc.slab, &sc.mpr, &sc.cen, &sc.mesh_list, &sc.mv_cnt, &sc.mv_off, &sc.mv_env, &sc.mv_q, &sc.mv_valid, &sc.mv_scan, &sc.plan_q,
+        for (DevBuf *b : {&sc.slab, &sc.mpr, &sc.cen, &sc.mesh_list, &sc.mesh_rows, &sc.mv_cnt, &sc.mv_off, &sc.mv_env, &sc.mv_q, &sc.mv_valid, &sc.mv_scan, &sc.plan_q,
                           &sc.plan_p, &sc.plan_ctr, &sc.pb_small, &sc.pb_rows, &sc.pb_act, &sc.ip_walk})
             if (b->p) (void)hipFree(b->p);
     }
@@ -1280,10 +1283,19 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
 #endif
         auto kern = min_dist ? k_is_valid_v2<true, false> : k_is_valid_v2<false, false>;   // main lists carry no mesh pair
         long long *mesh_list = nullptr;
+        unsigned long long *rows_cnt = nullptr;
+        double *mesh_rows = nullptr;
+        // rows the gate may hand over per launch (typically 1-2 % of the states have one): beyond it a state goes to the state list
+        const long long rows_cap = std::getenv("MOPA_MESH_ROWS_CAP") ? atoll(std::getenv("MOPA_MESH_ROWS_CAP")) : std::max<long long>(4096, (long long)N / 2);
         if (S->use_v5 && !S->v5_cen_lds && S->n_mesh_gp > 0) {
-            HIP_TRY(grow(S, sc.mesh_list, ((size_t)N + 1) * sizeof(long long)));
-            mesh_list = sc.mesh_list.as<long long>();
-            HIP_TRY(zero_async(mesh_list, sizeof(long long), st));
+            HIP_TRY(grow(S, sc.mesh_list, ((size_t)N + 2) * sizeof(long long)));
+            rows_cnt = sc.mesh_list.as<unsigned long long>();
+            mesh_list = sc.mesh_list.as<long long>() + 1;
+            HIP_TRY(zero_async(rows_cnt, 2 * sizeof(long long), st));
+            if (rows_cap > 0) {
+                HIP_TRY(grow(S, sc.mesh_rows, (size_t)rows_cap * kMprRow * sizeof(double)));
+                mesh_rows = sc.mesh_rows.as<double>();
+            }
         }
         // a device-side count stops the main pass at *n_dev; an ungated mesh pass would still walk all N worst-case rows
         // (uninitialised candidates beyond *n_dev): only the gated form (work list built by the main pass) is served
@@ -1297,7 +1309,14 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             if (min_dist) hk.v5_ent_cap = S->v5_ent_cap_md;
             hipLaunchKernelGGL(k5, grid, block, min_dist ? S->v5_lds_bytes_md : S->v5_lds_bytes, st, hk, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
                                (long long)N, (long long)samples_per_env, valid, min_dist, d_slab, env_idx, sc.mpr.as<double>(), mesh_list, sc.cen.as<float>(),
-                               n_dev, d_ctr);
+                               n_dev, d_ctr, mesh_list ? mesh_rows : nullptr, rows_cap, rows_cnt);
+            if (mesh_list && mesh_rows) {
+                auto kr = min_dist ? k_mesh_rows<true> : k_mesh_rows<false>;
+                // (159 registers: three waves per SIMD -- the rows are latency chains, so all the slots are offered; idle waves leave at once)
+                static const int rows_blocks = std::getenv("MOPA_MESH_ROWS_BLOCKS") ? atoi(std::getenv("MOPA_MESH_ROWS_BLOCKS")) : 0;
+                hipLaunchKernelGGL(kr, dim3((unsigned)(rows_blocks > 0 ? rows_blocks : 3 * S->n_cu)), block, (size_t)S->n_mesh_dbl * sizeof(double), st, S->hdr, S->d_dbl, (const double *)mesh_rows,
+                                   (const unsigned long long *)rows_cnt, rows_cap, S->n_mesh_dbl, valid, min_dist);
+            }
         } else
         hipLaunchKernelGGL(kern, grid, block, S->v2_lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
                            (long long)samples_per_env, valid, min_dist, d_slab, 0, env_idx, (const long long *)nullptr, d_ctr);
@@ -1306,16 +1325,19 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             auto km = min_dist ? k_is_valid_v2<true, true> : k_is_valid_v2<false, true>;
             // (the MESH instantiation holds one wave per SIMD: n_cu workgroups are all that run at once, and the gated pass sizes its tiles by
             //  the waves of the launch -- a second round of workgroups would only find the counter exhausted)
-            const dim3 grid_m(mesh_list ? std::min<unsigned>(grid.x, (unsigned)S->n_cu) : grid.x);
+            // (with the row list in front of it the gated pass only serves the states whose rows did not fit: a quarter of the CUs)
+            static const int fb_blocks = std::getenv("MOPA_MESH_FALLBACK_BLOCKS") ? atoi(std::getenv("MOPA_MESH_FALLBACK_BLOCKS")) : 0;
+            const unsigned fb = fb_blocks > 0 ? (unsigned)fb_blocks : (mesh_rows ? (unsigned)std::max(1, S->n_cu / 4) : (unsigned)S->n_cu);
+            const dim3 grid_m(mesh_list ? std::min<unsigned>(grid.x, fb) : grid.x);
             hipLaunchKernelGGL(km, grid_m, block, S->v2_lds_bytes, st, S->hdr_mesh, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
                                (long long)samples_per_env, valid, min_dist, d_slab, 1, env_idx, (const long long *)mesh_list, d_ctr);
         }
         HIP_TRY(hipGetLastError());
         if (mesh_list && std::getenv("MOPA_DEBUG_MESH")) {     // diagnostics: how many states the gate lets through
-            long long cnt = 0;
+            long long cnt[2] = {0, 0};
             (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(&cnt, mesh_list, sizeof(cnt), hipMemcpyDeviceToHost);
-            fprintf(stderr, "[mopa] mesh gate: %lld of %lld states go to the second pass\n", cnt, (long long)N);
+            (void)hipMemcpy(cnt, mesh_list - 1, sizeof(cnt), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[mopa] mesh gate: %lld rows handed to k_mesh_rows (cap %lld), %lld of %lld states go to the second pass\n", cnt[0], rows_cap, cnt[1], (long long)N);
         }
 #ifdef MOPA_V2_PROFILE
         {

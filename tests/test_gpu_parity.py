@@ -159,6 +159,44 @@ def test_plane_pairs_and_per_env_objects(kernel, oracle_mod):
         assert sc.is_valid_state(qf, want_min_dist=True) == (bool(ov[e * S + 3]), omd[e * S + 3])
 
 
+@pytest.mark.parametrize("cap", [0, 64, 100000])
+def test_lift_mesh_row_list_and_its_overflow(cap, oracle_mod, monkeypatch):
+    """The gate of k_is_valid_v5 hands the mesh pairs within reach to k_mesh_rows as complete records; rows beyond the list's capacity
+    put their state on the state list of the second (MESH) pass instead.  With the can parked at the gripper of most envs (thousands of
+    rows) the verdicts and depths must equal the oracle's whether every row fits (cap 100000), almost none does (64), or the row list is
+    off (0: every state with a mesh pair within reach goes through the state-list pass)."""
+    import torch
+    from mopa_rl_amd.batch import BatchPlanner
+    monkeypatch.setenv("MOPA_MESH_ROWS_CAP", str(cap))          # (read per call)
+    env = "SawyerLiftObstacle-v0"
+    pi, sc, orc = _mk(env, oracle_mod, "v5")
+    m = pi.model
+    bp = BatchPlanner(sc)
+    E, S = 48, 256
+    qa, row = sample_states(pi, E * S, 77, "near")
+    rows = np.repeat(row, E, axis=0)
+    ca = m.get_joint_qpos_addr("cube")
+    rng = np.random.default_rng(5)
+    names = [m.all_geom_names[i] for i in m.geom_mjid]
+    claw = [i for i, n in enumerate(names) if "claw" in n or "finger" in n][0]
+    for e in range(40):
+        base = qa[e * S].copy()
+        qa[e * S:(e + 1) * S] = np.clip(base + rng.normal(0, 0.05, (S, len(base))), pi.jnt_minimum, pi.jnt_maximum)
+        gpos, _ = orc.fk(_full(pi, base, row[0]))
+        rows[e, ca:ca + 3] = gpos[claw] + rng.normal(0, 0.04, 3)
+    quat = rng.normal(size=(40, 4))
+    rows[:40, ca + 3:ca + 7] = quat / np.linalg.norm(quat, axis=1, keepdims=True)
+    ov, omd = orc.is_valid_batch(qa, rows, samples_per_env=S, nthreads=0)
+    tq, tr = torch.from_numpy(qa).cuda(), torch.from_numpy(rows).cuda()
+    for _ in range(2):          # (twice: the counters of the row list / the state list are reset per call)
+        v, md = bp.is_valid(tq, tr, samples_per_env=S, want_min_dist=True)
+        v2 = bp.is_valid(tq, tr, samples_per_env=S)
+        torch.cuda.synchronize()
+        assert np.array_equal(v.cpu().numpy(), ov) and np.array_equal(v2.cpu().numpy(), ov)
+        assert np.array_equal(_bits(md.cpu().numpy()), _bits(omd))
+    assert 0.02 < ov.mean() < 0.98
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_lift_can_mesh_pairs_decide(kernel, oracle_mod):
     """SawyerLiftObstacle: the can is a convex mesh.  Park it (random orientation) around the gripper / in the arm's

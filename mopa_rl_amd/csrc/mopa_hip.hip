@@ -1286,7 +1286,7 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
         unsigned long long *rows_cnt = nullptr;
         double *mesh_rows = nullptr;
         // rows the gate may hand over per launch (typically 1-2 % of the states have one): beyond it a state goes to the state list
-        const long long rows_cap = std::getenv("MOPA_MESH_ROWS_CAP") ? atoll(std::getenv("MOPA_MESH_ROWS_CAP")) : std::max<long long>(4096, (long long)N / 2);
+        const long long rows_cap = std::getenv("MOPA_MESH_ROWS_CAP") ? atoll(std::getenv("MOPA_MESH_ROWS_CAP")) : std::min<long long>(std::max<long long>(4096, (long long)N / 2), 1ll << 22);      // (at most 1 GiB of rows; beyond: the state list)
         if (S->use_v5 && !S->v5_cen_lds && S->n_mesh_gp > 0) {
             HIP_TRY(grow(S, sc.mesh_list, ((size_t)N + 2) * sizeof(long long)));
             rows_cnt = sc.mesh_list.as<unsigned long long>();

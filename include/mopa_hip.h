@@ -560,6 +560,14 @@ int mopa_ik_solve_batch(MopaIk *ik, int64_t E, double *qpos_dev /*[E,nq] in/out*
 int mopa_ik_site_pose_batch(MopaIk *ik, int64_t E, const double *qpos_dev /*[E,nq]*/, double *site_pos_dev /*[E,3]*/,
                             double *site_mat_dev /*[E,9]*/, void *stream);
 
+/* The IK problem of the MoPA + IK action space for E envs (MoPARolloutRunner._cart2dispalcement, rl/mopa_rollouts.py:87-99,681-696):
+ * target_cart = clip(site_pos + action_range * ac[:3], world box); target_quat (w, x, y, z) = mulQuat(q_site[(w, x, y, y)], ac[3:7] / |ac[3:7]|)
+ * with q_site the quaternion of the float32-rounded site matrix (util/env.py:mat2quat, w >= 0).  ac rows are ac_stride (>= 7) doubles apart;
+ * world_lo / world_hi: 3 HOST doubles each (env.min_world_size / max_world_size).  One launch, one lane per env. */
+int mopa_ik_targets_batch(MopaIk *ik, int64_t E, const double *site_pos_dev /*[E,3]*/, const double *site_mat_dev /*[E,9]*/,
+                          const double *ac_dev /*[E,ac_stride]*/, int64_t ac_stride, double action_range, const double *world_lo /*[3] host*/,
+                          const double *world_hi /*[3] host*/, double *target_cart_dev /*[E,3]*/, double *target_quat_dev /*[E,4]*/, void *stream);
+
 /* The straight-line pre-check of SACAgent.plan / simple_interpolate (rl/sac_agent.py:198-204, 236-272) for E envs: the line
  * cur -> target is cut into int(s) equal steps, s = max(1, max_j |diff_j| / (0.8 ac_scale)) over the arm joints qpos[:n_arm]
  * (= the scene's active joints), each interior state a running sum from cur and validated (env row = cur); traj[e] = the

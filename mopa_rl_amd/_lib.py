@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "mopa_planner_status", "mopa_debug_fk", "mopa_debug_pair_dist",
     "mopa_env_create", "mopa_env_destroy", "mopa_env_obs_dim", "mopa_env_action_dim", "mopa_env_step_batch", "mopa_env_exec_batch", "mopa_env_desired_batch",
     "mopa_env_attach_dynamics", "mopa_env_attach_contacts", "mopa_env_set_contact_stats", "mopa_rollout_stage", "mopa_rollout_pool_pick", "mopa_rollout_step_size", "mopa_ct_desc_size", "mopa_env_contact_arena", "mopa_env_dyn_dofs", "mopa_env_dyn_qvel_width", "mopa_env_dyn_forward_batch", "mopa_env_dyn_substeps_batch", "mopa_env_step_dyn_batch",
-    "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch",
+    "mopa_ik_create", "mopa_ik_destroy", "mopa_ik_solve_batch", "mopa_ik_site_pose_batch", "mopa_ik_targets_batch",
     "mopa_paths_unwrap_batch", "mopa_paths_unwrap_seam_batch", "mopa_paths_walk_batch", "mopa_paths_assemble_batch", "mopa_interpolate_batch",
 ]
 
@@ -203,6 +203,7 @@ def lib() -> C.CDLL:
     L.mopa_ik_solve_batch.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_double, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
                                       vp, vp, vp, vp]
     L.mopa_ik_site_pose_batch.argtypes = [vp, C.c_int64, vp, vp, vp, vp]
+    L.mopa_ik_targets_batch.argtypes = [vp, C.c_int64, vp, vp, vp, C.c_int64, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double), vp, vp, vp]
     L.mopa_scene_valid_kernel.argtypes = [vp, C.c_int64, C.c_char_p, C.c_int32]
     i32, i64, f64 = C.c_int32, C.c_int64, C.c_double
     L.mopa_paths_unwrap_batch.argtypes = [C.c_int, i64, i32, i32, vp, i32, vp, vp, vp, f64, i32, vp, vp, vp, vp, vp, vp, vp, vp]

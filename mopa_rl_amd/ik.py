@@ -64,6 +64,26 @@ class BatchIK:
         _lib.check(_lib.lib().mopa_ik_site_pose_batch(self._h, E, _ptr(qpos), _ptr(pos), _ptr(mat), _stream_handle(stream)))
         return pos, mat
 
+    def targets(self, site_pos, site_mat, ac, action_range: float, world_lo, world_hi, stream=None):
+        """The IK problem of the MoPA + IK action space for E envs in ONE launch (`MoPARolloutRunner._cart2dispalcement`,
+        rl/mopa_rollouts.py:87-99,681-696): (target_cart [E,3], target_quat [E,4] wxyz) from the site pose and the policy's action rows
+        ac [E, >= 7] (Cartesian displacement + rotation quaternion); world_lo / world_hi: 3 floats each."""
+        import ctypes as C
+        torch = _torch()
+        E = site_pos.shape[0]
+        if ac.dim() != 2 or ac.shape[0] != E or ac.shape[1] < 7 or ac.stride(1) != 1 or ac.dtype != torch.float64 or not ac.is_cuda:
+            raise _lib.MopaError("ac must be a float64 GPU tensor [E, >= 7] with unit column stride")
+        for t, name in ((site_pos, "site_pos"), (site_mat, "site_mat")):
+            if t.dtype != torch.float64 or not t.is_cuda or not t.is_contiguous():
+                raise _lib.MopaError(f"{name} must be a contiguous float64 GPU tensor")
+        cart = torch.empty(E, 3, dtype=torch.float64, device=site_pos.device)
+        quat = torch.empty(E, 4, dtype=torch.float64, device=site_pos.device)
+        lo = (C.c_double * 3)(*[float(x) for x in world_lo])
+        hi = (C.c_double * 3)(*[float(x) for x in world_hi])
+        _lib.check(_lib.lib().mopa_ik_targets_batch(self._h, E, _ptr(site_pos), _ptr(site_mat), _ptr(ac), int(ac.stride(0)), float(action_range),
+                                                    lo, hi, _ptr(cart), _ptr(quat), _stream_handle(stream)))
+        return cart, quat
+
     def solve(self, qpos, target_pos, target_quat=None, max_steps: int = 100, rot_weight: float = 1.0, tol: float = 1e-14,
               max_update_norm: float = 2.0, progress_thresh: float = 20.0, regularization_strength: float = 3e-2, stream=None) -> IKResult:
         """qpos [E, nq] (updated in place), target_pos [E, 3], target_quat [E, 4] wxyz or None: contiguous float64 GPU tensors.
@@ -76,9 +96,10 @@ class BatchIK:
         E = qpos.shape[0]
         if target_pos.shape[0] != E or (target_quat is not None and target_quat.shape[0] != E):
             raise _lib.MopaError("qpos and targets disagree on E")
-        err = torch.zeros(E, dtype=torch.float64, device=qpos.device)
-        steps = torch.zeros(E, dtype=torch.int32, device=qpos.device)
-        succ = torch.zeros(E, dtype=torch.uint8, device=qpos.device)
+        # (the kernel writes all three for every row: no fill launches)
+        err = torch.empty(E, dtype=torch.float64, device=qpos.device)
+        steps = torch.empty(E, dtype=torch.int32, device=qpos.device)
+        succ = torch.empty(E, dtype=torch.uint8, device=qpos.device)
         _lib.check(_lib.lib().mopa_ik_solve_batch(self._h, E, _ptr(qpos), _ptr(target_pos),
                                                   _ptr(target_quat) if target_quat is not None else None, float(rot_weight),
                                                   int(max_steps), float(tol), float(max_update_norm), float(progress_thresh),

@@ -240,6 +240,33 @@ def seam_steps_np(P, idx):
 
 
 
+def ik_targets_torch(site_pos, site_mat, ac, action_range, world_lo, world_hi):
+    """The IK problem of `ik_displacement` as array operations (what `BatchIK.targets` computes in one launch): returns (target_cart, target_quat)."""
+    torch = _torch()
+    lo = torch.tensor(world_lo, dtype=torch.float64, device=ac.device)
+    hi = torch.tensor(world_hi, dtype=torch.float64, device=ac.device)
+    target_cart = torch.minimum(torch.maximum(site_pos + action_range * ac[:, :3], lo), hi).contiguous()
+    m = site_mat.to(torch.float32).to(torch.float64)                      # np.array(rmat, dtype=np.float32)
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = (m[:, i, j] for i in range(3) for j in range(3))
+    tr = m00 + m11 + m22
+    # closed-form quaternion, branch on the largest of (trace, m00, m11, m22) for conditioning
+    qw = torch.stack([1.0 + tr, m21 - m12, m02 - m20, m10 - m01], dim=1)
+    qx = torch.stack([m21 - m12, 1.0 + m00 - m11 - m22, m01 + m10, m02 + m20], dim=1)
+    qy = torch.stack([m02 - m20, m01 + m10, 1.0 - m00 + m11 - m22, m12 + m21], dim=1)
+    qz = torch.stack([m10 - m01, m02 + m20, m12 + m21, 1.0 - m00 - m11 + m22], dim=1)
+    pick = torch.stack([tr, m00, m11, m22], dim=1).argmax(dim=1)
+    q = torch.stack([qw, qx, qy, qz], dim=1)[torch.arange(len(m), device=m.device), pick]      # (w, x, y, z), unnormalised
+    q = q / q.norm(dim=1, keepdim=True)
+    q = torch.where(q[:, :1] < 0, -q, q)
+    tq = torch.stack([q[:, 0], q[:, 1], q[:, 2], q[:, 2]], dim=1)                               # [[3, 0, 1, 1]] of (x, y, z, w)
+    aq = ac[:, 3:7] / ac[:, 3:7].norm(dim=1, keepdim=True)
+    aw, ax, ay, az = tq.unbind(1)
+    bw, bx, by, bz = aq.unbind(1)
+    target_quat = torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                               aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], dim=1).contiguous()
+    return target_cart, target_quat
+
+
 class BatchMoPARollout:
     def reuse_transitions(self, out, rng, max_reuse_data: int = 30):
         """`reuse_transitions` on a recorded step of this rollout, with the env's gripper joint supplied where its action has
@@ -336,25 +363,9 @@ class BatchMoPARollout:
         torch = _torch()
         cfg = self.cfg
         site_pos, site_mat = self.ik.site_pose(cur.contiguous())
-        target_cart = torch.minimum(torch.maximum(site_pos + cfg.action_range * ac[:, :3], self._world_lo), self._world_hi).contiguous()
-        m = site_mat.to(torch.float32).to(torch.float64)                      # np.array(rmat, dtype=np.float32)
-        m00, m01, m02, m10, m11, m12, m20, m21, m22 = (m[:, i, j] for i in range(3) for j in range(3))
-        tr = m00 + m11 + m22
-        # closed-form quaternion, branch on the largest of (trace, m00, m11, m22) for conditioning
-        qw = torch.stack([1.0 + tr, m21 - m12, m02 - m20, m10 - m01], dim=1)
-        qx = torch.stack([m21 - m12, 1.0 + m00 - m11 - m22, m01 + m10, m02 + m20], dim=1)
-        qy = torch.stack([m02 - m20, m01 + m10, 1.0 - m00 + m11 - m22, m12 + m21], dim=1)
-        qz = torch.stack([m10 - m01, m02 + m20, m12 + m21, 1.0 - m00 - m11 + m22], dim=1)
-        pick = torch.stack([tr, m00, m11, m22], dim=1).argmax(dim=1)
-        q = torch.stack([qw, qx, qy, qz], dim=1)[torch.arange(len(m), device=m.device), pick]      # (w, x, y, z), unnormalised
-        q = q / q.norm(dim=1, keepdim=True)
-        q = torch.where(q[:, :1] < 0, -q, q)
-        tq = torch.stack([q[:, 0], q[:, 1], q[:, 2], q[:, 2]], dim=1)                               # [[3, 0, 1, 1]] of (x, y, z, w)
-        aq = ac[:, 3:7] / ac[:, 3:7].norm(dim=1, keepdim=True)
-        aw, ax, ay, az = tq.unbind(1)
-        bw, bx, by, bz = aq.unbind(1)
-        target_quat = torch.stack([aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
-                                   aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw], dim=1).contiguous()
+        # (one launch; the module's `ik_targets_torch` is the array-operation form it replaced -- ~70 elementwise launches per call -- kept as
+        #  the checker of tests/test_gpu_ik.py)
+        target_cart, target_quat = self.ik.targets(site_pos, site_mat, ac, cfg.action_range, cfg.min_world_size, cfg.max_world_size)
         q_ik = cur.clone()
         self.ik.solve(q_ik, target_cart, target_quat, max_steps=100, tol=1e-2)
         arm_t = torch.minimum(torch.maximum(q_ik[:, :self.n], self._ik_lo), self._ik_hi)

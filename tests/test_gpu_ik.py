@@ -163,3 +163,44 @@ def test_ik_equals_reference_qpos_from_site_pose(env, tag):
         assert np.array_equal(r.steps.cpu().numpy(), G[f"{tag}_steps"][sel])
         assert np.array_equal(r.success.cpu().numpy().astype(np.int64), G[f"{tag}_success"][sel])
     assert 0 < G[f"{tag}_success"].sum() < len(uq) and uq.sum() > 20
+
+
+def test_ik_targets_kernel_equals_the_array_operation_form():
+    """`BatchIK.targets` (k_ik_targets: the IK problem of the MoPA + IK action space in one launch, `_cart2dispalcement`,
+    rl/mopa_rollouts.py:87-99,681-696) against `rollout.ik_targets_torch`, the ~70 elementwise torch operations it replaced: arm poses
+    all over the joint box (every branch of the matrix -> quaternion form occurs), action rows with a gripper column behind the seven.  The
+    Cartesian target is identical; the quaternion agrees to an ulp or two (torch's `norm` reduction sums four squares in its own order)."""
+    import torch
+    from mopa_rl_amd.ik import BatchIK
+    from mopa_rl_amd.rollout import RolloutConfig, ik_targets_torch
+    from mopa_rl_amd.scene import default_qpos, planner_inputs
+    env = "SawyerAssemblyObstacle-v0"
+    pi = planner_inputs(env)
+    m = pi.model
+    ik = BatchIK(m, "grip_site", list(pi.spec.robot_joints))
+    E = 6000
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    lo = torch.tensor(np.asarray(pi.jnt_minimum, dtype=np.float64), device="cuda")
+    hi = torch.tensor(np.asarray(pi.jnt_maximum, dtype=np.float64), device="cuda")
+    q = torch.tensor(default_qpos(env, m), device="cuda").repeat(E, 1)
+    q[:, :7] = lo + (hi - lo) * torch.rand(E, 7, generator=g, dtype=torch.float64, device="cuda")
+    ac_full = torch.rand(E, 9, generator=g, dtype=torch.float64, device="cuda") * 2 - 1
+    ac = ac_full[:, :8]                                            # rows 9 doubles apart, 8 columns seen: a strided view
+    cfg = RolloutConfig()
+    # a world box that clips some targets
+    wl, wh = (-0.3, -0.4, 0.8), (0.9, 0.5, 1.3)
+    pos, mat = ik.site_pose(q)
+    cart, quat = ik.targets(pos, mat, ac, cfg.action_range, wl, wh)
+    cart_t, quat_t = ik_targets_torch(pos, mat, ac, cfg.action_range, wl, wh)
+    torch.cuda.synchronize()
+    assert torch.equal(cart, cart_t)
+    assert 0.02 < float(((cart == torch.tensor(wl, device="cuda")) | (cart == torch.tensor(wh, device="cuda"))).any(dim=1).double().mean()) < 0.98
+    d = (quat - quat_t).abs().max().item()
+    assert d <= 2e-15, d
+    # every branch of the closed form was taken somewhere
+    m32 = mat.to(torch.float32).to(torch.float64)
+    pick = torch.stack([m32[:, 0, 0] + m32[:, 1, 1] + m32[:, 2, 2], m32[:, 0, 0], m32[:, 1, 1], m32[:, 2, 2]], dim=1).argmax(dim=1)
+    assert set(pick.cpu().numpy().tolist()) == {0, 1, 2, 3}
+    with pytest.raises(Exception):
+        ik.targets(pos, mat, ac[:, :6], cfg.action_range, wl, wh)

@@ -1742,27 +1742,30 @@ void orc_env_step_batch(const OrcScene *s, const OrcEnvDesc *d, int64_t E, doubl
  * restatement uses an unpivoted Cholesky factorisation in a fixed operation order (shared with the HIP kernel). */
 #define ORC_IK_MAXJ 8
 
+/* (round 6: ONE division per pivot -- inv[j] = 1 / L[j][j] -- and products with it where 44 divisions stood: the kernel's iteration is a chain
+ * of dependent operations, a division costs a dozen of them.  Results move by ulps; the reference's own solve is LAPACK LU anyway.) */
 static void ik_chol_solve(double H[ORC_IK_MAXJ][ORC_IK_MAXJ], const double *g, double *x) {
-    double L[ORC_IK_MAXJ][ORC_IK_MAXJ], y[ORC_IK_MAXJ];
+    double L[ORC_IK_MAXJ][ORC_IK_MAXJ], y[ORC_IK_MAXJ], inv[ORC_IK_MAXJ];
     for (int j = 0; j < ORC_IK_MAXJ; j++) {
         double d = H[j][j];
         for (int k = 0; k < j; k++) d = fma(-L[j][k], L[j][k], d);
         L[j][j] = sqrt(d);
+        inv[j] = 1.0 / L[j][j];
         for (int i = j + 1; i < ORC_IK_MAXJ; i++) {
             double s = H[i][j];
             for (int k = 0; k < j; k++) s = fma(-L[i][k], L[j][k], s);
-            L[i][j] = s / L[j][j];
+            L[i][j] = s * inv[j];
         }
     }
     for (int i = 0; i < ORC_IK_MAXJ; i++) {
         double s = g[i];
         for (int k = 0; k < i; k++) s = fma(-L[i][k], y[k], s);
-        y[i] = s / L[i][i];
+        y[i] = s * inv[i];
     }
     for (int i = ORC_IK_MAXJ - 1; i >= 0; i--) {
         double s = y[i];
         for (int k = i + 1; k < ORC_IK_MAXJ; k++) s = fma(-L[k][i], x[k], s);
-        x[i] = s / L[i][i];
+        x[i] = s * inv[i];
     }
 }
 

@@ -411,14 +411,21 @@ template <bool WANT_MD, bool MESH>
 __global__ __launch_bounds__(kBlock) void k_is_valid(SceneHdr h, const double *__restrict__ g_dbl, const int32_t *__restrict__ g_int,
                                                       const double *__restrict__ q_active, const double *__restrict__ qpos_env,
                                                       long long N, long long samples_per_env, unsigned char *__restrict__ valid,
-                                                      double *__restrict__ min_dist) {
+                                                      double *__restrict__ min_dist, const int *__restrict__ env_idx /* nullable: env row of every state */,
+                                                      const long long *__restrict__ n_dev /* nullable: the state count lives on the device (<= N) */,
+                                                      long long n_small /* with n_dev: this launch serves counts below it only (the lane-per-state launch behind it the others) */) {
+    if (n_dev) {
+        const long long nd = *n_dev;
+        if (nd >= n_small) return;
+        if (nd < N) N = nd;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     LdsView v = make_view(h, smem);
     stage_scene(h, g_dbl, g_int, const_cast<double *>(v.dbl), const_cast<int *>(v.ints));
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const long long stride = (long long)gridDim.x * kWavesPerBlock;
     for (long long s = (long long)blockIdx.x * kWavesPerBlock + wave; s < N; s += stride) {
-        long long env = s / samples_per_env;
+        long long env = env_idx ? (long long)env_idx[s] : s / samples_per_env;
         wave_load_state(h, v, lane, q_active + s * h.na, qpos_env + env * h.nq);
         wave_fk(h, v, lane);
         double md;
@@ -1252,7 +1259,19 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
     // (tools/crossover.py): 8192 states 155 vs 171 us, 12288 states 202 vs 168 us  =>  ~36 states per CU.
     const int64_t v2_min = S->v2_forced ? 64 : std::max<int64_t>(64, (int64_t)S->n_cu * 36);
     if (n_dev && !(S->use_v2 && S->use_v5)) return fail(MOPA_ERR_UNSUPPORTED, "a device-side state count needs the lane-per-state kernel");
-    if (S->use_v2 && (N >= v2_min || env_idx || n_dev)) {
+    // Small batches with explicit env rows or a device-side count used to be sent to the lane-per-state kernel regardless -- at the latency of
+    // one 64-state tile (133 us on Push, 289 us on Assembly) for a few hundred states.  The wave-per-state kernel takes env_idx / n_dev too now;
+    // a batch whose count is only known on the device and whose WORST CASE is large gets both launches: each reads the count and one of them
+    // leaves at once (the wave-per-state one if the count reached v2_min, the lane-per-state one below it).
+    auto kern1 = S->hdr.has_mesh ? (min_dist ? k_is_valid<true, true> : k_is_valid<false, true>)
+                                 : (min_dist ? k_is_valid<true, false> : k_is_valid<false, false>);
+    long long n_small = 0;         // lane-per-state launch: counts below it are the other launch's
+    if (n_dev && !S->v2_forced && N >= v2_min && !std::getenv("MOPA_NO_DUAL_DISPATCH")) {
+        n_small = v2_min;
+        hipLaunchKernelGGL(kern1, dim3(grid_for(S, v2_min)), block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
+                           (long long)samples_per_env, valid, min_dist, env_idx, n_dev, n_small);
+    }
+    if (S->use_v2 && (N >= v2_min || ((env_idx || n_dev) && S->v2_forced))) {
         // one lane per state, 64-state tiles; 2 workgroups per CU keep the pose slab small and L2 resident
         int64_t tiles = (N + 63) / 64;
         int64_t blocks = std::min<int64_t>((tiles + kWavesPerBlock - 1) / kWavesPerBlock, (int64_t)S->n_cu * 2);
@@ -1309,7 +1328,7 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
             if (min_dist) hk.v5_ent_cap = S->v5_ent_cap_md;
             hipLaunchKernelGGL(k5, grid, block, min_dist ? S->v5_lds_bytes_md : S->v5_lds_bytes, st, hk, S->d_dbl, S->d_int, S->d_gp_tab, q_active, qpos_env,
                                (long long)N, (long long)samples_per_env, valid, min_dist, d_slab, env_idx, sc.mpr.as<double>(), mesh_list, sc.cen.as<float>(),
-                               n_dev, d_ctr, mesh_list ? mesh_rows : nullptr, rows_cap, rows_cnt);
+                               n_dev, d_ctr, mesh_list ? mesh_rows : nullptr, rows_cap, rows_cnt, n_small);
             if (mesh_list && mesh_rows) {
                 auto kr = min_dist ? k_mesh_rows<true> : k_mesh_rows<false>;
                 // (159 registers: three waves per SIMD -- the rows are latency chains, so all the slots are offered; idle waves leave at once)
@@ -1350,12 +1369,9 @@ static int launch_is_valid(MopaScene *S, const double *q_active, const double *q
 #endif
         return MOPA_OK;
     }
-    if (env_idx) return fail(MOPA_ERR_UNSUPPORTED, "explicit env indices need the lane-per-state kernels");
     dim3 grid(grid_for(S, N));
-    auto kern = S->hdr.has_mesh ? (min_dist ? k_is_valid<true, true> : k_is_valid<false, true>)
-                                : (min_dist ? k_is_valid<true, false> : k_is_valid<false, false>);
-    hipLaunchKernelGGL(kern, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
-                       (long long)samples_per_env, valid, min_dist);
+    hipLaunchKernelGGL(kern1, grid, block, S->lds_bytes, st, S->hdr, S->d_dbl, S->d_int, q_active, qpos_env, (long long)N,
+                       (long long)samples_per_env, valid, min_dist, env_idx, n_dev, (long long)(1ll << 62));
     HIP_TRY(hipGetLastError());
     return MOPA_OK;
 }

@@ -445,6 +445,22 @@ def test_pullback_kernel_equals_host_form(oracle_mod):
     want_t, want_n, want_v = handle_invalid_target_batch(bp, c, t, 0.02, 3)
     n = want_n.cpu().numpy()
     assert (n > 0).sum() > 30 and (~want_v.cpu().numpy()).sum() >= 0 and n.max() == 3
+    # A batch whose worst case is large (E x 100 candidate rows) but whose count, known on the device only, is small: the candidate rows
+    # then go through the wave-per-state kernel (both validity launches are enqueued, each reads the count, one leaves at once)
+    inv = np.where(n > 0)[0][:12]
+    tgt2 = cur.copy()
+    tgt2[inv] = tgt[inv]
+    t2 = torch.tensor(tgt2, device="cuda")
+    want_t, want_n, want_v = handle_invalid_target_batch(bp, c, t2, 0.02, 100)
+    os.environ["MOPA_PULLBACK"] = "batch"
+    try:
+        got_t, got_n, got_v = bp.pullback(c, t2, 0.02, 100)
+    finally:
+        del os.environ["MOPA_PULLBACK"]
+    assert np.array_equal(got_v.cpu().numpy().astype(bool), want_v.cpu().numpy())
+    assert np.array_equal(got_n.cpu().numpy().astype(np.int64), want_n.cpu().numpy())
+    assert np.array_equal(_bits(got_t.cpu().numpy()), _bits(want_t.cpu().numpy()))
+    assert len(inv) <= int((want_n.cpu().numpy() > 0).sum()) < 90        # (x 100 rows: below the 9216-state switch to the lane-per-state kernel)
 
 
 @pytest.mark.parametrize("env_name", ["SawyerPushObstacle-v0", "SawyerLiftObstacle-v0"])
